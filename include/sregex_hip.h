@@ -1,0 +1,121 @@
+/*
+ * sregex_hip.h — ADDITIVE device-resident, batched entry points (C ABI).
+ *
+ * The reference's executors take host pointers
+ * (sre_vm_pike_exec / sre_vm_thompson_exec, reference src/sregex/sregex.h:133-134,
+ * 147-148), so through them a GPU matcher is PCIe-bound.  These entry points
+ * are what a maintainer binds when the streams already live in HBM: many
+ * independent streams (one context each, reference README.markdown:376) are
+ * scanned in one call with the same compiled sre_program_t.  They replace, per
+ * stream, the call sequence
+ *     ctx = sre_vm_pike_create_ctx(pool, prog, ovector, ovecsize);   sre_vm_pike.c:94-145
+ *     rc  = sre_vm_pike_exec(ctx, stream, len, 1, NULL);             sre_vm_pike.c:148-689
+ * (resp. the Thompson pair, sre_vm_thompson.c:25-60 / :63-270), and for
+ * SRE_HIP_PIKE_COUNT the find-all iteration a caller writes around it
+ * (re-feeding from ovector[1]; sre_vm_pike.c:179-196, 624-628).
+ *
+ * Plain pointers and sizes only; no torch / C++ types.  See INTEGRATION.md for
+ * the C, ctypes and cgo-style bindings.
+ */
+#ifndef SREGEX_AMD_SREGEX_HIP_H
+#define SREGEX_AMD_SREGEX_HIP_H
+
+#include <sregex/sregex.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* what to compute per stream */
+enum {
+    SRE_HIP_THOMPSON   = 0,  /* match / no match                 (sre_vm_thompson_exec) */
+    SRE_HIP_PIKE_FIRST = 1,  /* first match: regex id + captures (sre_vm_pike_exec)     */
+    SRE_HIP_PIKE_COUNT = 2   /* iterate sre_vm_pike_exec from each match end: count     */
+};
+
+/* which device engine runs it */
+enum {
+    SRE_HIP_ENGINE_AUTO = 0, /* table-driven scanner when the program admits one  */
+    SRE_HIP_ENGINE_VM   = 1, /* exact bytecode VM kernel, one lane per stream     */
+    SRE_HIP_ENGINE_SCAN = 2  /* table-driven segment-parallel scanner, or fail    */
+};
+
+typedef struct sre_hip_scanner_s  sre_hip_scanner_t;
+
+/* number of HIP devices visible to this process (0 if none) */
+SRE_API int sre_hip_device_count(void);
+
+/* select the device used by subsequently created programs/scanners */
+SRE_API int sre_hip_set_device(int ordinal);
+
+/*
+ * Create a scanner for `prog`.  Owned by `pool` (freed by sre_destroy_pool).
+ * Returns NULL (with a diagnostic on stderr) when no HIP device is usable or
+ * when `engine` == SRE_HIP_ENGINE_SCAN and the program admits no table.
+ */
+SRE_API sre_hip_scanner_t *sre_hip_scanner_create(sre_pool_t *pool,
+    sre_program_t *prog, int mode, int engine);
+
+/* engine actually chosen: SRE_HIP_ENGINE_VM or SRE_HIP_ENGINE_SCAN */
+SRE_API int sre_hip_scanner_engine(sre_hip_scanner_t *sc);
+
+/*
+ * Per-stream result record, in sre_int_t units:
+ *     [0] rc     regex id (>= 0; SRE_OK for Thompson), SRE_DECLINED, SRE_ERROR
+ *     [1] count  matches found (COUNT mode; 0/1 otherwise)
+ *     [2..]      ovector of the (last) match, 2 * (max_ncaps + 1) slots,
+ *                absolute byte offsets, -1 = unset   (sre_vm_pike.c:945-989)
+ * sre_hip_scanner_result_slots() = 2 + 2 * (max_ncaps + 1).
+ */
+SRE_API size_t sre_hip_scanner_result_slots(sre_hip_scanner_t *sc);
+
+/*
+ * Enqueue the scan of `nstreams` device-resident streams on `hip_stream`
+ * (a hipStream_t, NULL = default stream).  `d_streams[i]` is a DEVICE pointer
+ * to `lens[i]` bytes; both arrays are HOST arrays.  Asynchronous: returns
+ * after the kernels are queued.  0 on success, -1 on failure.
+ */
+SRE_API int sre_hip_scan_enqueue(sre_hip_scanner_t *sc,
+    const void *const *d_streams, const size_t *lens, size_t nstreams,
+    void *hip_stream);
+
+/*
+ * Wait for the last enqueued scan and copy its records to `results`
+ * (host, nstreams * result_slots entries).  0 on success.
+ */
+SRE_API int sre_hip_scan_results(sre_hip_scanner_t *sc, sre_int_t *results);
+
+/* convenience: enqueue + results */
+SRE_API int sre_hip_scan_batch(sre_hip_scanner_t *sc,
+    const void *const *d_streams, const size_t *lens, size_t nstreams,
+    sre_int_t *results, void *hip_stream);
+
+/* ---- helpers for drivers that have no HIP runtime binding of their own ---- */
+
+/* device buffer management (hipMalloc / hipFree / hipMemcpy) */
+SRE_API void *sre_hip_alloc(size_t bytes);
+SRE_API void  sre_hip_free(void *d_ptr);
+SRE_API int   sre_hip_upload(void *d_dst, const void *h_src, size_t bytes);
+SRE_API int   sre_hip_download(void *h_dst, const void *d_src, size_t bytes);
+SRE_API int   sre_hip_synchronize(void *hip_stream);
+
+/*
+ * Fill d_dst[0..n) with the reference benchmark stream, generated on device
+ * (bench/gen-data.pl:9 restated):  byte i is "abccc"[i % 5] for
+ * i < n - tail_len, and the last tail_len bytes are `tail`.  With
+ * n = 5 * k + tail_len this is exactly  "abccc" x k . tail.
+ */
+SRE_API int sre_hip_gen_data(void *d_dst, size_t n, const void *h_tail,
+    size_t tail_len, void *hip_stream);
+
+/*
+ * Plain streaming read of n bytes (16 B per lane, grid-stride) — the box's
+ * measured HBM read ceiling, reported next to the scanner's rate.  Writes one
+ * checksum word per workgroup into an internal buffer.  Asynchronous.
+ */
+SRE_API int sre_hip_read_ceiling(const void *d_src, size_t n, void *hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

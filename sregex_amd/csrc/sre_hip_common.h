@@ -1,0 +1,82 @@
+/*
+ * sre_hip_common.h — layouts shared by the host HIP layer and the kernels.
+ *
+ * Device program image ("blob"): the sre_program_t flattened for the GPU.
+ *   - instructions are 16-byte records addressed by index (no pointers, no
+ *     mutable tags: the reference's per-instruction generation tag,
+ *     sre_vm_bytecode.h:51, becomes per-stream state),
+ *   - every IN/NOTIN range list (sre_vm_pike.c:336-346 walks it per byte) is
+ *     pre-expanded into a 256-bit membership bitmap, NOTIN already negated,
+ *     identical bitmaps shared.
+ */
+#ifndef SRE_HIP_COMMON_H
+#define SRE_HIP_COMMON_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#define SRE_DEV_ALIGN(n)  (((n) + 15) & ~(size_t) 15)
+
+#ifdef __HIPCC__
+#   define SRE_HD __host__ __device__
+#else
+#   define SRE_HD
+#endif
+
+typedef struct {
+    uint8_t   opcode;      /* SRE_OP_* */
+    uint8_t   ch;          /* CHAR byte / ASSERT bit */
+    uint16_t  cls;         /* IN/NOTIN: class bitmap index */
+    uint32_t  x;           /* SPLIT/JMP */
+    uint32_t  y;           /* SPLIT */
+    uint32_t  arg;         /* SAVE slot / MATCH regex id */
+} sre_dev_insn_t;
+
+typedef struct {
+    uint32_t  len;         /* instructions */
+    uint32_t  nslots;      /* capture slots of the internal vector */
+    uint32_t  nregexes;
+    uint32_t  nthreads;    /* list-able instructions */
+    uint32_t  nclasses;
+    uint32_t  pad[3];
+    /* followed, 16-B aligned, by:
+     *   sre_dev_insn_t insns[len]
+     *   uint32_t       classes[nclasses][8]
+     *   uint32_t       multi_ncaps[nregexes]
+     */
+} sre_dev_prog_hdr_t;
+
+SRE_HD static inline size_t sre_dev_prog_insns_off(void) { return SRE_DEV_ALIGN(sizeof(sre_dev_prog_hdr_t)); }
+SRE_HD static inline size_t sre_dev_prog_classes_off(uint32_t len) {
+    return sre_dev_prog_insns_off() + SRE_DEV_ALIGN((size_t) len * sizeof(sre_dev_insn_t));
+}
+SRE_HD static inline size_t sre_dev_prog_ncaps_off(uint32_t len, uint32_t nclasses) {
+    return sre_dev_prog_classes_off(len) + SRE_DEV_ALIGN((size_t) nclasses * 32);
+}
+SRE_HD static inline size_t sre_dev_prog_bytes(uint32_t len, uint32_t nclasses, uint32_t nregexes) {
+    return sre_dev_prog_ncaps_off(len, nclasses) + SRE_DEV_ALIGN((size_t) nregexes * 4);
+}
+
+/* ---- per-stream request / result of one exec() on the exact VM kernels ---- */
+
+typedef struct {
+    const uint8_t *input;       /* device pointer, or NULL when size <= 8 and   */
+    uint64_t       inline_bytes;/* the chunk travels in the kernel argument    */
+    uint64_t       size;
+    uint32_t       eof;
+    uint32_t       want_pending;/* caller passed a pending_matched pointer     */
+    void          *ctx;         /* device stream state, see sre_hip_vm.hip     */
+    void          *result;      /* sre_dev_result_t + ovector, host-visible    */
+    uint64_t       ovec_slots;  /* caller ovector length in slots              */
+} sre_dev_req_t;
+
+typedef struct {
+    int64_t   rc;               /* regex id >= 0, SRE_AGAIN, SRE_DECLINED, SRE_ERROR */
+    int64_t   has_pending;
+    int64_t   pending[2];
+    int64_t   consumed;         /* bytes of this chunk the VM looked at */
+    int64_t   pad[3];
+    /* int64_t ovector[ovec_slots] follows */
+} sre_dev_result_t;
+
+#endif

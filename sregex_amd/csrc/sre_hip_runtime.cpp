@@ -1,0 +1,127 @@
+/*
+ * sre_hip_runtime.cpp — device discovery, loud failure, and the device image
+ * of a compiled program.
+ */
+#include "sre_hip_runtime.h"
+#include "sre_dfa.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+extern "C" int
+sre_hip_fail(const char *what, hipError_t err)
+{
+    fprintf(stderr, "[sregex-hip] %s failed: %s\n", what, hipGetErrorString(err));
+    return -1;
+}
+
+extern "C" int
+sre_hip_ready(void)
+{
+    static int state = 0;   /* 0 unknown, 1 ok, -1 unusable */
+    if (state == 0) {
+        int        n = 0;
+        hipError_t e = hipGetDeviceCount(&n);
+        if (e != hipSuccess || n <= 0) {
+            fprintf(stderr,
+                    "[sregex-hip] no usable HIP device (%s): the matcher runs on "
+                    "gfx950 only, there is no CPU fallback\n",
+                    e != hipSuccess ? hipGetErrorString(e) : "0 devices");
+            state = -1;
+        } else {
+            state = 1;
+        }
+    }
+    return state == 1 ? 0 : -1;
+}
+
+static void
+free_program_image(void *data)
+{
+    sre_hip_program_s *dp = static_cast<sre_hip_program_s *>(data);
+    if (dp->d_blob) {
+        (void) hipFree(dp->d_blob);
+    }
+    sre_dfa_free(dp->dfa_pike);
+    sre_dfa_free(dp->dfa_thompson);
+    free(dp);
+}
+
+extern "C" struct sre_hip_program_s *
+sre_hip_program_get(sre_program_t *prog)
+{
+    if (prog->dev) {
+        return prog->dev;
+    }
+    if (sre_hip_ready() != 0) {
+        return NULL;
+    }
+
+    /* distinct 256-bit membership bitmaps, NOTIN stored negated */
+    std::vector<uint32_t> classes;
+    std::vector<uint16_t> cls_of(prog->len, 0);
+    for (uint32_t pc = 0; pc < prog->len; pc++) {
+        const sre_insn_t &in = prog->insns[pc];
+        if (in.opcode != SRE_OP_IN && in.opcode != SRE_OP_NOTIN) continue;
+        uint32_t bm[8] = {0};
+        for (unsigned c = 0; c < 256; c++) {
+            int hit = sre_in_ranges(&prog->ranges[in.x], in.nranges, c);
+            if (hit == (in.opcode == SRE_OP_IN)) bm[c >> 5] |= 1u << (c & 31);
+        }
+        size_t n = classes.size() / 8, k;
+        for (k = 0; k < n; k++) {
+            if (memcmp(&classes[k * 8], bm, 32) == 0) break;
+        }
+        if (k == n) classes.insert(classes.end(), bm, bm + 8);
+        if (k > 0xffff) {
+            fprintf(stderr, "[sregex-hip] too many distinct character classes\n");
+            return NULL;
+        }
+        cls_of[pc] = (uint16_t) k;
+    }
+    uint32_t nclasses = (uint32_t) (classes.size() / 8);
+
+    size_t               bytes = sre_dev_prog_bytes(prog->len, nclasses, prog->nregexes);
+    std::vector<uint8_t> img(bytes, 0);
+    sre_dev_prog_hdr_t  *h = reinterpret_cast<sre_dev_prog_hdr_t *>(img.data());
+    h->len = prog->len;
+    h->nslots = prog->nslots;
+    h->nregexes = prog->nregexes;
+    h->nthreads = prog->nthreads;
+    h->nclasses = nclasses;
+    sre_dev_insn_t *di = reinterpret_cast<sre_dev_insn_t *>(img.data() + sre_dev_prog_insns_off());
+    for (uint32_t pc = 0; pc < prog->len; pc++) {
+        const sre_insn_t &in = prog->insns[pc];
+        di[pc].opcode = in.opcode;
+        di[pc].ch = in.ch;
+        di[pc].cls = cls_of[pc];
+        di[pc].x = in.x;
+        di[pc].y = in.y;
+        di[pc].arg = in.arg;
+    }
+    if (nclasses) {
+        memcpy(img.data() + sre_dev_prog_classes_off(prog->len), classes.data(),
+               (size_t) nclasses * 32);
+    }
+    memcpy(img.data() + sre_dev_prog_ncaps_off(prog->len, nclasses), prog->multi_ncaps,
+           (size_t) prog->nregexes * 4);
+
+    sre_hip_program_s *dp = static_cast<sre_hip_program_s *>(calloc(1, sizeof(*dp)));
+    if (dp == NULL) return NULL;
+    SRE_HIP_TRY(hipGetDevice(&dp->device));
+    SRE_HIP_TRY(hipMalloc(&dp->d_blob, bytes));
+    SRE_HIP_TRY(hipMemcpy(dp->d_blob, img.data(), bytes, hipMemcpyHostToDevice));
+    dp->blob_bytes = bytes;
+    dp->nclasses = nclasses;
+    dp->pike_layout = sre_pike_layout(prog->len, prog->nthreads, prog->nslots);
+    dp->thompson_layout = sre_thompson_layout(prog->len);
+    if (sre_pool_add_cleanup(prog->pool, free_program_image, dp) != SRE_OK) goto hip_failed;
+    prog->dev = dp;
+    return dp;
+
+hip_failed:
+    if (dp->d_blob) (void) hipFree(dp->d_blob);
+    free(dp);
+    return NULL;
+}

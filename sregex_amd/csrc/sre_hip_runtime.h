@@ -1,0 +1,52 @@
+/*
+ * sre_hip_runtime.h — host-side HIP plumbing shared by the compat API
+ * (sre_vm_api.cpp) and the batched device API (sre_hip_batch.cpp).
+ */
+#ifndef SRE_HIP_RUNTIME_H
+#define SRE_HIP_RUNTIME_H
+
+#include <hip/hip_runtime.h>
+#include "sre_program.h"
+#include "sre_hip_common.h"
+#include "sre_hip_vm.h"
+
+struct sre_dfa_s;           /* sre_dfa.h */
+
+/* device images of one compiled program; owned by the program's pool */
+struct sre_hip_program_s {
+    int         device;
+    void       *d_blob;         /* sre_dev_prog_hdr_t + arrays */
+    size_t      blob_bytes;
+    uint32_t    nclasses;
+    sre_pike_layout_t      pike_layout;
+    sre_thompson_layout_t  thompson_layout;
+    /* step automata for the scanner (NULL until first use / if not buildable) */
+    struct sre_dfa_s *dfa_pike;
+    struct sre_dfa_s *dfa_thompson;
+    int         dfa_pike_tried, dfa_thompson_tried;
+};
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* 0 when a HIP device is usable; otherwise prints ONE diagnostic to stderr and
+ * returns -1.  There is no CPU matcher to fall back to. */
+SRE_NOAPI int sre_hip_ready(void);
+
+/* report a HIP failure loudly; returns -1 */
+SRE_NOAPI int sre_hip_fail(const char *what, hipError_t err);
+
+/* build (once) and return the device image of `prog`, or NULL */
+SRE_NOAPI struct sre_hip_program_s *sre_hip_program_get(sre_program_t *prog);
+
+#define SRE_HIP_TRY(expr)                                                     \
+    do {                                                                      \
+        hipError_t e_ = (expr);                                               \
+        if (e_ != hipSuccess) { sre_hip_fail(#expr, e_); goto hip_failed; }   \
+    } while (0)
+
+#ifdef __cplusplus
+}
+#endif
+#endif

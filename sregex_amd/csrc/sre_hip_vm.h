@@ -1,0 +1,45 @@
+/*
+ * sre_hip_vm.h — host-visible interface of the exact VM kernels
+ * (sre_hip_vm.hip): per-stream state layouts and launchers.
+ */
+#ifndef SRE_HIP_VM_H
+#define SRE_HIP_VM_H
+
+#include <hip/hip_runtime.h>
+#include "sre_hip_common.h"
+
+/* byte offsets inside one Pike stream context (zero-filled == fresh) */
+typedef struct {
+    size_t   tags;          /* uint32_t[len + 1]     generation per instruction  */
+    size_t   nodes[2];      /* two thread lists, (nthreads + 1) nodes each        */
+    size_t   matched;       /* int64_t[nslots]       capture of the pending match */
+    size_t   work;          /* int64_t[nslots]       closure working vector       */
+    size_t   stack;         /* closure stack, len + 2 records                     */
+    size_t   total;
+    uint32_t node_bytes;    /* 16 + 8 * nslots                                    */
+} sre_pike_layout_t;
+
+typedef struct {
+    size_t   tags, list[2], stack, total;
+} sre_thompson_layout_t;
+
+__host__ __device__ sre_pike_layout_t sre_pike_layout(uint32_t len, uint32_t nthreads,
+    uint32_t nslots);
+__host__ __device__ sre_thompson_layout_t sre_thompson_layout(uint32_t len);
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+hipError_t sre_launch_pike_exec(const void *blob, const sre_dev_req_t *d_reqs,
+    uint32_t nreqs, hipStream_t stream);
+hipError_t sre_launch_thompson_exec(const void *blob, const sre_dev_req_t *d_reqs,
+    uint32_t nreqs, hipStream_t stream);
+/* whole-stream scan, one lane per stream; mode = SRE_HIP_THOMPSON / PIKE_FIRST / PIKE_COUNT */
+hipError_t sre_launch_vm_scan(const void *blob, int mode, const void *const *d_streams,
+    const uint64_t *d_lens, uint32_t nstreams, void *d_ctx, uint64_t ctx_stride,
+    int64_t *d_records, uint32_t ovec_slots, hipStream_t stream);
+#ifdef __cplusplus
+}
+#endif
+
+#endif

@@ -1,0 +1,816 @@
+/*
+ * sre_hip_vm.hip — the EXACT streaming VM kernels (gfx950).
+ *
+ * One lane owns one stream: it carries that stream's whole VM state (thread
+ * lists, per-thread capture vectors, generation tags) in HBM between exec()
+ * calls, so the chunked C API (AGAIN / pending matches / byte-at-a-time
+ * feeding) behaves exactly like the reference.  These kernels take EVERY
+ * program — look-ahead assertions, thousands of instructions, any number of
+ * threads — and are the semantic anchor of the device path; the throughput
+ * path for large streams is the table-driven scanner in sre_hip_scan.hip.
+ *
+ * What is mirrored (reference file:line):
+ *   pike_exec        sre_vm_pike.c:148-689     byte loop, MATCH cut-off, re-arm
+ *   pike_closure     sre_vm_pike.c:756-942     epsilon closure incl. the SPLIT
+ *                                              re-descent quirk (:774-784)
+ *   thompson_exec    sre_vm_thompson.c:63-270
+ *   thompson_closure sre_vm_thompson.c:273-345
+ * What is different by design:
+ *   - no recursion: the closure runs on an explicit stack whose RESTORE records
+ *     undo SAVEs, so capture vectors are plain per-thread values (no
+ *     ref-counted copy-on-write objects, sre_capture.c:20-85, and none of the
+ *     reference's capture leak);
+ *   - generation tags are per stream, the program image is read-only;
+ *   - the leading-byte skip (sre_vm_pike.c:256-309) is not replicated: it is a
+ *     result-neutral host optimisation.
+ */
+#include <hip/hip_runtime.h>
+#include "sre_hip_common.h"
+#include "sre_hip_vm.h"
+
+namespace {
+
+enum : uint8_t {
+    OP_CHAR = 1, OP_MATCH = 2, OP_JMP = 3, OP_SPLIT = 4, OP_ANY = 5, OP_SAVE = 6,
+    OP_IN = 7, OP_NOTIN = 8, OP_ASSERT = 9
+};
+enum : uint8_t {
+    AS_SMALL_Z = 0x01, AS_DOLLAR = 0x02, AS_BIG_B = 0x04, AS_SMALL_B = 0x08,
+    AS_BIG_A = 0x10, AS_CARET = 0x20
+};
+enum : int64_t { RC_OK = 0, RC_ERROR = -1, RC_AGAIN = -2, RC_DONE = -4, RC_DECLINED = -5 };
+
+struct Prog {
+    const sre_dev_prog_hdr_t *h;
+    const sre_dev_insn_t     *insns;
+    const uint32_t           *classes;
+    const uint32_t           *multi_ncaps;
+};
+
+__device__ inline Prog prog_view(const uint8_t *blob)
+{
+    Prog p;
+    p.h = reinterpret_cast<const sre_dev_prog_hdr_t *>(blob);
+    p.insns = reinterpret_cast<const sre_dev_insn_t *>(blob + sre_dev_prog_insns_off());
+    p.classes = reinterpret_cast<const uint32_t *>(blob + sre_dev_prog_classes_off(p.h->len));
+    p.multi_ncaps = reinterpret_cast<const uint32_t *>(
+        blob + sre_dev_prog_ncaps_off(p.h->len, p.h->nclasses));
+    return p;
+}
+
+__device__ inline bool is_word(unsigned c)
+{
+    return (c - '0' < 10u) || (c - 'A' < 26u) || (c - 'a' < 26u) || c == '_';
+}
+
+__device__ inline bool consumes(const Prog &P, const sre_dev_insn_t &in, unsigned c)
+{
+    switch (in.opcode) {
+    case OP_CHAR:  return c == in.ch;
+    case OP_ANY:   return true;
+    case OP_IN:
+    case OP_NOTIN: return (P.classes[in.cls * 8u + (c >> 5)] >> (c & 31u)) & 1u;
+    default:       return false;
+    }
+}
+
+/* chunk bytes: from HBM, or from the kernel argument for tiny chunks */
+struct Chunk {
+    const uint8_t *p;
+    uint64_t       inl;
+    __device__ inline unsigned at(int64_t i) const
+    {
+        return p ? p[i] : (unsigned) ((inl >> (8 * i)) & 0xff);
+    }
+};
+
+/* ======================================================================= Pike */
+
+constexpr uint32_t PIKE_MAGIC = 0x50494b45u;
+
+struct PikeHdr {
+    int64_t  processed_bytes;
+    int64_t  last_matched_pos;
+    int64_t  matched_regex_id;
+    uint32_t magic, tag;
+    uint32_t first_buf, eof, empty_capture, seen_newline, seen_word, has_matched;
+    uint32_t cur;                 /* which of the two lists is "current" */
+    int32_t  head[2], tail[2];
+    uint32_t used[2];
+    uint32_t pad;
+};
+
+struct Node {           /* followed by int64_t cap[nslots] */
+    uint32_t pc;
+    uint32_t seen_word;
+    int32_t  next;
+    int32_t  pad;
+};
+
+struct StackRec {
+    uint32_t a;         /* VISIT: pc   RESTORE: slot */
+    uint32_t restore;
+    int64_t  old;
+};
+
+}  // namespace
+
+__host__ __device__ sre_pike_layout_t
+sre_pike_layout(uint32_t len, uint32_t nthreads, uint32_t nslots)
+{
+    sre_pike_layout_t L;
+    size_t            off = SRE_DEV_ALIGN(sizeof(PikeHdr));
+    L.node_bytes = (uint32_t) (sizeof(Node) + (size_t) nslots * 8);
+    L.tags = off;       off += SRE_DEV_ALIGN((size_t) (len + 1) * 4);
+    L.nodes[0] = off;   off += SRE_DEV_ALIGN((size_t) (nthreads + 1) * L.node_bytes);
+    L.nodes[1] = off;   off += SRE_DEV_ALIGN((size_t) (nthreads + 1) * L.node_bytes);
+    L.matched = off;    off += SRE_DEV_ALIGN((size_t) (nslots + 1) * 8);
+    L.work = off;       off += SRE_DEV_ALIGN((size_t) (nslots + 1) * 8);
+    L.stack = off;      off += SRE_DEV_ALIGN((size_t) (len + 2) * sizeof(StackRec));
+    L.total = off;
+    return L;
+}
+
+__host__ __device__ sre_thompson_layout_t
+sre_thompson_layout(uint32_t len)
+{
+    sre_thompson_layout_t L;
+    size_t                off = 64;
+    L.tags = off;       off += SRE_DEV_ALIGN((size_t) (len + 1) * 4);
+    L.list[0] = off;    off += SRE_DEV_ALIGN((size_t) (len + 1) * 4);
+    L.list[1] = off;    off += SRE_DEV_ALIGN((size_t) (len + 1) * 4);
+    L.stack = off;      off += SRE_DEV_ALIGN((size_t) (len + 2) * 4);
+    L.total = off;
+    return L;
+}
+
+namespace {
+
+struct Pike {
+    Prog               P;
+    PikeHdr           *h;
+    uint32_t          *tags;
+    uint8_t           *nodes[2];
+    int64_t           *matched, *work;
+    StackRec          *stack;
+    uint32_t           node_bytes, nslots;
+    Chunk              in;
+
+    __device__ inline Node *node(int l, int32_t i) const
+    {
+        return reinterpret_cast<Node *>(nodes[l] + (size_t) i * node_bytes);
+    }
+    __device__ inline int64_t *cap(Node *n) const { return reinterpret_cast<int64_t *>(n + 1); }
+
+    __device__ inline void list_reset(int l)
+    {
+        h->head[l] = h->tail[l] = -1;
+        h->used[l] = 0;
+    }
+
+    /* append a thread carrying the working capture vector */
+    __device__ inline int32_t node_new(int l, uint32_t pc, uint32_t seen_word)
+    {
+        int32_t  i = (int32_t) h->used[l]++;
+        Node    *n = node(l, i);
+        int64_t *c = cap(n);
+        n->pc = pc;
+        n->seen_word = seen_word;
+        n->next = -1;
+        for (uint32_t k = 0; k < nslots; k++) c[k] = work[k];
+        return i;
+    }
+
+    /*
+     * Epsilon closure from `pc0` at chunk offset `pos` (sre_vm_pike.c:756-942).
+     * The capture vector of the source thread is in `work`; on return `work`
+     * is unchanged.  Threads are appended to the (head, tail) chain given by
+     * reference in list `l`.  from_loop == the reference's pcap != NULL.
+     */
+    __device__ int64_t closure(int l, int32_t &head, int32_t &tail, uint32_t pc0,
+                               int64_t pos, bool from_loop)
+    {
+        uint32_t sptr = 0;
+        uint32_t tag = h->tag;
+        bool     restart = true;
+        uint32_t pc = pc0;
+
+        for (;;) {
+            if (!restart) {
+                /* "return": unwind to the next pending SPLIT branch */
+                for (;;) {
+                    if (sptr == 0) return RC_OK;
+                    StackRec r = stack[--sptr];
+                    if (r.restore) {
+                        work[r.a] = r.old;
+                    } else {
+                        pc = r.a;
+                        break;
+                    }
+                }
+            }
+            restart = false;
+
+            /* follow one chain of tail calls */
+            for (;;) {
+                const sre_dev_insn_t in = P.insns[pc];
+                uint32_t             seen_word = 0;
+                bool                 list_it = false;
+
+                if (tags[pc] == tag) {
+                    /* :770-787 */
+                    if (in.opcode == OP_SPLIT && tags[in.y] != tag) {
+                        pc = in.y;
+                        continue;
+                    }
+                    break;
+                }
+                tags[pc] = tag;
+
+                switch (in.opcode) {
+                case OP_JMP:
+                    pc = in.x;
+                    continue;
+                case OP_SPLIT:
+                    stack[sptr++] = StackRec{in.y, 0u, 0};
+                    pc = in.x;
+                    continue;
+                case OP_SAVE:
+                    stack[sptr++] = StackRec{in.arg, 1u, work[in.arg]};
+                    work[in.arg] = h->processed_bytes + pos;
+                    pc = pc + 1;
+                    continue;
+                case OP_ASSERT:
+                    if (in.ch == AS_BIG_A) {
+                        if (pos || h->processed_bytes) break;
+                        pc = pc + 1;
+                        continue;
+                    }
+                    if (in.ch == AS_CARET) {
+                        if (pos == 0) {
+                            if (h->processed_bytes && !h->seen_newline) break;
+                        } else if (in_at(pos - 1) != '\n') {
+                            break;
+                        }
+                        pc = pc + 1;
+                        continue;
+                    }
+                    if (in.ch == AS_SMALL_B || in.ch == AS_BIG_B) {
+                        seen_word = pos == 0 ? 0u : (uint32_t) is_word(in_at(pos - 1));
+                    }
+                    list_it = true;
+                    break;
+                case OP_MATCH:
+                    h->last_matched_pos = work[1];
+                    if (from_loop) {
+                        /* :895-898 SRE_DONE: the capture becomes the match */
+                        for (uint32_t k = 0; k < nslots; k++) matched[k] = work[k];
+                        h->matched_regex_id = in.arg;
+                        /* undo pending SAVEs so `work` is the caller's again */
+                        while (sptr) {
+                            StackRec r = stack[--sptr];
+                            if (r.restore) work[r.a] = r.old;
+                        }
+                        return RC_DONE;
+                    }
+                    list_it = true;
+                    break;
+                default:
+                    list_it = true;
+                    break;
+                }
+
+                if (list_it) {
+                    int32_t i = node_new(l, pc, seen_word);
+                    if (tail >= 0) {
+                        node(l, tail)->next = i;
+                    } else {
+                        head = i;
+                    }
+                    tail = i;
+                }
+                break;
+            }
+        }
+    }
+
+    __device__ inline unsigned in_at(int64_t i) const { return in.at(i); }
+
+    __device__ void load_work(Node *n)
+    {
+        const int64_t *c = cap(n);
+        for (uint32_t k = 0; k < nslots; k++) work[k] = c[k];
+    }
+
+    /* sre_vm_pike.c:945-989 */
+    __device__ int64_t prepare_matched(int64_t *ov, uint64_t ovec_slots, bool complete)
+    {
+        int64_t id = h->matched_regex_id;
+        if (id >= (int64_t) P.h->nregexes) return RC_ERROR;
+        uint64_t ofs = 0;
+        for (int64_t i = 0; i < id; i++) ofs += P.multi_ncaps[i] + 1;
+        ofs *= 2;
+        uint64_t n = complete ? 2ull * (P.multi_ncaps[id] + 1) : 2ull;
+        for (uint64_t k = 0; k < n && k < ovec_slots; k++) ov[k] = matched[ofs + k];
+        if (complete) {
+            for (uint64_t k = n; k < ovec_slots; k++) ov[k] = -1;
+        }
+        return RC_OK;
+    }
+
+    /* sre_vm_pike.c:692-735 (end offset read without the per-regex offset, :721) */
+    __device__ void prepare_temp(int64_t *ov, int l)
+    {
+        int64_t a0 = -1, a1 = -1;
+        for (int32_t i = h->head[l]; i >= 0; i = node(l, i)->next) {
+            const int64_t *c = cap(node(l, i));
+            uint64_t       ofs = 0;
+            for (uint32_t r = 0; r < P.h->nregexes; r++) {
+                int64_t b = c[ofs];
+                if (b != -1 && (a0 == -1 || b < a0)) a0 = b;
+                b = c[1];
+                if (b != -1 && (a1 == -1 || b > a1)) a1 = b;
+                ofs += 2ull * (P.multi_ncaps[r] + 1);
+            }
+        }
+        ov[0] = a0;
+        ov[1] = a1;
+    }
+
+    __device__ int64_t exec(uint64_t size, unsigned eof, bool want_pending,
+                            sre_dev_result_t *res, int64_t *ov, uint64_t ovec_slots)
+    {
+        if (h->magic != PIKE_MAGIC) {
+            /* fresh (zero-filled) context: sre_vm_pike.c:94-145 */
+            h->magic = PIKE_MAGIC;
+            h->processed_bytes = 0;
+            h->last_matched_pos = -1;
+            h->tag = 1;
+            h->first_buf = 1;
+            h->eof = h->empty_capture = h->seen_newline = h->seen_word = 0;
+            h->has_matched = 0;
+            h->cur = 0;
+            list_reset(0);
+            list_reset(1);
+        }
+
+        res->has_pending = 0;
+        res->consumed = 0;
+        if (h->eof) return RC_ERROR;                               /* :165-168 */
+
+        int     cl = (int) h->cur, nl = cl ^ 1;
+        int64_t sp = 0, last = (int64_t) size;
+        bool    has_matched = h->has_matched != 0;
+
+        h->last_matched_pos = -1;
+        if (h->empty_capture) {                                    /* :179-196 */
+            h->empty_capture = 0;
+            if (size == 0) {
+                if (eof) {
+                    h->eof = 1;
+                    return RC_DECLINED;
+                }
+                return RC_AGAIN;
+            }
+            sp = 1;
+        }
+
+        if (h->first_buf) {                                        /* :202-233 */
+            h->first_buf = 0;
+            for (uint32_t k = 0; k < nslots; k++) work[k] = -1;
+            h->tag++;
+            list_reset(cl);
+            closure(cl, h->head[cl], h->tail[cl], 0, sp, false);
+        }
+
+        for (; sp < last || (eof && sp == last); sp++) {           /* :235 */
+            if (h->head[cl] < 0) break;
+            h->tag++;                                              /* :312 */
+            const bool     at_end = (sp == last);
+            const unsigned c = at_end ? 0u : in_at(sp);
+            bool           done = false;
+
+            while (h->head[cl] >= 0) {                             /* :314 */
+                Node *t = node(cl, h->head[cl]);
+                h->head[cl] = t->next;
+                if (h->head[cl] < 0) h->tail[cl] = -1;
+                const uint32_t       pc = t->pc;
+                const sre_dev_insn_t in = P.insns[pc];
+
+                if (in.opcode == OP_ASSERT) {                      /* :450-528 */
+                    bool hold = false;
+                    if (in.ch == AS_SMALL_Z) {
+                        hold = at_end;
+                    } else if (in.ch == AS_DOLLAR) {
+                        hold = at_end || c == '\n';
+                    } else {
+                        bool sw = t->seen_word || (sp == 0 && h->seen_word);
+                        hold = sw != (!at_end && is_word(c));
+                        if (in.ch == AS_BIG_B) hold = !hold;
+                    }
+                    if (!hold) continue;
+                    /* closure at the same offset under the CURRENT list's
+                     * generation, spliced in front of the rest (:506-526) */
+                    load_work(t);
+                    int32_t sh = -1, st = -1;
+                    h->tag--;
+                    closure(cl, sh, st, pc + 1, sp, false);
+                    h->tag++;
+                    if (sh >= 0) {
+                        node(cl, st)->next = h->head[cl];
+                        if (h->head[cl] < 0) h->tail[cl] = st;
+                        h->head[cl] = sh;
+                    }
+                    continue;
+                }
+
+                if (in.opcode == OP_MATCH) {                       /* :530-553 */
+                    const int64_t *cp = cap(t);
+                    h->last_matched_pos = cp[1];
+                    for (uint32_t k = 0; k < nslots; k++) matched[k] = cp[k];
+                    h->matched_regex_id = in.arg;
+                    done = true;
+                    break;
+                }
+
+                if (at_end || !consumes(P, in, c)) continue;       /* :329-448 */
+                load_work(t);
+                if (closure(nl, h->head[nl], h->tail[nl], pc + 1, sp + 1, true) == RC_DONE) {
+                    done = true;
+                    break;
+                }
+            }
+
+            if (done) {
+                /* every thread of lower priority is dropped (:547-553) */
+                has_matched = true;
+            }
+            /* step_done :569-580 */
+            list_reset(cl);
+            cl ^= 1;
+            nl ^= 1;
+            if (at_end) break;
+        }
+
+        if (h->last_matched_pos >= 0) {                            /* :586-601 */
+            int64_t p = h->last_matched_pos - h->processed_bytes;
+            if (p > 0) {
+                unsigned b = in_at(p - 1);
+                h->seen_newline = (b == '\n');
+                h->seen_word = is_word(b);
+            }
+            h->last_matched_pos = -1;
+        }
+
+        h->cur = (uint32_t) cl;
+        res->consumed = sp;
+
+        if (has_matched) {                                         /* :607-658 */
+            if (eof || h->head[cl] < 0) {
+                if (prepare_matched(ov, ovec_slots, true) != RC_OK) return RC_ERROR;
+                if (h->head[cl] >= 0) {
+                    list_reset(cl);
+                    h->eof = 1;
+                }
+                /* :624-628 re-arm for the next search on the same context */
+                uint64_t ofs = 0;
+                for (int64_t i = 0; i < h->matched_regex_id; i++) ofs += P.multi_ncaps[i] + 1;
+                ofs *= 2;
+                h->processed_bytes = matched[ofs + 1];
+                h->empty_capture = (matched[ofs] == matched[ofs + 1]);
+                h->has_matched = 0;
+                h->first_buf = 1;
+                return h->matched_regex_id;
+            }
+            if (want_pending) {
+                res->has_pending = 1;
+                if (prepare_matched(res->pending, 2, false) != RC_OK) return RC_ERROR;
+            }
+        } else if (eof) {                                          /* :660-666 */
+            h->eof = 1;
+            h->has_matched = 0;
+            return RC_DECLINED;
+        }
+
+        h->processed_bytes += sp;                                  /* :673-688 */
+        h->has_matched = has_matched ? 1u : 0u;
+        if (ovec_slots >= 2) prepare_temp(ov, cl);
+        return RC_AGAIN;
+    }
+};
+
+/* =================================================================== Thompson */
+
+constexpr uint32_t THOMPSON_MAGIC = 0x54484f4du;
+
+struct ThompsonHdr {
+    uint32_t magic, tag, first_buf, cur;
+    uint32_t count[2];
+};
+
+struct Thompson {
+    Prog         P;
+    ThompsonHdr *h;
+    uint32_t    *tags;
+    uint32_t    *list[2];      /* entries: pc | seen_word << 31 */
+    uint32_t    *stack;
+    Chunk        in;
+
+    /* sre_vm_thompson.c:273-345; `sp` is the chunk offset, chunk start == 0 */
+    __device__ void closure(int l, uint32_t pc0, int64_t sp)
+    {
+        uint32_t sptr = 0, tag = h->tag, pc = pc0;
+        bool     first = true;
+
+        for (;;) {
+            if (!first) {
+                if (sptr == 0) return;
+                pc = stack[--sptr];
+            }
+            first = false;
+            for (;;) {
+                const sre_dev_insn_t in = P.insns[pc];
+                uint32_t             seen_word = 0;
+
+                if (tags[pc] == tag) break;          /* plain de-dup (:280-282) */
+                tags[pc] = tag;
+
+                if (in.opcode == OP_JMP) {
+                    pc = in.x;
+                    continue;
+                }
+                if (in.opcode == OP_SPLIT) {
+                    stack[sptr++] = in.y;
+                    pc = in.x;
+                    continue;
+                }
+                if (in.opcode == OP_SAVE) {
+                    pc = pc + 1;
+                    continue;
+                }
+                if (in.opcode == OP_ASSERT) {
+                    if (in.ch == AS_BIG_A) {
+                        if (sp != 0) break;          /* chunk-local (:302-309) */
+                        pc = pc + 1;
+                        continue;
+                    }
+                    if (in.ch == AS_CARET) {
+                        if (sp != 0 && this->in.at(sp - 1) != '\n') break;
+                        pc = pc + 1;
+                        continue;
+                    }
+                    if (in.ch == AS_SMALL_B || in.ch == AS_BIG_B) {
+                        seen_word = (sp != 0 && is_word(this->in.at(sp - 1))) ? 1u : 0u;
+                    }
+                }
+                list[l][h->count[l]++] = pc | (seen_word << 31);
+                break;
+            }
+        }
+    }
+
+    __device__ int64_t exec(uint64_t size, unsigned eof, sre_dev_result_t *res)
+    {
+        if (h->magic != THOMPSON_MAGIC) {
+            h->magic = THOMPSON_MAGIC;
+            h->tag = 1;
+            h->first_buf = 1;
+            h->cur = 0;
+            h->count[0] = h->count[1] = 0;
+        }
+        int cl = (int) h->cur, nl = cl ^ 1;
+
+        if (h->first_buf) {                                        /* :81-84 */
+            h->first_buf = 0;
+            closure(cl, 0, 0);
+        }
+
+        int64_t sp = 0, last = (int64_t) size;
+        for (; sp < last || (eof && sp == last); sp++) {           /* :88 */
+            if (h->count[cl] == 0) break;
+            h->tag++;
+            const bool     at_end = (sp == last);
+            const unsigned c = at_end ? 0u : in.at(sp);
+
+            for (uint32_t i = 0; i < h->count[cl]; i++) {
+                const uint32_t       e = list[cl][i];
+                const uint32_t       pc = e & 0x7fffffffu;
+                const sre_dev_insn_t ins = P.insns[pc];
+
+                if (ins.opcode == OP_MATCH) {                      /* :233-235 */
+                    res->consumed = sp;
+                    return RC_OK;
+                }
+                if (ins.opcode == OP_ASSERT) {                     /* :174-231 */
+                    bool hold;
+                    if (ins.ch == AS_SMALL_Z) {
+                        hold = at_end;
+                    } else if (ins.ch == AS_DOLLAR) {
+                        hold = at_end || c == '\n';
+                    } else {
+                        hold = ((e >> 31) != 0) != (!at_end && is_word(c));
+                        if (ins.ch == AS_BIG_B) hold = !hold;
+                    }
+                    if (hold) {
+                        h->tag--;
+                        closure(cl, pc + 1, sp);       /* appended to the current list */
+                        h->tag++;
+                    }
+                    continue;
+                }
+                if (at_end || !consumes(P, ins, c)) continue;
+                closure(nl, pc + 1, sp + 1);
+            }
+
+            h->count[cl] = 0;
+            cl ^= 1;
+            nl ^= 1;
+            if (at_end) break;
+        }
+
+        h->cur = (uint32_t) cl;
+        res->consumed = sp;
+        return eof ? RC_DECLINED : RC_AGAIN;
+    }
+};
+
+}  // namespace
+
+/* One lane per request: lane i of the grid serves reqs[i]. */
+extern "C" __global__ void
+sre_k_pike_exec(const uint8_t *__restrict__ blob, const sre_dev_req_t *__restrict__ reqs,
+                uint32_t nreqs)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nreqs) return;
+    const sre_dev_req_t rq = reqs[i];
+
+    Pike vm;
+    vm.P = prog_view(blob);
+    const sre_pike_layout_t L = sre_pike_layout(vm.P.h->len, vm.P.h->nthreads, vm.P.h->nslots);
+    uint8_t *base = static_cast<uint8_t *>(rq.ctx);
+    vm.h = reinterpret_cast<PikeHdr *>(base);
+    vm.tags = reinterpret_cast<uint32_t *>(base + L.tags);
+    vm.nodes[0] = base + L.nodes[0];
+    vm.nodes[1] = base + L.nodes[1];
+    vm.matched = reinterpret_cast<int64_t *>(base + L.matched);
+    vm.work = reinterpret_cast<int64_t *>(base + L.work);
+    vm.stack = reinterpret_cast<StackRec *>(base + L.stack);
+    vm.node_bytes = L.node_bytes;
+    vm.nslots = vm.P.h->nslots;
+    vm.in.p = rq.input;
+    vm.in.inl = rq.inline_bytes;
+
+    sre_dev_result_t *res = static_cast<sre_dev_result_t *>(rq.result);
+    int64_t          *ov = reinterpret_cast<int64_t *>(res + 1);
+    res->rc = vm.exec(rq.size, rq.eof, rq.want_pending != 0, res, ov, rq.ovec_slots);
+}
+
+extern "C" __global__ void
+sre_k_thompson_exec(const uint8_t *__restrict__ blob, const sre_dev_req_t *__restrict__ reqs,
+                    uint32_t nreqs)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nreqs) return;
+    const sre_dev_req_t rq = reqs[i];
+
+    Thompson vm;
+    vm.P = prog_view(blob);
+    const sre_thompson_layout_t L = sre_thompson_layout(vm.P.h->len);
+    uint8_t *base = static_cast<uint8_t *>(rq.ctx);
+    vm.h = reinterpret_cast<ThompsonHdr *>(base);
+    vm.tags = reinterpret_cast<uint32_t *>(base + L.tags);
+    vm.list[0] = reinterpret_cast<uint32_t *>(base + L.list[0]);
+    vm.list[1] = reinterpret_cast<uint32_t *>(base + L.list[1]);
+    vm.stack = reinterpret_cast<uint32_t *>(base + L.stack);
+    vm.in.p = rq.input;
+    vm.in.inl = rq.inline_bytes;
+
+    sre_dev_result_t *res = static_cast<sre_dev_result_t *>(rq.result);
+    res->has_pending = 0;
+    res->consumed = 0;
+    res->rc = vm.exec(rq.size, rq.eof, res);
+}
+
+/*
+ * Whole-stream scan for the batched API: lane i owns stream i for the whole
+ * call (fresh context, eof = 1).  mode 1: first match; mode 2: the find-all
+ * iteration a caller writes around sre_vm_pike_exec, re-feeding the SAME
+ * context from each match end (sre_vm_pike.c:179-196, 624-628).
+ * Record per stream: [rc, count, ovector[ovec_slots]].
+ */
+extern "C" __global__ void
+sre_k_pike_scan(const uint8_t *__restrict__ blob, const uint8_t *const *__restrict__ streams,
+                const uint64_t *__restrict__ lens, uint32_t nstreams, uint8_t *ctx_base,
+                uint64_t ctx_stride, int64_t *__restrict__ records, uint32_t ovec_slots,
+                int mode)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nstreams) return;
+
+    Pike vm;
+    vm.P = prog_view(blob);
+    const sre_pike_layout_t L = sre_pike_layout(vm.P.h->len, vm.P.h->nthreads, vm.P.h->nslots);
+    uint8_t *base = ctx_base + (size_t) i * ctx_stride;
+    vm.h = reinterpret_cast<PikeHdr *>(base);
+    vm.tags = reinterpret_cast<uint32_t *>(base + L.tags);
+    vm.nodes[0] = base + L.nodes[0];
+    vm.nodes[1] = base + L.nodes[1];
+    vm.matched = reinterpret_cast<int64_t *>(base + L.matched);
+    vm.work = reinterpret_cast<int64_t *>(base + L.work);
+    vm.stack = reinterpret_cast<StackRec *>(base + L.stack);
+    vm.node_bytes = L.node_bytes;
+    vm.nslots = vm.P.h->nslots;
+    vm.in.inl = 0;
+
+    int64_t         *rec = records + (size_t) i * (2 + ovec_slots);
+    int64_t         *ov = rec + 2;
+    const uint8_t   *s = streams[i];
+    const uint64_t   n = lens[i];
+    sre_dev_result_t res;
+    uint64_t         off = 0;
+    int64_t          count = 0, rc, last_rc = RC_DECLINED;
+
+    for (uint32_t k = 0; k < ovec_slots; k++) ov[k] = -1;
+    for (;;) {
+        vm.in.p = s + off;
+        rc = vm.exec(n - off, 1u, false, &res, ov, ovec_slots);
+        if (rc < 0) break;
+        count++;
+        last_rc = rc;
+        if (mode != 2) break;
+        off = (uint64_t) vm.h->processed_bytes;      /* == ovector[1] of this match */
+    }
+    /* the final DECLINED leaves the ovector of the last match in place
+     * (sre_vm_pike.c:660-666 writes nothing) */
+    rec[0] = (rc == RC_ERROR) ? rc : (count > 0 ? last_rc : rc);
+    rec[1] = count;
+}
+
+extern "C" __global__ void
+sre_k_thompson_scan(const uint8_t *__restrict__ blob, const uint8_t *const *__restrict__ streams,
+                    const uint64_t *__restrict__ lens, uint32_t nstreams, uint8_t *ctx_base,
+                    uint64_t ctx_stride, int64_t *__restrict__ records, uint32_t ovec_slots)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nstreams) return;
+
+    Thompson vm;
+    vm.P = prog_view(blob);
+    const sre_thompson_layout_t L = sre_thompson_layout(vm.P.h->len);
+    uint8_t *base = ctx_base + (size_t) i * ctx_stride;
+    vm.h = reinterpret_cast<ThompsonHdr *>(base);
+    vm.tags = reinterpret_cast<uint32_t *>(base + L.tags);
+    vm.list[0] = reinterpret_cast<uint32_t *>(base + L.list[0]);
+    vm.list[1] = reinterpret_cast<uint32_t *>(base + L.list[1]);
+    vm.stack = reinterpret_cast<uint32_t *>(base + L.stack);
+    vm.in.p = streams[i];
+    vm.in.inl = 0;
+
+    sre_dev_result_t res;
+    int64_t         *rec = records + (size_t) i * (2 + ovec_slots);
+    int64_t          rc = vm.exec(lens[i], 1u, &res);
+    rec[0] = rc;
+    rec[1] = rc == RC_OK ? 1 : 0;
+    for (uint32_t k = 0; k < ovec_slots; k++) rec[2 + k] = -1;
+}
+
+extern "C" hipError_t
+sre_launch_vm_scan(const void *blob, int mode, const void *const *d_streams,
+                   const uint64_t *d_lens, uint32_t nstreams, void *d_ctx, uint64_t ctx_stride,
+                   int64_t *d_records, uint32_t ovec_slots, hipStream_t stream)
+{
+    uint32_t block = 64, grid = (nstreams + block - 1) / block;
+    if (mode == 0) {
+        hipLaunchKernelGGL(sre_k_thompson_scan, dim3(grid), dim3(block), 0, stream,
+                           static_cast<const uint8_t *>(blob),
+                           reinterpret_cast<const uint8_t *const *>(d_streams), d_lens, nstreams,
+                           static_cast<uint8_t *>(d_ctx), ctx_stride, d_records, ovec_slots);
+    } else {
+        hipLaunchKernelGGL(sre_k_pike_scan, dim3(grid), dim3(block), 0, stream,
+                           static_cast<const uint8_t *>(blob),
+                           reinterpret_cast<const uint8_t *const *>(d_streams), d_lens, nstreams,
+                           static_cast<uint8_t *>(d_ctx), ctx_stride, d_records, ovec_slots, mode);
+    }
+    return hipGetLastError();
+}
+
+extern "C" hipError_t
+sre_launch_pike_exec(const void *blob, const sre_dev_req_t *d_reqs, uint32_t nreqs,
+                     hipStream_t stream)
+{
+    uint32_t block = 64, grid = (nreqs + block - 1) / block;
+    hipLaunchKernelGGL(sre_k_pike_exec, dim3(grid), dim3(block), 0, stream,
+                       static_cast<const uint8_t *>(blob), d_reqs, nreqs);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t
+sre_launch_thompson_exec(const void *blob, const sre_dev_req_t *d_reqs, uint32_t nreqs,
+                         hipStream_t stream)
+{
+    uint32_t block = 64, grid = (nreqs + block - 1) / block;
+    hipLaunchKernelGGL(sre_k_thompson_exec, dim3(grid), dim3(block), 0, stream,
+                       static_cast<const uint8_t *>(blob), d_reqs, nreqs);
+    return hipGetLastError();
+}

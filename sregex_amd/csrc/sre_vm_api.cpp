@@ -1,0 +1,265 @@
+/*
+ * sre_vm_api.cpp — the reference's executor entry points over the HIP kernels.
+ *
+ *   sre_vm_pike_create_ctx / sre_vm_pike_exec          reference sregex.h:130-134
+ *   sre_vm_thompson_create_ctx / sre_vm_thompson_exec  reference sregex.h:144-148
+ *   sre_vm_thompson_jit_*                              reference sregex.h:162-171
+ *
+ * A context is one stream: its VM state stays resident in HBM between exec()
+ * calls, each call runs one kernel over the chunk and is synchronous on return
+ * (rc, ovector and *pending_matched are valid host memory), exactly the
+ * reference's contract.  Chunks of <= 8 bytes ride in the kernel argument,
+ * larger ones are staged with one H2D copy.  Requests and results live in one
+ * pinned, device-mapped host block per context, so an exec() is: fill request,
+ * one launch, one stream sync.
+ *
+ * There is no CPU matcher behind these calls: without a HIP device exec()
+ * returns SRE_ERROR after a diagnostic on stderr.
+ */
+#include "sre_hip_runtime.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+namespace {
+
+/* pinned host block: request, result header, ovector */
+struct HostBlock {
+    sre_dev_req_t    req;
+    sre_dev_result_t res;
+    int64_t          ov[1];   /* ovec_slots */
+};
+
+struct DeviceStream {
+    sre_hip_program_s *dp;
+    void              *d_ctx;       /* VM state, zero-filled == fresh */
+    size_t             ctx_bytes;
+    void              *d_in;        /* staging for chunks > 8 bytes */
+    size_t             in_cap;
+    HostBlock         *h_blk;       /* pinned + mapped */
+    HostBlock         *d_blk;       /* device alias of h_blk */
+    hipStream_t        stream;
+    int                failed;
+};
+
+void
+device_stream_release(void *data)
+{
+    DeviceStream *ds = static_cast<DeviceStream *>(data);
+    if (ds->d_ctx) (void) hipFree(ds->d_ctx);
+    if (ds->d_in) (void) hipFree(ds->d_in);
+    if (ds->h_blk) (void) hipHostFree(ds->h_blk);
+    if (ds->stream) (void) hipStreamDestroy(ds->stream);
+    free(ds);
+}
+
+DeviceStream *
+device_stream_open(sre_pool_t *pool, sre_program_t *prog, size_t ctx_bytes, size_t ovec_slots)
+{
+    sre_hip_program_s *dp = sre_hip_program_get(prog);
+    if (dp == NULL) return NULL;
+
+    DeviceStream *ds = static_cast<DeviceStream *>(calloc(1, sizeof(DeviceStream)));
+    if (ds == NULL) return NULL;
+    ds->dp = dp;
+    ds->ctx_bytes = ctx_bytes;
+    size_t blk = sizeof(HostBlock) + ovec_slots * sizeof(int64_t);
+
+    SRE_HIP_TRY(hipStreamCreateWithFlags(&ds->stream, hipStreamNonBlocking));
+    SRE_HIP_TRY(hipMalloc(&ds->d_ctx, ctx_bytes));
+    SRE_HIP_TRY(hipMemsetAsync(ds->d_ctx, 0, ctx_bytes, ds->stream));
+    SRE_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&ds->h_blk), blk, hipHostMallocMapped));
+    SRE_HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&ds->d_blk), ds->h_blk, 0));
+    memset(ds->h_blk, 0, blk);
+    if (sre_pool_add_cleanup(pool, device_stream_release, ds) != SRE_OK) goto hip_failed;
+    return ds;
+
+hip_failed:
+    device_stream_release(ds);
+    return NULL;
+}
+
+/* run one chunk through `launch`; returns 0 when h_blk->res is valid */
+int
+device_stream_exec(DeviceStream *ds, const sre_char *input, size_t len, unsigned eof,
+                   unsigned want_pending, size_t ovec_slots,
+                   hipError_t (*launch)(const void *, const sre_dev_req_t *, uint32_t, hipStream_t))
+{
+    sre_dev_req_t *rq = &ds->h_blk->req;
+
+    rq->size = len;
+    rq->eof = eof ? 1u : 0u;
+    rq->want_pending = want_pending;
+    rq->ctx = ds->d_ctx;
+    rq->result = &ds->d_blk->res;
+    rq->ovec_slots = ovec_slots;
+    rq->input = NULL;
+    rq->inline_bytes = 0;
+    if (len > 0 && len <= 8) {
+        memcpy(&rq->inline_bytes, input, len);
+    } else if (len > 8) {
+        if (len > ds->in_cap) {
+            if (ds->d_in) (void) hipFree(ds->d_in);
+            ds->d_in = NULL;
+            ds->in_cap = 0;
+            size_t cap = len + (len >> 2) + 4096;
+            SRE_HIP_TRY(hipMalloc(&ds->d_in, cap));
+            ds->in_cap = cap;
+        }
+        SRE_HIP_TRY(hipMemcpyAsync(ds->d_in, input, len, hipMemcpyHostToDevice, ds->stream));
+        rq->input = static_cast<const uint8_t *>(ds->d_in);
+    }
+    ds->h_blk->res.rc = SRE_ERROR;
+
+    SRE_HIP_TRY(launch(ds->dp->d_blob, &ds->d_blk->req, 1, ds->stream));
+    SRE_HIP_TRY(hipStreamSynchronize(ds->stream));
+    return 0;
+
+hip_failed:
+    ds->failed = 1;
+    return -1;
+}
+
+}  // namespace
+
+/* ------------------------------------------------------------------ Pike */
+
+struct sre_vm_pike_ctx_s {
+    sre_pool_t    *pool;
+    sre_program_t *prog;
+    sre_int_t     *ovector;         /* caller-owned (reference sre_vm_pike.c:131-132) */
+    size_t         ovec_slots;
+    sre_int_t      pending[2];
+    DeviceStream  *ds;
+};
+
+extern "C" SRE_API sre_vm_pike_ctx_t *
+sre_vm_pike_create_ctx(sre_pool_t *pool, sre_program_t *prog, sre_int_t *ovector,
+    size_t ovecsize)
+{
+    sre_vm_pike_ctx_t *ctx =
+        static_cast<sre_vm_pike_ctx_t *>(sre_pcalloc(pool, sizeof(sre_vm_pike_ctx_t)));
+    if (ctx == NULL) return NULL;
+    ctx->pool = pool;
+    ctx->prog = prog;
+    ctx->ovector = ovector;
+    ctx->ovec_slots = ovecsize / sizeof(sre_int_t);
+    ctx->ds = NULL;     /* device state is opened by the first exec() */
+    return ctx;
+}
+
+extern "C" SRE_API sre_int_t
+sre_vm_pike_exec(sre_vm_pike_ctx_t *ctx, sre_char *input, size_t len, unsigned eof,
+    sre_int_t **pending_matched)
+{
+    if (ctx->ds == NULL) {
+        sre_hip_program_s *dp = sre_hip_program_get(ctx->prog);
+        if (dp == NULL) return SRE_ERROR;
+        ctx->ds = device_stream_open(ctx->pool, ctx->prog, dp->pike_layout.total, ctx->ovec_slots);
+        if (ctx->ds == NULL) return SRE_ERROR;
+    }
+    DeviceStream *ds = ctx->ds;
+    if (ds->failed) return SRE_ERROR;
+
+    if (device_stream_exec(ds, input, len, eof, pending_matched ? 1u : 0u, ctx->ovec_slots,
+                           sre_launch_pike_exec) != 0)
+    {
+        return SRE_ERROR;
+    }
+
+    const sre_dev_result_t *res = &ds->h_blk->res;
+    sre_int_t               rc = (sre_int_t) res->rc;
+
+    if (rc >= 0) {
+        /* complete match: the whole caller ovector is defined (reference
+         * sre_vm_pike.c:978-986) */
+        for (size_t k = 0; k < ctx->ovec_slots; k++) ctx->ovector[k] = (sre_int_t) ds->h_blk->ov[k];
+    } else if (rc == SRE_AGAIN) {
+        /* temporary $& range only (reference sre_vm_pike.c:700-701) */
+        for (size_t k = 0; k < ctx->ovec_slots && k < 2; k++) {
+            ctx->ovector[k] = (sre_int_t) ds->h_blk->ov[k];
+        }
+    }
+    if (pending_matched && (rc == SRE_AGAIN)) {
+        if (res->has_pending) {
+            ctx->pending[0] = (sre_int_t) res->pending[0];
+            ctx->pending[1] = (sre_int_t) res->pending[1];
+            *pending_matched = ctx->pending;
+        } else {
+            *pending_matched = NULL;
+        }
+    }
+    return rc;
+}
+
+/* -------------------------------------------------------------- Thompson */
+
+struct sre_vm_thompson_ctx_s {
+    sre_pool_t    *pool;
+    sre_program_t *prog;
+    DeviceStream  *ds;
+};
+
+extern "C" SRE_API sre_vm_thompson_ctx_t *
+sre_vm_thompson_create_ctx(sre_pool_t *pool, sre_program_t *prog)
+{
+    sre_vm_thompson_ctx_t *ctx =
+        static_cast<sre_vm_thompson_ctx_t *>(sre_pcalloc(pool, sizeof(sre_vm_thompson_ctx_t)));
+    if (ctx == NULL) return NULL;
+    ctx->pool = pool;
+    ctx->prog = prog;
+    return ctx;
+}
+
+extern "C" SRE_API sre_int_t
+sre_vm_thompson_exec(sre_vm_thompson_ctx_t *ctx, sre_char *input, size_t len, unsigned eof)
+{
+    if (ctx->ds == NULL) {
+        sre_hip_program_s *dp = sre_hip_program_get(ctx->prog);
+        if (dp == NULL) return SRE_ERROR;
+        ctx->ds = device_stream_open(ctx->pool, ctx->prog, dp->thompson_layout.total, 0);
+        if (ctx->ds == NULL) return SRE_ERROR;
+    }
+    if (ctx->ds->failed) return SRE_ERROR;
+    if (device_stream_exec(ctx->ds, input, len, eof, 0, 0, sre_launch_thompson_exec) != 0) {
+        return SRE_ERROR;
+    }
+    return (sre_int_t) ctx->ds->h_blk->res.rc;
+}
+
+/* ------------------------------------------------------------------- JIT */
+/* The x86-64 DynASM JIT (reference sre_vm_thompson_jit.c) is dropped; the
+ * entry points remain so that the reference's clients link.  compile() says
+ * SRE_DECLINED, which they treat as "JIT disabled" (src/sre_cli.c:419-424). */
+
+extern "C" SRE_API sre_int_t
+sre_vm_thompson_jit_compile(sre_pool_t *pool, sre_program_t *prog,
+    sre_vm_thompson_code_t **pcode)
+{
+    (void) pool;
+    (void) prog;
+    if (pcode) *pcode = NULL;
+    return SRE_DECLINED;
+}
+
+extern "C" SRE_API sre_vm_thompson_ctx_t *
+sre_vm_thompson_jit_create_ctx(sre_pool_t *pool, sre_program_t *prog)
+{
+    (void) pool;
+    (void) prog;
+    return NULL;
+}
+
+extern "C" SRE_API sre_vm_thompson_exec_pt
+sre_vm_thompson_jit_get_handler(sre_vm_thompson_code_t *code)
+{
+    (void) code;
+    return NULL;
+}
+
+extern "C" SRE_API sre_int_t
+sre_vm_thompson_jit_free(sre_vm_thompson_code_t *code)
+{
+    (void) code;
+    return SRE_OK;
+}

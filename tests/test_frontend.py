@@ -1,0 +1,74 @@
+"""Host front end (parser + compiler) against the reference's own output.
+
+Pinned per reference test block, in the single-regex form and in the forced
+multi-regex form (t/SRegex.pm:45-47): the AST dump (sre_regex_dump), the
+capture count, the program dump (sre_program_dump) — i.e. the exact
+instruction sequence that defines thread priority — and, for the 77 rejecting
+blocks, the syntax-error offset printed by the CLI.
+"""
+import sregex_amd as S
+import harness
+
+
+def _front(regexes, flags, multi):
+    with S.Pool() as pool:
+        try:
+            re = S.parse(pool, regexes, flags, multi)
+        except S.SyntaxError_ as e:
+            return {"err": str(e) + "\n"}
+        prog = S.compile(pool, re)
+        return {"ast": re.dump(), "ncaps": re.ncaps, "prog": prog.dump().rstrip("\n")}
+
+
+def test_dumps_and_error_offsets_match_reference(lib, blocks):
+    bad = []
+    n = 0
+    for blk in blocks:
+        for name, regexes, flags, multi, ref in harness.block_variants(blk):
+            got = _front(regexes, flags, multi)
+            n += 1
+            if ref["rc"] != 0:
+                ok = got.get("err") == ref["err"]
+            else:
+                ok = ("err" not in got and got["prog"] == ref["prog"] and got["ncaps"] == ref["ncaps"]
+                      and ("ast" not in ref or got["ast"] == ref["ast"]))
+            if not ok:
+                bad.append((blk["file"], blk["name"], name))
+    assert n == 3984
+    assert not bad, bad[:10]
+
+
+def test_explicit_error_expectations_of_the_suite(lib, blocks):
+    """The reference's own `--- err` sections (e.g. t/01-sanity-04.t:224-225)."""
+    n = 0
+    for blk in blocks:
+        if "err" not in blk:
+            continue
+        _, regexes, flags, multi, _ = harness.block_variants(blk)[0]
+        got = _front(regexes, flags, multi)
+        assert got.get("err") == blk["err"], (blk["file"], blk["name"])
+        n += 1
+    assert n == 21
+
+
+def test_quantifier_stacking_is_rejected_at_the_second_quantifier(lib):
+    # oracle offsets 2, 2, 2, 4, 4
+    for src, pos in [(b"a**", 2), (b"a++", 2), (b"a?*", 2), (b"a{2}{3}", 4), (b"a{2}+", 4),
+                     (b"(ab", 3), (b"a)", 1), (b"*a", 0), (b"a|*", 2), (b"ab\\", 2),
+                     (b"(?i)a", 2), (b"(?=a)", 2), (b"\\1", 0), (b"[b-a]", 0), (b"[a", 0)]:
+        with S.Pool() as pool:
+            try:
+                S.parse(pool, [src])
+            except S.SyntaxError_ as e:
+                assert e.offset == pos, (src, e.offset, pos)
+            else:
+                raise AssertionError("accepted %r" % src)
+
+
+def test_newline_flag_turns_dot_into_not_newline(lib):
+    # SRE_REGEX_NEWLINE: '.' and \C become [^\n] (sre_yyparser.y:293-297, 865-869);
+    # not exercised by the reference CLI => checked against the documented shape only
+    with S.Pool() as pool:
+        re = S.parse(pool, [b"a.\\C"], [S.SRE_REGEX_NEWLINE])
+        assert re.dump() == ("Cat(NgStar(Dot), TOPLEVEL(0, Paren(0, Cat(Cat(Lit(97), NCLASS([10, 10])), "
+                             "NCLASS([10, 10])))))")
