@@ -44,9 +44,10 @@ SRE_API void sre_oracle_thompson_free(sre_oracle_thompson_ctx_t *ctx);
 
 /* iterate exec over one buffer on one ctx, re-feeding from each match end
  * (SURVEY.md 8b "stream contract"); returns the number of matches and, if
- * `spans` is non-NULL, writes up to max_spans records of (regex_id, ovector[nov]). */
+ * `spans` is non-NULL, writes up to max_spans records of (regex_id, ovector[nov]);
+ * *final_rc receives the rc that ended the iteration. */
 SRE_API sre_int_t sre_oracle_pike_count(sre_program_t *prog, const sre_char *input,
-    size_t size, sre_int_t *spans, size_t nov, size_t max_spans);
+    size_t size, sre_int_t *spans, size_t nov, size_t max_spans, sre_int_t *final_rc);
 
 #ifdef __cplusplus
 }

@@ -596,7 +596,7 @@ step_done:
 
 SRE_API sre_int_t
 sre_oracle_pike_count(sre_program_t *prog, const sre_char *input, size_t size,
-    sre_int_t *spans, size_t nov, size_t max_spans)
+    sre_int_t *spans, size_t nov, size_t max_spans, sre_int_t *final_rc)
 {
     sre_uint_t  maxcaps = 0;
     sre_int_t  *ov, count = 0, rc;
@@ -623,5 +623,8 @@ sre_oracle_pike_count(sre_program_t *prog, const sre_char *input, size_t size,
     }
     sre_oracle_pike_free(ctx);
     free(ov);
-    return rc == SRE_DECLINED ? count : SRE_ERROR;
+    /* the iteration ends with SRE_DECLINED, or with SRE_ERROR when the previous
+     * call returned its match with threads still listed (sre_vm_pike.c:616-622) */
+    if (final_rc) *final_rc = rc;
+    return count;
 }

@@ -1,4 +1,340 @@
+/*
+ * sre_dfa.cpp — builds the step automaton described in sre_dfa.h by running
+ * the reference VM's step on capture-free thread lists.
+ *
+ * Mirrors (capture-free): byte loop sre_vm_pike.c:314-567, closure
+ * sre_vm_pike.c:756-942.  Look-ahead assertions are not admitted here, so the
+ * assertion splice (:506-526) never occurs; \A and ^ are resolved at add time
+ * from the byte just consumed (:839-864) and are therefore functions of the
+ * input symbol.
+ *
+ * The leading-byte skip (sre_vm_pike.c:256-309) is part of the observable
+ * behaviour (its initial-state test ignores the last thread, :266-273, so it
+ * can re-seed a search that already holds a match) and is modelled byte by
+ * byte: a state that passes that test moves, on a non-leading byte, to the
+ * freshly seeded list.  For that the state key also carries the
+ * seen_start_state flag and which initial list the search was seeded from.
+ */
 #include "sre_dfa.h"
 #include <stdlib.h>
-struct sre_dfa_s { int dummy; };
-extern "C" void sre_dfa_free(sre_dfa_t *dfa) { free(dfa); }
+#include <string.h>
+#include <map>
+
+namespace {
+
+struct Builder {
+    const sre_program_t *prog;
+    sre_dfa_t           *d;
+    std::vector<uint32_t> tags;
+    uint32_t             gen = 0;
+    std::map<std::vector<uint32_t>, uint32_t> ids;     /* key: pcs..., matched|sss<<1|variant<<2 */
+    std::vector<std::vector<uint32_t>> lists;          /* per state */
+    std::vector<uint8_t>               sss, variant;   /* per state */
+    bool                 visited_start = false;        /* pc 0 reached by the last closure(s) */
+
+    /* result of one closure / step */
+    std::vector<uint32_t> nl;          /* new list pcs */
+    std::vector<uint8_t>  npar;
+    std::vector<uint64_t> nsav;
+
+    bool consumes(const sre_insn_t &in, unsigned c) const
+    {
+        switch (in.opcode) {
+        case SRE_OP_CHAR:  return c == in.ch;
+        case SRE_OP_ANY:   return true;
+        case SRE_OP_IN:    return sre_in_ranges(&prog->ranges[in.x], in.nranges, c) != 0;
+        case SRE_OP_NOTIN: return sre_in_ranges(&prog->ranges[in.x], in.nranges, c) == 0;
+        default:           return false;
+        }
+    }
+
+    /*
+     * Capture-free closure (sre_vm_pike.c:756-942).  Appends to nl/npar/nsav.
+     * Returns true when MATCH was reached with from_loop set (SRE_DONE);
+     * *done_saves / *done_regex then describe the match.
+     */
+    bool closure(uint32_t pc0, bool a_ok, bool caret_ok, bool from_loop, uint8_t parent,
+                 uint64_t *done_saves, uint32_t *done_regex)
+    {
+        struct Rec { uint32_t pc; uint64_t mask; };
+        std::vector<Rec> stack;
+        uint32_t pc = pc0;
+        uint64_t mask = 0;
+
+        for (;;) {
+            /* one chain of tail calls */
+            for (;;) {
+                const sre_insn_t &in = prog->insns[pc];
+                if (tags[pc] == gen) {
+                    if (in.opcode == SRE_OP_SPLIT && tags[in.y] != gen) {   /* :774-784 */
+                        if (pc == 0) visited_start = true;
+                        pc = in.y;
+                        continue;
+                    }
+                    break;
+                }
+                tags[pc] = gen;
+                if (pc == 0) visited_start = true;                          /* :799-802 */
+                if (in.opcode == SRE_OP_JMP) {
+                    pc = in.x;
+                    continue;
+                }
+                if (in.opcode == SRE_OP_SPLIT) {
+                    stack.push_back(Rec{in.y, mask});
+                    pc = in.x;
+                    continue;
+                }
+                if (in.opcode == SRE_OP_SAVE) {
+                    mask |= 1ull << in.arg;
+                    pc++;
+                    continue;
+                }
+                if (in.opcode == SRE_OP_ASSERT) {
+                    bool ok = in.ch == SRE_ASSERT_BIG_A ? a_ok : caret_ok;
+                    if (!ok) break;
+                    pc++;
+                    continue;
+                }
+                if (in.opcode == SRE_OP_MATCH && from_loop) {
+                    *done_saves = mask;
+                    *done_regex = in.arg;
+                    return true;
+                }
+                nl.push_back(pc);
+                npar.push_back(parent);
+                nsav.push_back(mask);
+                break;
+            }
+            if (stack.empty()) return false;
+            pc = stack.back().pc;
+            mask = stack.back().mask;
+            stack.pop_back();
+        }
+    }
+
+    /* seen_start: 0 clear, 1 set (consumed by the next check), 2 set by a skip
+     * re-seed that is still travelling to its target byte (see step) */
+    uint32_t intern(const std::vector<uint32_t> &pcs, bool matched, int seen_start, int var)
+    {
+        if (pcs.empty()) return SRE_DFA_DEAD;
+        if (prog->nleading == 0) {       /* the skip does not exist: flags are inert */
+            seen_start = 0;
+            var = 0;
+        }
+        std::vector<uint32_t> key(pcs);
+        key.push_back((matched ? 1u : 0u) | ((uint32_t) seen_start << 1) | ((uint32_t) var << 3));
+        auto it = ids.find(key);
+        if (it != ids.end()) return it->second;
+        uint32_t id = (uint32_t) lists.size();
+        ids.emplace(key, id);
+        lists.push_back(pcs);
+        d->matched.push_back(matched ? 1 : 0);
+        sss.push_back((uint8_t) seen_start);
+        variant.push_back((uint8_t) var);
+        return id;
+    }
+
+    /* sre_vm_pike.c:992-1061: can byte c start a match? */
+    bool is_leading(unsigned c) const
+    {
+        if (prog->leading_byte != -1) return (int) c == prog->leading_byte;
+        for (uint32_t i = 0; i < prog->nleading; i++) {
+            if (consumes(prog->insns[prog->leading_insns[i]], c)) return true;
+        }
+        return false;
+    }
+};
+
+}  // namespace
+
+extern "C" void
+sre_dfa_free(sre_dfa_t *dfa)
+{
+    delete dfa;
+}
+
+extern "C" sre_dfa_t *
+sre_dfa_build(const sre_program_t *prog, uint32_t max_states, const char **why)
+{
+    const char *dummy;
+    if (why == NULL) why = &dummy;
+    *why = NULL;
+
+    if (prog->lookahead_asserts) {
+        *why = "program has look-ahead assertions ($ \\z \\b \\B)";
+        return NULL;
+    }
+    if (prog->nslots > 64) {
+        *why = "more than 64 capture slots";
+        return NULL;
+    }
+
+    sre_dfa_t *d = new sre_dfa_t();
+    Builder    b;
+    b.prog = prog;
+    b.d = d;
+    b.tags.assign(prog->len + 1, 0);
+    d->nslots = prog->nslots;
+    d->has_caret = 0;
+
+    /* ---- byte classes: bytes no consuming instruction can tell apart ---- */
+    {
+        std::map<std::vector<uint8_t>, uint32_t> sigs;
+        for (uint32_t pc = 0; pc < prog->len; pc++) {
+            if (prog->insns[pc].opcode == SRE_OP_ASSERT) d->has_caret = 1;
+        }
+        for (unsigned c = 0; c < 256; c++) {
+            std::vector<uint8_t> sig;
+            for (uint32_t pc = 0; pc < prog->len; pc++) {
+                const sre_insn_t &in = prog->insns[pc];
+                if (in.opcode == SRE_OP_CHAR || in.opcode == SRE_OP_IN || in.opcode == SRE_OP_NOTIN) {
+                    sig.push_back(b.consumes(in, c) ? 1 : 0);
+                }
+            }
+            if (d->has_caret) sig.push_back(c == '\n');
+            auto it = sigs.find(sig);
+            if (it == sigs.end()) it = sigs.emplace(sig, (uint32_t) sigs.size()).first;
+            d->cls_map[c] = (uint8_t) it->second;
+            if (sigs.size() > 255) {
+                *why = "more than 255 byte classes";
+                delete d;
+                return NULL;
+            }
+        }
+        d->ncls = (uint32_t) sigs.size();
+    }
+    std::vector<int> rep(d->ncls, -1);
+    for (int c = 255; c >= 0; c--) rep[d->cls_map[c]] = c;
+
+    /* ---- state 0 = DEAD; then the three initial lists ---- */
+    b.lists.push_back(std::vector<uint32_t>());
+    d->matched.push_back(0);
+    b.sss.push_back(0);
+    b.variant.push_back(0);
+    std::vector<std::vector<uint32_t>> init_lists(SRE_DFA_NINIT);
+    std::vector<std::vector<uint8_t>>  lin_par_of_init(SRE_DFA_NINIT);
+    std::vector<std::vector<uint64_t>> lin_sav_of_init(SRE_DFA_NINIT);
+    for (int v = 0; v < SRE_DFA_NINIT; v++) {
+        uint64_t ds;
+        uint32_t dr;
+        b.gen++;
+        b.nl.clear();
+        b.npar.clear();
+        b.nsav.clear();
+        b.closure(0, v == SRE_DFA_INIT_START, v != SRE_DFA_INIT_RESTART, false,
+                  SRE_DFA_NO_PARENT, &ds, &dr);
+        d->init[v] = b.intern(b.nl, false, 1, v);
+        lin_par_of_init[v] = b.npar;
+        lin_sav_of_init[v] = b.nsav;
+        init_lists[v] = b.nl;
+    }
+
+    /* ---- breadth-first exploration ---- */
+    const uint32_t nsym = d->ncls + 1;
+    for (uint32_t s = 0; s < b.lists.size(); s++) {
+        if (b.lists.size() > max_states) {
+            *why = "state cap exceeded";
+            delete d;
+            return NULL;
+        }
+        const std::vector<uint32_t> L = b.lists[s];
+        const bool                  was_matched = d->matched[s] != 0;
+        if (L.size() > d->max_threads) d->max_threads = (uint32_t) L.size();
+
+        for (uint32_t sym = 0; sym < nsym; sym++) {
+            sre_dfa_trans_t t;
+            memset(&t, 0, sizeof(t));
+            const bool eof = (sym == d->ncls);
+            const int  c = eof ? -1 : rep[sym];
+
+            b.gen++;
+            b.nl.clear();
+            b.npar.clear();
+            b.nsav.clear();
+            b.visited_start = false;
+
+            /* :256-309.  In the reference one check can jump sp over many
+             * bytes, re-seed at the target and run that byte's step in the SAME
+             * iteration, i.e. without a second check and with the flag the
+             * re-seed has just set.  Byte by byte that is: flag value 2 =
+             * "travelling": keep re-seeding on non-leading bytes, and on the
+             * target byte step normally with the flag still set.  Flag value 1
+             * is consumed by a check, which skips only when the list "equals"
+             * the search's initial closure — a comparison that leaves out the
+             * last thread of both lists (:266-273). */
+            bool skip = false;
+            int  base_flag = 0;
+            const int var = b.variant[s];
+            if (prog->nleading && b.sss[s] == 2) {
+                skip = !eof && !b.is_leading((unsigned) c);
+                base_flag = 1;
+            } else if (prog->nleading && b.sss[s] == 1 && !eof) {
+                const std::vector<uint32_t> &I = init_lists[var];
+                skip = (L.size() == I.size());
+                for (size_t i = 0; skip && i + 1 < L.size(); i++) {
+                    if (L[i] != I[i]) skip = false;
+                }
+                if (skip && b.is_leading((unsigned) c)) skip = false;    /* p == sp */
+            }
+            if (skip) {
+                /* re-seed one byte further with a fresh capture (:286-302) */
+                uint64_t ds;
+                uint32_t dr;
+                b.closure(0, false, c == '\n', false, SRE_DFA_NO_PARENT, &ds, &dr);
+                t.skipped = 1;
+                t.next = b.intern(b.nl, was_matched, 2, var);
+            } else {
+                for (size_t idx = 0; idx < L.size(); idx++) {
+                    const sre_insn_t &in = prog->insns[L[idx]];
+                    if (in.opcode == SRE_OP_MATCH) {                  /* :530-553 */
+                        t.ev_kind = SRE_DFA_EV_POP;
+                        t.ev_src = (uint8_t) idx;
+                        t.ev_regex = (uint16_t) in.arg;
+                        break;
+                    }
+                    if (eof || !b.consumes(in, (unsigned) c)) continue;
+                    uint64_t ds = 0;
+                    uint32_t dr = 0;
+                    if (b.closure(L[idx] + 1, false, c == '\n', true, (uint8_t) idx, &ds, &dr)) {
+                        t.ev_kind = SRE_DFA_EV_DONE;                  /* :356-358, 535-553 */
+                        t.ev_src = (uint8_t) idx;
+                        t.ev_regex = (uint16_t) dr;
+                        t.ev_saves = ds;
+                        break;
+                    }
+                }
+                t.next = b.intern(b.nl, was_matched || t.ev_kind != SRE_DFA_EV_NONE,
+                                  (base_flag || b.visited_start) ? 1 : 0, var);
+            }
+            t.lin_off = (uint32_t) d->lin_parent.size();
+            t.lin_n = (uint16_t) b.nl.size();
+            d->lin_parent.insert(d->lin_parent.end(), b.npar.begin(), b.npar.end());
+            d->lin_saves.insert(d->lin_saves.end(), b.nsav.begin(), b.nsav.end());
+            d->trans.push_back(t);
+        }
+    }
+
+    d->nstates = (uint32_t) b.lists.size();
+    d->nthreads.resize(d->nstates);
+    d->list_off.resize(d->nstates + 1);
+    for (uint32_t s = 0; s < d->nstates; s++) {
+        d->list_off[s] = (uint32_t) d->list_pcs.size();
+        d->nthreads[s] = (uint16_t) b.lists[s].size();
+        d->list_pcs.insert(d->list_pcs.end(), b.lists[s].begin(), b.lists[s].end());
+    }
+    d->list_off[d->nstates] = (uint32_t) d->list_pcs.size();
+
+    /* the initial lists' own SAVEs (value = search start) ride as pseudo
+     * transitions appended after the real ones: trans[nstates * nsym + v] */
+    for (int v = 0; v < SRE_DFA_NINIT; v++) {
+        sre_dfa_trans_t t;
+        memset(&t, 0, sizeof(t));
+        t.next = d->init[v];
+        t.lin_off = (uint32_t) d->lin_parent.size();
+        t.lin_n = (uint16_t) lin_par_of_init[v].size();
+        d->lin_parent.insert(d->lin_parent.end(), lin_par_of_init[v].begin(), lin_par_of_init[v].end());
+        d->lin_saves.insert(d->lin_saves.end(), lin_sav_of_init[v].begin(), lin_sav_of_init[v].end());
+        d->trans.push_back(t);
+    }
+    return d;
+}

@@ -38,11 +38,14 @@ typedef struct {
     uint32_t  nregexes;
     uint32_t  nthreads;    /* list-able instructions */
     uint32_t  nclasses;
-    uint32_t  pad[3];
+    uint32_t  nleading;    /* leading instructions (0: no leading-byte skip) */
+    int32_t   leading_byte;/* single leading CHAR, or -1 */
+    uint32_t  pad;
     /* followed, 16-B aligned, by:
      *   sre_dev_insn_t insns[len]
      *   uint32_t       classes[nclasses][8]
      *   uint32_t       multi_ncaps[nregexes]
+     *   uint32_t       leading[nleading]      instruction indices
      */
 } sre_dev_prog_hdr_t;
 
@@ -53,8 +56,12 @@ SRE_HD static inline size_t sre_dev_prog_classes_off(uint32_t len) {
 SRE_HD static inline size_t sre_dev_prog_ncaps_off(uint32_t len, uint32_t nclasses) {
     return sre_dev_prog_classes_off(len) + SRE_DEV_ALIGN((size_t) nclasses * 32);
 }
-SRE_HD static inline size_t sre_dev_prog_bytes(uint32_t len, uint32_t nclasses, uint32_t nregexes) {
+SRE_HD static inline size_t sre_dev_prog_leading_off(uint32_t len, uint32_t nclasses, uint32_t nregexes) {
     return sre_dev_prog_ncaps_off(len, nclasses) + SRE_DEV_ALIGN((size_t) nregexes * 4);
+}
+SRE_HD static inline size_t sre_dev_prog_bytes(uint32_t len, uint32_t nclasses, uint32_t nregexes,
+                                               uint32_t nleading) {
+    return sre_dev_prog_leading_off(len, nclasses, nregexes) + SRE_DEV_ALIGN((size_t) (nleading + 1) * 4);
 }
 
 /* ---- per-stream request / result of one exec() on the exact VM kernels ---- */

@@ -82,7 +82,7 @@ sre_hip_program_get(sre_program_t *prog)
     }
     uint32_t nclasses = (uint32_t) (classes.size() / 8);
 
-    size_t               bytes = sre_dev_prog_bytes(prog->len, nclasses, prog->nregexes);
+    size_t               bytes = sre_dev_prog_bytes(prog->len, nclasses, prog->nregexes, prog->nleading);
     std::vector<uint8_t> img(bytes, 0);
     sre_dev_prog_hdr_t  *h = reinterpret_cast<sre_dev_prog_hdr_t *>(img.data());
     h->len = prog->len;
@@ -90,6 +90,8 @@ sre_hip_program_get(sre_program_t *prog)
     h->nregexes = prog->nregexes;
     h->nthreads = prog->nthreads;
     h->nclasses = nclasses;
+    h->nleading = prog->nleading;
+    h->leading_byte = prog->leading_byte;
     sre_dev_insn_t *di = reinterpret_cast<sre_dev_insn_t *>(img.data() + sre_dev_prog_insns_off());
     for (uint32_t pc = 0; pc < prog->len; pc++) {
         const sre_insn_t &in = prog->insns[pc];
@@ -106,6 +108,10 @@ sre_hip_program_get(sre_program_t *prog)
     }
     memcpy(img.data() + sre_dev_prog_ncaps_off(prog->len, nclasses), prog->multi_ncaps,
            (size_t) prog->nregexes * 4);
+    if (prog->nleading) {
+        memcpy(img.data() + sre_dev_prog_leading_off(prog->len, nclasses, prog->nregexes),
+               prog->leading_insns, (size_t) prog->nleading * 4);
+    }
 
     sre_hip_program_s *dp = static_cast<sre_hip_program_s *>(calloc(1, sizeof(*dp)));
     if (dp == NULL) return NULL;

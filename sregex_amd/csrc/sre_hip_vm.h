@@ -11,6 +11,7 @@
 /* byte offsets inside one Pike stream context (zero-filled == fresh) */
 typedef struct {
     size_t   tags;          /* uint32_t[len + 1]     generation per instruction  */
+    size_t   initial;       /* uint32_t[nthreads+1]  initial closure snapshot     */
     size_t   nodes[2];      /* two thread lists, (nthreads + 1) nodes each        */
     size_t   matched;       /* int64_t[nslots]       capture of the pending match */
     size_t   work;          /* int64_t[nslots]       closure working vector       */

@@ -20,9 +20,11 @@
  *     undo SAVEs, so capture vectors are plain per-thread values (no
  *     ref-counted copy-on-write objects, sre_capture.c:20-85, and none of the
  *     reference's capture leak);
- *   - generation tags are per stream, the program image is read-only;
- *   - the leading-byte skip (sre_vm_pike.c:256-309) is not replicated: it is a
- *     result-neutral host optimisation.
+ *   - generation tags are per stream, the program image is read-only.
+ * The leading-byte skip (sre_vm_pike.c:256-309, 992-1061) IS replicated: its
+ * "is this the initial state" test ignores the last thread of the list
+ * (:266-273), so after a match it can re-seed the search and replace the match
+ * — observable behaviour of the reference, pinned by tests/golden/findall.jsonl.
  */
 #include <hip/hip_runtime.h>
 #include "sre_hip_common.h"
@@ -45,6 +47,7 @@ struct Prog {
     const sre_dev_insn_t     *insns;
     const uint32_t           *classes;
     const uint32_t           *multi_ncaps;
+    const uint32_t           *leading;
 };
 
 __device__ inline Prog prog_view(const uint8_t *blob)
@@ -55,6 +58,8 @@ __device__ inline Prog prog_view(const uint8_t *blob)
     p.classes = reinterpret_cast<const uint32_t *>(blob + sre_dev_prog_classes_off(p.h->len));
     p.multi_ncaps = reinterpret_cast<const uint32_t *>(
         blob + sre_dev_prog_ncaps_off(p.h->len, p.h->nclasses));
+    p.leading = reinterpret_cast<const uint32_t *>(
+        blob + sre_dev_prog_leading_off(p.h->len, p.h->nclasses, p.h->nregexes));
     return p;
 }
 
@@ -96,7 +101,8 @@ struct PikeHdr {
     uint32_t first_buf, eof, empty_capture, seen_newline, seen_word, has_matched;
     uint32_t cur;                 /* which of the two lists is "current" */
     int32_t  head[2], tail[2];
-    uint32_t used[2];
+    uint32_t used[2], count[2];
+    uint32_t seen_start_state, initial_count;
     uint32_t pad;
 };
 
@@ -122,6 +128,7 @@ sre_pike_layout(uint32_t len, uint32_t nthreads, uint32_t nslots)
     size_t            off = SRE_DEV_ALIGN(sizeof(PikeHdr));
     L.node_bytes = (uint32_t) (sizeof(Node) + (size_t) nslots * 8);
     L.tags = off;       off += SRE_DEV_ALIGN((size_t) (len + 1) * 4);
+    L.initial = off;    off += SRE_DEV_ALIGN((size_t) (nthreads + 1) * 4);
     L.nodes[0] = off;   off += SRE_DEV_ALIGN((size_t) (nthreads + 1) * L.node_bytes);
     L.nodes[1] = off;   off += SRE_DEV_ALIGN((size_t) (nthreads + 1) * L.node_bytes);
     L.matched = off;    off += SRE_DEV_ALIGN((size_t) (nslots + 1) * 8);
@@ -149,7 +156,7 @@ namespace {
 struct Pike {
     Prog               P;
     PikeHdr           *h;
-    uint32_t          *tags;
+    uint32_t          *tags, *initial;
     uint8_t           *nodes[2];
     int64_t           *matched, *work;
     StackRec          *stack;
@@ -166,6 +173,7 @@ struct Pike {
     {
         h->head[l] = h->tail[l] = -1;
         h->used[l] = 0;
+        h->count[l] = 0;
     }
 
     /* append a thread carrying the working capture vector */
@@ -173,6 +181,7 @@ struct Pike {
     {
         int32_t  i = (int32_t) h->used[l]++;
         Node    *n = node(l, i);
+        h->count[l]++;
         int64_t *c = cap(n);
         n->pc = pc;
         n->seen_word = seen_word;
@@ -220,6 +229,7 @@ struct Pike {
                 if (tags[pc] == tag) {
                     /* :770-787 */
                     if (in.opcode == OP_SPLIT && tags[in.y] != tag) {
+                        if (pc == 0) h->seen_start_state = 1;
                         pc = in.y;
                         continue;
                     }
@@ -232,6 +242,7 @@ struct Pike {
                     pc = in.x;
                     continue;
                 case OP_SPLIT:
+                    if (pc == 0) h->seen_start_state = 1;      /* :799-802 */
                     stack[sptr++] = StackRec{in.y, 0u, 0};
                     pc = in.x;
                     continue;
@@ -296,6 +307,23 @@ struct Pike {
 
     __device__ inline unsigned in_at(int64_t i) const { return in.at(i); }
 
+    /* sre_vm_pike.c:992-1061 */
+    __device__ int64_t find_first_byte(int64_t pos, int64_t last) const
+    {
+        const int32_t lb = P.h->leading_byte;
+        for (; pos != last; pos++) {
+            const unsigned c = in_at(pos);
+            if (lb != -1) {
+                if (c == (unsigned) lb) return pos;
+                continue;
+            }
+            for (uint32_t i = 0; i < P.h->nleading; i++) {
+                if (consumes(P, P.insns[P.leading[i]], c)) return pos;
+            }
+        }
+        return pos;
+    }
+
     __device__ void load_work(Node *n)
     {
         const int64_t *c = cap(n);
@@ -350,6 +378,8 @@ struct Pike {
             h->eof = h->empty_capture = h->seen_newline = h->seen_word = 0;
             h->has_matched = 0;
             h->cur = 0;
+            h->seen_start_state = 0;
+            h->initial_count = 0;
             list_reset(0);
             list_reset(1);
         }
@@ -381,10 +411,38 @@ struct Pike {
             h->tag++;
             list_reset(cl);
             closure(cl, h->head[cl], h->tail[cl], 0, sp, false);
+            /* snapshot of the initial closure, all but its last thread (:218-229) */
+            h->initial_count = h->count[cl];
+            uint32_t k = 0;
+            for (int32_t i = h->head[cl]; i >= 0 && node(cl, i)->next >= 0; i = node(cl, i)->next) {
+                initial[k++] = node(cl, i)->pc;
+            }
         }
 
         for (; sp < last || (eof && sp == last); sp++) {           /* :235 */
             if (h->head[cl] < 0) break;
+
+            if (P.h->nleading && h->seen_start_state) {            /* :256-309 */
+                h->seen_start_state = 0;
+                bool same = (sp != last) && (h->count[cl] == h->initial_count);
+                uint32_t k = 0;
+                for (int32_t i = h->head[cl]; same && i >= 0 && node(cl, i)->next >= 0;
+                     i = node(cl, i)->next)
+                {
+                    if (node(cl, i)->pc != initial[k++]) same = false;
+                }
+                if (same) {
+                    int64_t p = find_first_byte(sp, last);
+                    if (p > sp) {
+                        sp = p;
+                        list_reset(cl);
+                        for (uint32_t s2 = 0; s2 < nslots; s2++) work[s2] = -1;
+                        h->tag++;
+                        closure(cl, h->head[cl], h->tail[cl], 0, sp, false);
+                        if (sp == last) break;
+                    }
+                }
+            }
             h->tag++;                                              /* :312 */
             const bool     at_end = (sp == last);
             const unsigned c = at_end ? 0u : in_at(sp);
@@ -394,6 +452,7 @@ struct Pike {
                 Node *t = node(cl, h->head[cl]);
                 h->head[cl] = t->next;
                 if (h->head[cl] < 0) h->tail[cl] = -1;
+                h->count[cl]--;
                 const uint32_t       pc = t->pc;
                 const sre_dev_insn_t in = P.insns[pc];
 
@@ -417,6 +476,7 @@ struct Pike {
                     closure(cl, sh, st, pc + 1, sp, false);
                     h->tag++;
                     if (sh >= 0) {
+                        /* node_new() already counted the spliced threads */
                         node(cl, st)->next = h->head[cl];
                         if (h->head[cl] < 0) h->tail[cl] = st;
                         h->head[cl] = sh;
@@ -651,6 +711,7 @@ sre_k_pike_exec(const uint8_t *__restrict__ blob, const sre_dev_req_t *__restric
     uint8_t *base = static_cast<uint8_t *>(rq.ctx);
     vm.h = reinterpret_cast<PikeHdr *>(base);
     vm.tags = reinterpret_cast<uint32_t *>(base + L.tags);
+    vm.initial = reinterpret_cast<uint32_t *>(base + L.initial);
     vm.nodes[0] = base + L.nodes[0];
     vm.nodes[1] = base + L.nodes[1];
     vm.matched = reinterpret_cast<int64_t *>(base + L.matched);
@@ -714,6 +775,7 @@ sre_k_pike_scan(const uint8_t *__restrict__ blob, const uint8_t *const *__restri
     uint8_t *base = ctx_base + (size_t) i * ctx_stride;
     vm.h = reinterpret_cast<PikeHdr *>(base);
     vm.tags = reinterpret_cast<uint32_t *>(base + L.tags);
+    vm.initial = reinterpret_cast<uint32_t *>(base + L.initial);
     vm.nodes[0] = base + L.nodes[0];
     vm.nodes[1] = base + L.nodes[1];
     vm.matched = reinterpret_cast<int64_t *>(base + L.matched);

@@ -228,6 +228,14 @@ FINDALL_CASES = [
     (CFG_PATTERNS["cfg2"], b"mail bob@example.com, al@b.c; x@y"),
     (CFG_PATTERNS["cfg4"], b"see http://a.b/c?d=e and ftp://host/ and x://y "),
     (CFG_PATTERNS["cfg1"], b"abccc" * 10 + b"aaabbccbaaaaaaa"),
+    # the leading-byte skip re-seeding a search that already holds a match
+    # (sre_vm_pike.c:256-309: the initial-state test ignores the last thread)
+    ([rb"(a+)(b+)?"], b"b a\nca"),
+    ([rb"(a+)(b+)?"], b" a\nc"),
+    ([rb"(a+)(b+)?"], b"\n \n b a\nca.xx b.bcxaa\nbaa\n"),
+    ([rb"ab?"], b"xa  ab a"),
+    ([rb"a(b|c)?"], b"a a ab ac a"),
+    ([rb"[ab]c?"], b"a.b.bc..a"),
 ]
 
 

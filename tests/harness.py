@@ -83,7 +83,7 @@ def oracle_lib():
         L.sre_oracle_thompson_exec.argtypes = [_vp, _vp, _sz, ctypes.c_uint]
         L.sre_oracle_thompson_free.argtypes = [_vp]
         L.sre_oracle_pike_count.restype = _ssz
-        L.sre_oracle_pike_count.argtypes = [_vp, _vp, _sz, _pssz, _sz, _sz]
+        L.sre_oracle_pike_count.argtypes = [_vp, _vp, _sz, _pssz, _sz, _sz, _pssz]
         _oracle = L
     return _oracle
 
@@ -142,8 +142,11 @@ class OracleEngine:
         L = oracle_lib()
         spans = (ctypes.c_ssize_t * (max(max_spans, 1) * (nov + 1)))()
         buf = ctypes.create_string_buffer(bytes(data), max(len(data), 1))
-        n = L.sre_oracle_pike_count(prog.h, ctypes.cast(buf, _vp), len(data), spans, nov, max_spans)
+        final = ctypes.c_ssize_t(0)
+        n = L.sre_oracle_pike_count(prog.h, ctypes.cast(buf, _vp), len(data), spans, nov, max_spans,
+                                    ctypes.byref(final))
         got = [list(spans[i * (nov + 1):(i + 1) * (nov + 1)]) for i in range(min(n, max_spans))]
+        self.final_rc = final.value
         return n, got
 
 

@@ -1,0 +1,153 @@
+"""The step automaton + lineage tables (sregex_amd/csrc/sre_dfa.cpp), checked on
+the CPU through a test-only sequential model (tests/dfa_sim.cpp) against the
+reference goldens and the oracle.  This pins the ALGORITHM of the table-driven
+scanner — control flow by automaton, captures by backward lineage walk —
+independently of the GPU kernels."""
+import ctypes
+import os
+import random
+import subprocess
+
+import pytest
+
+import sregex_amd as S
+import harness
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+_vp, _i64 = ctypes.c_void_p, ctypes.c_int64
+
+
+@pytest.fixture(scope="module")
+def sim(lib):
+    out = os.path.join(HERE, "_build")
+    os.makedirs(out, exist_ok=True)
+    so = os.path.join(out, "libdfasim.so")
+    srcs = [os.path.join(HERE, "dfa_sim.cpp"), os.path.join(ROOT, "sregex_amd", "csrc", "sre_dfa.cpp")]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["g++", "-O2", "-g", "-std=c++17", "-shared", "-fPIC", "-o", so] + srcs +
+                              ["-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "sregex_amd", "csrc")])
+    L = ctypes.CDLL(so)
+    L.dfa_sim_build.restype = _vp
+    L.dfa_sim_build.argtypes = [_vp, ctypes.c_uint32, ctypes.POINTER(ctypes.c_char_p)]
+    L.dfa_sim_free.argtypes = [_vp]
+    L.dfa_sim_nstates.argtypes = [_vp]
+    L.dfa_sim_nstates.restype = ctypes.c_uint32
+    L.dfa_sim_max_threads.argtypes = [_vp]
+    L.dfa_sim_max_threads.restype = ctypes.c_uint32
+    L.dfa_sim_findall.restype = _i64
+    L.dfa_sim_findall.argtypes = [_vp, _vp, ctypes.c_char_p, _i64, ctypes.POINTER(_i64), _i64, _i64]
+    L.dfa_sim_thompson.restype = _i64
+    L.dfa_sim_thompson.argtypes = [_vp, ctypes.c_char_p, _i64]
+    return L
+
+
+def _build(sim, prog, cap=4096):
+    why = ctypes.c_char_p()
+    d = sim.dfa_sim_build(prog.h, cap, ctypes.byref(why))
+    return d, (why.value or b"").decode()
+
+
+def _findall(sim, d, prog, ncaps, data, limit=1 << 20):
+    nov = 2 * (ncaps + 1)
+    cap = min(limit, len(data) + 2)
+    out = (_i64 * (cap * (nov + 1)))()
+    n = sim.dfa_sim_findall(d, prog.h, bytes(data), len(data), out, nov, cap)
+    tail = []
+    if n < 0:                      # the iteration ended with SRE_ERROR after -n-1 matches
+        n, tail = -n - 1, [[S.SRE_ERROR]]
+    return [list(out[i * (nov + 1):(i + 1) * (nov + 1)]) for i in range(n)] + tail
+
+
+def test_model_first_match_on_all_assertion_free_blocks(sim, blocks):
+    admitted = declined = 0
+    bad = []
+    for blk in blocks:
+        subject = bytes.fromhex(blk["s"])
+        for name, regexes, flags, multi, ref in harness.block_variants(blk):
+            if ref["rc"] != 0:
+                continue
+            with S.Pool() as pool:
+                prog = S.compile(pool, S.parse(pool, regexes, flags, multi))
+                d, why = _build(sim, prog)
+                if not d:
+                    declined += 1
+                    continue
+                admitted += 1
+                got = _findall(sim, d, prog, ref["ncaps"], subject, 1)
+                line = ("pike match %d%s" % (got[0][0], harness._fmt_caps(got[0][1:], 2 * (ref["ncaps"] + 1)))
+                        if got else "pike no match")
+                th = "thompson " + ("match" if sim.dfa_sim_thompson(d, subject, len(subject)) == 0 else "no match")
+                if line != ref["res"][4] or th != ref["res"][0]:
+                    bad.append((blk["file"], blk["name"], name, line, ref["res"][4], th, ref["res"][0]))
+                sim.dfa_sim_free(d)
+    assert admitted > 1400, (admitted, declined)
+    assert not bad, (len(bad), bad[:5])
+
+
+def test_model_findall_goldens(sim):
+    n = 0
+    for rec in harness.load_jsonl("findall.jsonl"):
+        pats = [bytes.fromhex(h) for h in rec["re"]]
+        data = bytes.fromhex(rec["s"])
+        with S.Pool() as pool:
+            prog = S.compile(pool, S.parse(pool, pats))
+            d, why = _build(sim, prog)
+            if not d:
+                continue
+            want = rec["matches"] if rec["matches"][-1] == [S.SRE_ERROR] else rec["matches"][:-1]
+            assert _findall(sim, d, prog, rec["ncaps"], data) == want, rec["re"]
+            sim.dfa_sim_free(d)
+            n += 1
+    assert n >= 8
+
+
+def test_model_gen_data_goldens(sim):
+    for rec in harness.load_jsonl("gen_data.jsonl"):
+        pats = [bytes.fromhex(h) for h in rec["re"]]
+        data = S.gen_data_host(rec["n"], bytes.fromhex(rec["tail"]))
+        with S.Pool() as pool:
+            prog = S.compile(pool, S.parse(pool, pats))
+            d, why = _build(sim, prog)
+            assert d, why
+            got = _findall(sim, d, prog, rec["ncaps"], data, 1)
+            if rec["pike_rc"] < 0:
+                assert got == []
+            else:
+                assert got == [[rec["pike_rc"]] + rec["pike_ov"]], (rec["cfg"], rec["n"])
+            assert sim.dfa_sim_thompson(d, data, len(data)) == rec["thompson"]
+            sim.dfa_sim_free(d)
+
+
+def test_model_vs_oracle_random_findall(sim):
+    ora = harness.OracleEngine()
+    rng = random.Random(7)
+    zoo = [
+        [rb"(a*)*b"], [rb"(a*)+"], [rb"(a|b)*?c"], [rb"(a+)(b+)?"], [rb"x*"], [rb"(|a)+"], [rb"a{2,3}b{0,2}"],
+        [rb"\Aab|\n^b"], [rb"^a|^c|c"], [rb"(a?)*?b"], [rb"((a)|b)+"], [rb"a.c"], [rb"[a-c]+\.[^b]"],
+        [rb"a", rb"ab", rb"\s+", rb"b"], [rb"(a)|b", rb"(b)(c)?"], [rb"^", rb"a"], [rb"(?:a.*b|a)"],
+        [rb"^b", rb"(a)\n"], [rb"(a|ab)(c|bcd)(d*)"],
+    ]
+    alphabet = b"ab c\n.x"
+    for pats in zoo:
+        with S.Pool() as pool:
+            re = S.parse(pool, pats)
+            prog = S.compile(pool, re)
+            d, why = _build(sim, prog)
+            assert d, (pats, why)
+            for _ in range(80):
+                data = bytes(rng.choice(alphabet) for _ in range(rng.randrange(0, 40)))
+                want = harness.findall(ora, prog, re.ncaps, data)
+                if want[-1] != [S.SRE_ERROR]:
+                    want = want[:-1]
+                assert _findall(sim, d, prog, re.ncaps, data) == want, (pats, data)
+            sim.dfa_sim_free(d)
+
+
+def test_builder_declines_what_it_cannot_model(sim):
+    with S.Pool() as pool:
+        for src in (rb"a$", rb"\bfoo", rb"a\z", rb"\Ba"):
+            d, why = _build(sim, S.compile(pool, S.parse(pool, [src])))
+            assert not d and "look-ahead" in why
+        d, why = _build(sim, S.compile(pool, S.parse(pool, [rb"[ab]*a[ab]{12}"])), 256)
+        assert not d and "cap" in why

@@ -100,6 +100,7 @@ def test_findall_iteration_matches_reference(lib):
             n, spans = ENG.count(prog, data, 2 * (rec["ncaps"] + 1), 1024)
             assert n == len(rec["matches"]) - 1
             assert spans == rec["matches"][:-1]
+            assert ENG.final_rc == rec["matches"][-1][0]
 
 
 # ---------------------------------------------------------------- live vs _ref
