@@ -60,8 +60,23 @@ SRE_API sre_hip_scanner_t *sre_hip_scanner_create(sre_pool_t *pool,
 SRE_API int sre_hip_scanner_engine(sre_hip_scanner_t *sc);
 
 /*
+ * Tuning / testing knob of the table-driven scanner: bytes per segment (one
+ * lane walks one segment).  0 restores the automatic choice (about 256K lanes
+ * per call, at least 4 KiB per segment); otherwise a multiple of 64.
+ */
+SRE_API int sre_hip_scanner_set_segment_bytes(sre_hip_scanner_t *sc, size_t bytes);
+
+/* diagnostics: fix-up rounds the last scan needed (0 = every assumed segment
+ * entry state was right) */
+SRE_API int sre_hip_scanner_last_fixups(sre_hip_scanner_t *sc);
+
+/*
  * Per-stream result record, in sre_int_t units:
- *     [0] rc     regex id (>= 0; SRE_OK for Thompson), SRE_DECLINED, SRE_ERROR
+ *     [0] rc     regex id (>= 0; SRE_OK for Thompson) of the (last) match, or
+ *                SRE_DECLINED when there is none; SRE_ERROR when the iteration
+ *                of COUNT mode ended with SRE_ERROR (sre_vm_pike.c:165-168 after
+ *                :616-622) — [1] and the ovector are still those of the matches
+ *                found before
  *     [1] count  matches found (COUNT mode; 0/1 otherwise)
  *     [2..]      ovector of the (last) match, 2 * (max_ncaps + 1) slots,
  *                absolute byte offsets, -1 = unset   (sre_vm_pike.c:945-989)

@@ -57,6 +57,8 @@ API = {
     "sre_hip_scanner_create": (_vp, [_vp, _vp, ctypes.c_int, ctypes.c_int]),
     "sre_hip_scanner_engine": (ctypes.c_int, [_vp]),
     "sre_hip_scanner_result_slots": (_sz, [_vp]),
+    "sre_hip_scanner_set_segment_bytes": (ctypes.c_int, [_vp, _sz]),
+    "sre_hip_scanner_last_fixups": (ctypes.c_int, [_vp]),
     "sre_hip_scan_enqueue": (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_sz), _sz, _vp]),
     "sre_hip_scan_results": (ctypes.c_int, [_vp, _pssz]),
     "sre_hip_scan_batch": (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_sz), _sz, _pssz, _vp]),
@@ -268,6 +270,14 @@ class Scanner:
         self.slots = self.lib.sre_hip_scanner_result_slots(self.h)
         self.engine = self.lib.sre_hip_scanner_engine(self.h)
         self._n = 0
+
+    def set_segment_bytes(self, nbytes):
+        if self.lib.sre_hip_scanner_set_segment_bytes(self.h, nbytes) != 0:
+            raise ValueError("segment size must be a multiple of 64")
+
+    @property
+    def last_fixups(self):
+        return self.lib.sre_hip_scanner_last_fixups(self.h)
 
     def enqueue(self, d_ptrs, lens, hip_stream=None):
         n = len(d_ptrs)

@@ -121,6 +121,7 @@ struct Builder {
             seen_start = 0;
             var = 0;
         }
+        if (!d->has_caret) var = 0;      /* all three initial lists coincide */
         std::vector<uint32_t> key(pcs);
         key.push_back((matched ? 1u : 0u) | ((uint32_t) seen_start << 1) | ((uint32_t) var << 3));
         auto it = ids.find(key);
@@ -315,6 +316,7 @@ sre_dfa_build(const sre_program_t *prog, uint32_t max_states, const char **why)
     }
 
     d->nstates = (uint32_t) b.lists.size();
+    d->seen_start = b.sss;
     d->nthreads.resize(d->nstates);
     d->list_off.resize(d->nstates + 1);
     for (uint32_t s = 0; s < d->nstates; s++) {

@@ -67,6 +67,7 @@ struct sre_dfa_s {
     std::vector<uint8_t>         lin_parent; /* old-list index or SRE_DFA_NO_PARENT */
     std::vector<uint64_t>        lin_saves;  /* slots saved on the closure path (value pos + 1) */
     std::vector<uint8_t>         matched;    /* [nstates] a match is pending in this state */
+    std::vector<uint8_t>         seen_start; /* [nstates] 0/1, 2 = reached by a leading-byte skip */
     std::vector<uint16_t>        nthreads;   /* [nstates] list length */
     std::vector<uint32_t>        list_off;   /* [nstates + 1] into list_pcs */
     std::vector<uint32_t>        list_pcs;   /* the thread lists themselves (debug / tests) */

@@ -11,6 +11,8 @@
 #include <sregex_hip.h>
 #include "sre_hip_runtime.h"
 #include "sre_hip_scan.h"
+#include "sre_scan_host.h"
+#include "sre_dfa.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -31,6 +33,19 @@ struct sre_hip_scanner_s {
     const void       **h_ptrs;
     size_t             last_n;
     hipStream_t        last_stream;
+    /* ENGINE_SCAN */
+    sre_dfa_t                *dfa;
+    sre_scan_device_tables_t *tab;
+    uint32_t                  seg_override;     /* 0 = automatic */
+    sre_scan_geom_t           geom;
+    uint64_t                 *d_seg_first, *h_seg_first;
+    sre_seg_summary_t        *d_sum;
+    size_t                    sum_cap;
+    sre_stream_status_t      *d_status, *h_status;
+    int64_t                  *d_lo, *h_lo;
+    uint16_t                 *d_scratch;
+    size_t                    scratch_cap;
+    int                       fixup_rounds;     /* of the last scan (diagnostics) */
 };
 
 static void
@@ -43,6 +58,16 @@ scanner_release(void *data)
     if (sc->d_ctx) (void) hipFree(sc->d_ctx);
     if (sc->h_lens) (void) hipHostFree(sc->h_lens);
     if (sc->h_ptrs) (void) hipHostFree(sc->h_ptrs);
+    if (sc->d_seg_first) (void) hipFree(sc->d_seg_first);
+    if (sc->h_seg_first) (void) hipHostFree(sc->h_seg_first);
+    if (sc->d_sum) (void) hipFree(sc->d_sum);
+    if (sc->d_status) (void) hipFree(sc->d_status);
+    if (sc->h_status) (void) hipHostFree(sc->h_status);
+    if (sc->d_lo) (void) hipFree(sc->d_lo);
+    if (sc->h_lo) (void) hipHostFree(sc->h_lo);
+    if (sc->d_scratch) (void) hipFree(sc->d_scratch);
+    sre_scan_tables_release(sc->tab);
+    sre_dfa_free(sc->dfa);
     free(sc);
 }
 
@@ -78,17 +103,26 @@ sre_hip_scanner_create(sre_pool_t *pool, sre_program_t *prog, int mode, int engi
         if (prog->multi_ncaps[i] > maxcaps) maxcaps = prog->multi_ncaps[i];
     }
     sc->ovec_slots = 2 * (maxcaps + 1);
-
-    if (engine == SRE_HIP_ENGINE_SCAN) {
-        fprintf(stderr, "[sregex-hip] the table-driven scanner is not available for this program\n");
-        free(sc);
-        return NULL;
-    }
     sc->engine = SRE_HIP_ENGINE_VM;
+
+    if (engine != SRE_HIP_ENGINE_VM) {
+        /* compile step: step automaton + device tables (independent of any input) */
+        const char *why = NULL;
+        sc->dfa = sre_dfa_build(prog, 4 * SRE_SCAN_MAX_STATES, &why);
+        if (sc->dfa) sc->tab = sre_scan_tables_build(prog, sc->dfa, mode, &why);
+        if (sc->tab) {
+            sc->engine = SRE_HIP_ENGINE_SCAN;
+        } else if (engine == SRE_HIP_ENGINE_SCAN) {
+            fprintf(stderr, "[sregex-hip] table-driven scanner not available: %s\n",
+                    why ? why : "unknown");
+            scanner_release(sc);
+            return NULL;
+        }
+    }
     sc->ctx_stride = mode == SRE_HIP_THOMPSON ? dp->thompson_layout.total : dp->pike_layout.total;
 
     if (sre_pool_add_cleanup(pool, scanner_release, sc) != SRE_OK) {
-        free(sc);
+        scanner_release(sc);
         return NULL;
     }
     return sc;
@@ -106,6 +140,20 @@ sre_hip_scanner_result_slots(sre_hip_scanner_t *sc)
     return 2 + (size_t) sc->ovec_slots;
 }
 
+extern "C" SRE_API int
+sre_hip_scanner_set_segment_bytes(sre_hip_scanner_t *sc, size_t bytes)
+{
+    if (bytes != 0 && (bytes % SRE_SCAN_TILE != 0 || bytes > (1u << 30))) return -1;
+    sc->seg_override = (uint32_t) bytes;
+    return 0;
+}
+
+extern "C" SRE_API int
+sre_hip_scanner_last_fixups(sre_hip_scanner_t *sc)
+{
+    return sc->fixup_rounds;
+}
+
 static int
 scanner_reserve(sre_hip_scanner_t *sc, size_t n)
 {
@@ -115,11 +163,20 @@ scanner_reserve(sre_hip_scanner_t *sc, size_t n)
         if (sc->d_records) (void) hipFree(sc->d_records);
         if (sc->h_lens) (void) hipHostFree(sc->h_lens);
         if (sc->h_ptrs) (void) hipHostFree(sc->h_ptrs);
+        if (sc->d_seg_first) (void) hipFree(sc->d_seg_first);
+        if (sc->h_seg_first) (void) hipHostFree(sc->h_seg_first);
+        if (sc->d_status) (void) hipFree(sc->d_status);
+        if (sc->h_status) (void) hipHostFree(sc->h_status);
+        if (sc->d_lo) (void) hipFree(sc->d_lo);
+        if (sc->h_lo) (void) hipHostFree(sc->h_lo);
         sc->d_ptrs = NULL;
         sc->d_lens = NULL;
         sc->d_records = NULL;
         sc->h_lens = NULL;
         sc->h_ptrs = NULL;
+        sc->d_seg_first = sc->h_seg_first = NULL;
+        sc->d_status = sc->h_status = NULL;
+        sc->d_lo = sc->h_lo = NULL;
         sc->cap_streams = 0;
         SRE_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&sc->d_ptrs), n * sizeof(void *)));
         SRE_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&sc->d_lens), n * sizeof(uint64_t)));
@@ -127,6 +184,12 @@ scanner_reserve(sre_hip_scanner_t *sc, size_t n)
                               n * (2 + (size_t) sc->ovec_slots) * sizeof(int64_t)));
         SRE_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&sc->h_lens), n * sizeof(uint64_t), 0));
         SRE_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&sc->h_ptrs), n * sizeof(void *), 0));
+        SRE_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&sc->d_seg_first), (n + 1) * sizeof(uint64_t)));
+        SRE_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&sc->h_seg_first), (n + 1) * sizeof(uint64_t), 0));
+        SRE_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&sc->d_status), n * sizeof(sre_stream_status_t)));
+        SRE_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&sc->h_status), n * sizeof(sre_stream_status_t), 0));
+        SRE_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&sc->d_lo), n * sizeof(int64_t)));
+        SRE_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&sc->h_lo), n * sizeof(int64_t), 0));
         sc->cap_streams = n;
     }
     if (sc->engine == SRE_HIP_ENGINE_VM && n * sc->ctx_stride > sc->ctx_cap) {
@@ -141,11 +204,61 @@ hip_failed:
     return -1;
 }
 
+/* segment geometry: about 256K lanes for the whole batch (256 CUs x 16 waves),
+ * segments a multiple of the 64-byte tile and at least 4 KiB so that the
+ * 256-byte warm-up stays a few percent */
+static int
+scan_geometry(sre_hip_scanner_t *sc, size_t nstreams)
+{
+    uint64_t total = 0;
+    for (size_t i = 0; i < nstreams; i++) total += sc->h_lens[i];
+    uint64_t seg = sc->seg_override;
+    if (seg == 0) {
+        seg = (total / 262144 + SRE_SCAN_TILE - 1) / SRE_SCAN_TILE * SRE_SCAN_TILE;
+        if (seg < 4096) seg = 4096;
+    }
+    uint64_t nsegs = 0;
+    for (size_t i = 0; i < nstreams; i++) {
+        sc->h_seg_first[i] = nsegs;
+        uint64_t k = (sc->h_lens[i] + seg - 1) / seg;
+        nsegs += k ? k : 1;             /* an empty stream still takes its EOF step */
+    }
+    sc->h_seg_first[nstreams] = nsegs;
+    sc->geom.streams = reinterpret_cast<const uint8_t *const *>(sc->d_ptrs);
+    sc->geom.lens = sc->d_lens;
+    sc->geom.seg_first = sc->d_seg_first;
+    sc->geom.nstreams = (uint32_t) nstreams;
+    sc->geom.seg_bytes = (uint32_t) seg;
+    sc->geom.nsegs = nsegs;
+
+    if (nsegs > sc->sum_cap) {
+        if (sc->d_sum) (void) hipFree(sc->d_sum);
+        sc->d_sum = NULL;
+        sc->sum_cap = 0;
+        SRE_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&sc->d_sum), nsegs * sizeof(sre_seg_summary_t)));
+        sc->sum_cap = nsegs;
+    }
+    {
+        size_t need = nstreams * ((size_t) seg + 16);
+        if (need > sc->scratch_cap) {
+            if (sc->d_scratch) (void) hipFree(sc->d_scratch);
+            sc->d_scratch = NULL;
+            sc->scratch_cap = 0;
+            SRE_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&sc->d_scratch), need * sizeof(uint16_t)));
+            sc->scratch_cap = need;
+        }
+    }
+    return 0;
+hip_failed:
+    return -1;
+}
+
 extern "C" SRE_API int
 sre_hip_scan_enqueue(sre_hip_scanner_t *sc, const void *const *d_streams, const size_t *lens,
     size_t nstreams, void *hip_stream)
 {
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    sc->fixup_rounds = 0;
     if (nstreams == 0) {
         sc->last_n = 0;
         return 0;
@@ -165,6 +278,16 @@ sre_hip_scan_enqueue(sre_hip_scanner_t *sc, const void *const *d_streams, const 
         SRE_HIP_TRY(sre_launch_vm_scan(sc->dp->d_blob, sc->mode, sc->d_ptrs, sc->d_lens,
                                        (uint32_t) nstreams, sc->d_ctx, sc->ctx_stride,
                                        sc->d_records, sc->ovec_slots, stream));
+    } else {
+        if (scan_geometry(sc, nstreams) != 0) return -1;
+        SRE_HIP_TRY(hipMemcpyAsync(sc->d_seg_first, sc->h_seg_first, (nstreams + 1) * sizeof(uint64_t),
+                                   hipMemcpyHostToDevice, stream));
+        /* speculative pass, chain check, captures — all queued; results() only
+         * has to look at the status words */
+        SRE_HIP_TRY(sre_launch_scan(sc->tab->d_tab, sc->tab->h, sc->geom, sc->d_sum, NULL, stream));
+        SRE_HIP_TRY(sre_launch_verify(sc->tab->h, sc->geom, sc->d_sum, sc->d_status, stream));
+        SRE_HIP_TRY(sre_launch_captures(sc->tab->d_tab, sc->tab->h, sc->geom, sc->d_sum, sc->d_status,
+                                        sc->d_scratch, sc->d_records, sc->ovec_slots, stream));
     }
     sc->last_n = nstreams;
     sc->last_stream = stream;
@@ -177,10 +300,43 @@ extern "C" SRE_API int
 sre_hip_scan_results(sre_hip_scanner_t *sc, sre_int_t *results)
 {
     if (sc->last_n == 0) return 0;
-    size_t bytes = sc->last_n * (2 + (size_t) sc->ovec_slots) * sizeof(int64_t);
-    SRE_HIP_TRY(hipMemcpyAsync(results, sc->d_records, bytes, hipMemcpyDeviceToHost,
-                               sc->last_stream));
-    SRE_HIP_TRY(hipStreamSynchronize(sc->last_stream));
+    const size_t n = sc->last_n;
+    hipStream_t  stream = sc->last_stream;
+
+    if (sc->engine == SRE_HIP_ENGINE_SCAN) {
+        /* segments behind a broken state chain are re-run from the exact carried
+         * state until every stream's verified prefix reaches its end */
+        for (;;) {
+            SRE_HIP_TRY(hipMemcpyAsync(sc->h_status, sc->d_status, n * sizeof(sre_stream_status_t),
+                                       hipMemcpyDeviceToHost, stream));
+            SRE_HIP_TRY(hipStreamSynchronize(stream));
+            size_t pending = 0;
+            for (size_t i = 0; i < n; i++) {
+                if (sc->h_status[i].done) {
+                    sc->h_lo[i] = -1;
+                } else {
+                    sc->h_lo[i] = sc->h_status[i].first_bad;
+                    pending++;
+                }
+            }
+            if (pending == 0) break;
+            if (++sc->fixup_rounds > 1000000) {
+                fprintf(stderr, "[sregex-hip] scanner fix-up did not converge\n");
+                return -1;
+            }
+            SRE_HIP_TRY(hipMemcpyAsync(sc->d_lo, sc->h_lo, n * sizeof(int64_t), hipMemcpyHostToDevice, stream));
+            SRE_HIP_TRY(sre_launch_scan(sc->tab->d_tab, sc->tab->h, sc->geom, sc->d_sum, sc->d_lo, stream));
+            SRE_HIP_TRY(sre_launch_verify(sc->tab->h, sc->geom, sc->d_sum, sc->d_status, stream));
+            SRE_HIP_TRY(sre_launch_captures(sc->tab->d_tab, sc->tab->h, sc->geom, sc->d_sum,
+                                            sc->d_status, sc->d_scratch, sc->d_records,
+                                            sc->ovec_slots, stream));
+        }
+    }
+    {
+        size_t bytes = n * (2 + (size_t) sc->ovec_slots) * sizeof(int64_t);
+        SRE_HIP_TRY(hipMemcpyAsync(results, sc->d_records, bytes, hipMemcpyDeviceToHost, stream));
+        SRE_HIP_TRY(hipStreamSynchronize(stream));
+    }
     return 0;
 hip_failed:
     return -1;

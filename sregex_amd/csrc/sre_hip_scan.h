@@ -1,5 +1,6 @@
 /*
- * sre_hip_scan.h — launchers of sre_hip_scan.hip.
+ * sre_hip_scan.h — device tables, per-segment summaries and launchers of the
+ * table-driven segment-parallel scanner (sre_hip_scan.hip).
  */
 #ifndef SRE_HIP_SCAN_H
 #define SRE_HIP_SCAN_H
@@ -7,7 +8,97 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define SRE_CEILING_GRID 2048
+#define SRE_CEILING_GRID   2048
+
+/* ---- fast table: one 32-bit entry per (state, byte), staged into LDS ----
+ *   bits 31..10  byte offset of the next state's row (state * 1024)
+ *   bit  0       SLOW: this transition carries a match event or kills the list
+ *   bit  1       COUNT mode only: a match completes here and the next search
+ *                starts at the next byte (entry already points at its initial
+ *                state) — counted in the fast loop */
+#define SRE_FAST_SLOW       1u
+#define SRE_FAST_COUNT      2u
+#define SRE_FAST_ROW_BYTES  1024u
+
+#define SRE_SCAN_MAX_STATES   64u     /* LDS budget: 64 KiB of fast table */
+#define SRE_SCAN_MAX_THREADS  16u     /* lineage vectors are 16 bytes */
+#define SRE_SCAN_BLOCK        256u    /* lanes = segments per workgroup */
+#define SRE_SCAN_TILE         64u     /* bytes per lane per LDS round */
+#define SRE_SCAN_WARMUP       256u    /* speculative warm-up before a segment */
+
+/* full transition record (global memory; slow path and lineage kernels) */
+typedef struct {
+    uint32_t next;
+    uint8_t  kind;          /* SRE_DFA_EV_* */
+    uint8_t  src;           /* matching thread's index in the old list */
+    uint16_t regex;
+    uint32_t lin_off;       /* per new thread: parent / saves */
+    uint16_t lin_n;
+    uint8_t  skipped;
+    uint8_t  pad;
+    uint64_t saves;         /* DONE: slots written on the way to MATCH */
+} sre_dev_trans_t;
+
+typedef struct {
+    uint32_t nstates, ncls, nslots, max_threads;
+    uint32_t init[4];                   /* SRE_DFA_INIT_* -> state */
+    int32_t  mode;                      /* SRE_HIP_* */
+    uint32_t fast_bytes;                /* nstates * 1024 */
+    const uint32_t        *fast;        /* [nstates][256] */
+    const uint8_t         *cls;         /* [256] */
+    const sre_dev_trans_t *trans;       /* [nstates][ncls + 1], then 3 pseudo rows for the initial closures */
+    const uint8_t         *lin_parent;
+    const uint64_t        *lin_saves;
+    const uint8_t         *state_flags; /* [nstates] bit0 matched, bits 1-2 seen_start (2 = reached by a skip) */
+    const uint32_t        *list_off;    /* [nstates + 1] */
+    const uint32_t        *list_pcs;
+    const uint32_t        *multi_ncaps; /* [nregexes] */
+    uint32_t nregexes, pad;
+} sre_scan_tables_t;
+
+/* what one lane learnt about its segment */
+typedef struct {
+    uint32_t s_in;          /* state assumed at the segment start (after warm-up) */
+    uint32_t s_out;         /* state at the segment end */
+    uint32_t flags;         /* SRE_SUM_* */
+    uint32_t pad;
+    /* SRE_SUM_PENDING: the search in flight at the segment end holds a match */
+    uint32_t pe_state, pe_sym;      /* state before the event's transition, its symbol */
+    int64_t  pe_pos, pe_sp;         /* event position; start of its search (-1 unknown) */
+    /* SRE_SUM_LASTEV: FIRST: last match event seen here; COUNT: last completed match */
+    uint32_t lm_state, lm_sym;
+    int64_t  lm_pos, lm_sp;
+    int64_t  term_pos;      /* position where the scan of this stream ended, -1 none */
+    int64_t  count;         /* COUNT: searches completed with a match in this segment */
+    int64_t  cur_sp;        /* start of the search in flight at the segment end, -1 unknown */
+} sre_seg_summary_t;
+
+#define SRE_SUM_PENDING   1u
+#define SRE_SUM_TERM      2u   /* the scan of this stream ended inside this segment */
+#define SRE_SUM_LASTEV    4u
+#define SRE_SUM_ERROR     8u   /* COUNT: ... and the iteration ended with SRE_ERROR */
+
+/* per-stream outcome of verify + reduce */
+typedef struct {
+    int64_t  first_bad;     /* first segment whose assumed entry state was wrong, or nseg */
+    int64_t  limit;         /* segments [0, limit) are verified and sufficient */
+    int64_t  count;
+    int64_t  rc;            /* regex id / SRE_DECLINED / SRE_ERROR */
+    int64_t  ev_pos, ev_sp;
+    uint32_t ev_state, ev_sym;
+    int64_t  ev_seg;        /* segment holding the event */
+    int32_t  done;          /* 1: result final, 0: needs a fix-up round from first_bad */
+    int32_t  error;         /* COUNT: the iteration ended with SRE_ERROR */
+} sre_stream_status_t;
+
+typedef struct {
+    const uint8_t *const *streams;  /* device array of device pointers */
+    const uint64_t *lens;
+    const uint64_t *seg_first;      /* [nstreams + 1] prefix of segment counts */
+    uint32_t nstreams;
+    uint32_t seg_bytes;
+    uint64_t nsegs;
+} sre_scan_geom_t;
 
 #ifdef __cplusplus
 extern "C" {
@@ -16,6 +107,17 @@ hipError_t sre_launch_gen_data(void *d_dst, uint64_t n, uint64_t tail_len, const
     hipStream_t stream);
 hipError_t sre_launch_read_ceiling(const void *d_src, uint64_t n, uint32_t *d_sink,
     hipStream_t stream);
+
+/* control pass over segments [lo[s], nseg_s) of every stream; lo == NULL: all.
+ * carry[s] (with lo) = exact entry of segment lo[s] taken from summaries[lo[s]-1]. */
+hipError_t sre_launch_scan(const sre_scan_tables_t *d_tab, sre_scan_tables_t h_tab,
+    sre_scan_geom_t geom, sre_seg_summary_t *d_sum, const int64_t *d_lo, hipStream_t stream);
+hipError_t sre_launch_verify(sre_scan_tables_t h_tab, sre_scan_geom_t geom,
+    const sre_seg_summary_t *d_sum, sre_stream_status_t *d_status, hipStream_t stream);
+/* captures of each stream's final match -> records [rc, count, ovector] */
+hipError_t sre_launch_captures(const sre_scan_tables_t *d_tab, sre_scan_tables_t h_tab,
+    sre_scan_geom_t geom, const sre_seg_summary_t *d_sum, const sre_stream_status_t *d_status,
+    uint16_t *d_scratch, int64_t *d_records, uint32_t ovec_slots, hipStream_t stream);
 #ifdef __cplusplus
 }
 #endif

@@ -1,9 +1,38 @@
 /*
- * sre_hip_scan.hip — table-driven segment-parallel scanner kernels (gfx950)
- * and the two utility kernels of the measurement harness.
+ * sre_hip_scan.hip — the table-driven segment-parallel scanner (gfx950) and the
+ * two utility kernels of the measurement harness.
+ *
+ * Data layout.  A stream is cut into fixed segments; ONE LANE walks ONE
+ * SEGMENT, so a wavefront advances 64 independent segments per step and every
+ * input byte is examined by exactly one lane (plus a 256-byte speculative
+ * warm-up per segment).  A workgroup of 256 lanes stages its 256 segments
+ * through LDS in 64-byte rows: the global loads are 16 B per lane with four
+ * consecutive lanes covering one 64-byte row piece (coalesced, each 128-byte
+ * line is fetched once), the rows are padded to 80 bytes so that the per-lane
+ * ds_read_b128 of "my row" is bank-conflict free.  The automaton's fast table
+ * (one 32-bit word per state x byte, <= 64 KiB) lives in LDS next to the tile;
+ * the per-byte work of a lane is one dependent LDS lookup.
+ *
+ * Exactness.  A lane does not know the true automaton state at the start of
+ * its segment; it assumes the state reached after a short warm-up and records
+ * what it assumed (s_in) and where it ended (s_out).  sre_k_verify checks the
+ * chain s_out[k-1] == s_in[k]; segments behind a broken link are re-run from
+ * the exact carried state.  Nothing is reported from an unverified segment.
+ *
+ * Semantics reproduced here, per reference exec (sre_vm_pike.c:148-689): the
+ * search runs until the thread list dies (state DEAD) or end of input (one
+ * extra step with the EOF symbol, :235); the LAST match event seen wins
+ * (:535-553); in COUNT mode the next search starts at the match end, one byte
+ * further after an empty match (:179-196, :624-628).
  */
 #include <hip/hip_runtime.h>
 #include "sre_hip_scan.h"
+
+#define SRE_HIP_PIKE_COUNT 2
+#define EV_DONE 1
+#define EV_POP  2
+#define RC_DECLINED (-5)
+#define RC_ERROR    (-1)
 
 /* ---- benchmark stream generator: bench/gen-data.pl:9 restated on device ---- */
 
@@ -77,5 +106,654 @@ sre_launch_read_ceiling(const void *d_src, uint64_t n, uint32_t *d_sink, hipStre
     if (nvec == 0) return hipSuccess;
     hipLaunchKernelGGL(sre_k_read_ceiling, dim3(SRE_CEILING_GRID), dim3(256), 0, stream,
                        static_cast<const uint4 *>(d_src), nvec, d_sink);
+    return hipGetLastError();
+}
+
+/* ======================================================================= scan */
+
+namespace {
+
+constexpr uint32_t ROW_BYTES = SRE_SCAN_TILE + 16;      /* padded tile row */
+
+/* the search a lane is currently following */
+struct Walk {
+    const sre_scan_tables_t *T;
+    const uint8_t           *data;      /* stream base */
+    int64_t                  n;         /* stream length */
+    uint32_t st;                        /* automaton state */
+    bool     has_ev;                    /* the search in flight holds a match */
+    uint8_t  ev_kind;
+    uint32_t ev_state, ev_sym;
+    int64_t  ev_pos, ev_sp;
+    int64_t  cur_sp;                    /* start of the search in flight, -1 unknown */
+    bool     lm_valid;                  /* FIRST: last event seen; COUNT: last completed match */
+    uint32_t lm_state, lm_sym;
+    int64_t  lm_pos, lm_sp;
+    int64_t  count;
+    int64_t  term_pos;
+    bool     finished, error, unresolved;
+
+    __device__ void complete_match()
+    {
+        count++;
+        lm_valid = true;
+        lm_state = ev_state;
+        lm_sym = ev_sym;
+        lm_pos = ev_pos;
+        lm_sp = ev_sp;
+        has_ev = false;
+    }
+};
+
+/*
+ * Exact, byte-at-a-time: process positions [p, p_to) — position n is the EOF
+ * step — following every restart the reference's caller would make.  `p` may
+ * move backwards (a search restarts at its predecessor's match end).
+ * warm: speculative warm-up; nothing is counted and a dead list is replaced by
+ * state `warm_seed`.
+ */
+template <int MODE>
+__device__ void slow_run(Walk &w, int64_t p, int64_t p_to, bool warm, uint32_t warm_seed)
+{
+    const sre_scan_tables_t &T = *w.T;
+    const uint32_t           nsym = T.ncls + 1;
+
+    while (p < p_to && !w.finished) {
+        if (p == w.n && ((T.state_flags[w.st] >> 1) & 3) == 2) {
+            /* the leading-byte skip ran to the end of input: the reference
+             * leaves its loop without the EOF step and returns with threads
+             * still listed, which poisons the context (sre_vm_pike.c:304-306,
+             * 616-622): a pending match is returned, the next exec fails */
+            w.term_pos = p;
+            if (MODE == SRE_HIP_PIKE_COUNT && w.has_ev) {
+                w.complete_match();
+                w.error = true;
+            }
+            w.finished = true;
+            return;
+        }
+        const uint32_t         sym = p < w.n ? T.cls[w.data[p]] : T.ncls;
+        const sre_dev_trans_t &tr = T.trans[(size_t) w.st * nsym + sym];
+        if (tr.kind) {
+            w.has_ev = true;
+            w.ev_kind = tr.kind;
+            w.ev_state = w.st;
+            w.ev_sym = sym;
+            w.ev_pos = p;
+            w.ev_sp = w.cur_sp;
+            if (MODE != SRE_HIP_PIKE_COUNT && !warm) {
+                w.lm_valid = true;
+                w.lm_state = w.st;
+                w.lm_sym = sym;
+                w.lm_pos = p;
+                w.lm_sp = w.cur_sp;
+            }
+        }
+        w.st = tr.next;
+        if (w.st != 0) {
+            p++;
+            continue;
+        }
+
+        /* the thread list died: this search is over */
+        if (warm) {
+            w.st = warm_seed;
+            w.has_ev = false;
+            w.cur_sp = -1;
+            p++;
+            continue;
+        }
+        if (MODE != SRE_HIP_PIKE_COUNT) {
+            w.term_pos = p;
+            w.finished = true;
+            return;
+        }
+        if (!w.has_ev) {
+            /* no match: only possible at end of input => DECLINED ends the
+             * iteration.  Earlier it means this lane assumed a matched-mode
+             * state whose event it never saw: it cannot resolve the restart. */
+            if (p < w.n) w.unresolved = true;
+            w.term_pos = p;
+            w.finished = true;
+            return;
+        }
+        {
+            /* next exec: from the match end; one byte further after an empty
+             * match (sre_vm_pike.c:179-196, 624-628) */
+            const bool    empty = (w.ev_kind == EV_POP);
+            const int64_t e = empty ? w.ev_pos : w.ev_pos + 1;
+            w.complete_match();
+            if (empty) {
+                if (e >= w.n) {
+                    w.term_pos = p;
+                    w.finished = true;      /* size == 0 && eof => DECLINED */
+                    return;
+                }
+                w.cur_sp = e + 1;
+            } else {
+                w.cur_sp = e;
+            }
+            w.st = T.init[2];
+            p = w.cur_sp;
+        }
+    }
+}
+
+/* COUNT: matches completed inside one pure-fast 16-byte group were only counted;
+ * recover the last one and the start of the search now in flight. */
+__device__ void resolve_fast_group(Walk &w, int64_t gpos, uint32_t s0, int64_t sp0, bool is_last)
+{
+    const sre_scan_tables_t &T = *w.T;
+    uint32_t st = s0;
+    int64_t  sp = sp0, last_pos = -1, last_sp = -1;
+    uint32_t last_state = 0, last_sym = 0;
+    for (int b = 0; b < 16; b++) {
+        const uint32_t         sym = T.cls[w.data[gpos + b]];
+        const sre_dev_trans_t &tr = T.trans[(size_t) st * (T.ncls + 1) + sym];
+        if (tr.kind && tr.next == 0) {
+            last_pos = gpos + b;
+            last_state = st;
+            last_sym = sym;
+            last_sp = sp;
+            sp = gpos + b + 1;
+            st = T.init[2];
+        } else {
+            st = tr.next;
+        }
+    }
+    if (is_last && last_pos >= 0) {
+        w.lm_valid = true;
+        w.lm_pos = last_pos;
+        w.lm_state = last_state;
+        w.lm_sym = last_sym;
+        w.lm_sp = last_sp;
+    }
+    w.cur_sp = sp;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(SRE_SCAN_BLOCK) void
+sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
+           sre_seg_summary_t *__restrict__ sum, const int64_t *__restrict__ lo)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    __shared__ const uint8_t *row_ptr[SRE_SCAN_BLOCK];
+    __shared__ int64_t        row_len[SRE_SCAN_BLOCK];
+    __shared__ sre_scan_tables_t Ts;
+
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) Ts = *tabp;
+    __syncthreads();
+    const sre_scan_tables_t &T = Ts;
+
+    uint32_t *fast = reinterpret_cast<uint32_t *>(lds);
+    uint8_t  *tile = lds + T.fast_bytes;
+    for (uint32_t i = tid; i < T.fast_bytes / 16; i += SRE_SCAN_BLOCK) {
+        reinterpret_cast<uint4 *>(fast)[i] = reinterpret_cast<const uint4 *>(T.fast)[i];
+    }
+
+    /* ---- which segment am I ---- */
+    const uint64_t g = (uint64_t) blockIdx.x * SRE_SCAN_BLOCK + tid;
+    bool           active = g < G.nsegs;
+    uint32_t       sidx = 0;
+    uint64_t       k = 0;                   /* segment index inside the stream */
+    if (active) {
+        uint32_t a = 0, b = G.nstreams;     /* seg_first[a] <= g < seg_first[b] */
+        while (b - a > 1) {
+            uint32_t m = (a + b) >> 1;
+            if (G.seg_first[m] <= g) a = m; else b = m;
+        }
+        sidx = a;
+        k = g - G.seg_first[a];
+        if (lo != nullptr && (lo[sidx] < 0 || (int64_t) k < lo[sidx])) active = false;
+    }
+
+    Walk w;
+    w.T = &T;
+    w.data = nullptr;
+    w.n = 0;
+    w.st = 0;
+    w.has_ev = false;
+    w.ev_kind = 0;
+    w.ev_state = w.ev_sym = 0;
+    w.ev_pos = w.ev_sp = -1;
+    w.cur_sp = -1;
+    w.lm_valid = false;
+    w.lm_state = w.lm_sym = 0;
+    w.lm_pos = w.lm_sp = -1;
+    w.count = 0;
+    w.term_pos = -1;
+    w.finished = w.error = w.unresolved = false;
+
+    int64_t  seg_a = 0, seg_b = 0;
+    uint32_t s_in = 0;
+    bool     last_seg = false;
+    if (active) {
+        w.data = G.streams[sidx];
+        w.n = (int64_t) G.lens[sidx];
+        seg_a = (int64_t) k * G.seg_bytes;
+        seg_b = seg_a + G.seg_bytes;
+        const uint64_t nseg = G.seg_first[sidx + 1] - G.seg_first[sidx];
+        last_seg = (k + 1 == nseg);
+        if (seg_b > w.n) seg_b = w.n;
+
+        if (k == 0) {
+            w.st = T.init[0];
+            w.cur_sp = 0;
+        } else if (lo != nullptr && (int64_t) k == lo[sidx]) {
+            /* exact carry from the verified predecessor */
+            const sre_seg_summary_t &c = sum[g - 1];
+            w.st = c.s_out;
+            w.cur_sp = c.cur_sp;
+            if (c.flags & SRE_SUM_PENDING) {
+                w.has_ev = true;
+                w.ev_state = c.pe_state;
+                w.ev_sym = c.pe_sym;
+                w.ev_pos = c.pe_pos;
+                w.ev_sp = c.pe_sp;
+                w.ev_kind = T.trans[(size_t) c.pe_state * (T.ncls + 1) + c.pe_sym].kind;
+            }
+        } else {
+            /* speculative: warm up over the bytes in front of the segment.  In
+             * a fix-up round the warm-up starts from the state the verified
+             * prefix ended in (it tends to recur), otherwise from the initial
+             * state. */
+            uint32_t seed = T.init[0];
+            if (lo != nullptr && lo[sidx] > 0) {
+                const uint32_t cs = sum[G.seg_first[sidx] + lo[sidx] - 1].s_out;
+                /* COUNT cannot resolve a pending match it has not seen */
+                if (cs != 0 && !(MODE == SRE_HIP_PIKE_COUNT && (T.state_flags[cs] & 1))) seed = cs;
+            }
+            int64_t from = seg_a - SRE_SCAN_WARMUP;
+            if (from <= 0) {
+                from = 0;
+                seed = T.init[0];
+                w.cur_sp = 0;
+            }
+            w.st = seed;
+            slow_run<MODE>(w, from, seg_a, true, seed);
+        }
+        s_in = w.st;
+        if (w.st == 0) w.finished = true;   /* carried in dead: the scan ended before us */
+        row_ptr[tid] = w.data + seg_a;
+        row_len[tid] = seg_b - seg_a;
+    } else {
+        row_ptr[tid] = nullptr;
+        row_len[tid] = 0;
+    }
+
+    /* pure-fast COUNT bookkeeping: the last 16-byte group that completed matches
+     * without leaving the fast loop, while it still holds the segment's last
+     * completed match */
+    int64_t  fc_gpos = -1, fc_sp0 = -1;
+    uint32_t fc_s0 = 0;
+    bool     fc_pending = false;
+
+    const uint32_t nrounds = G.seg_bytes / SRE_SCAN_TILE;
+    for (uint32_t r = 0; r < nrounds; r++) {
+        __syncthreads();
+        /* ---- stage 256 rows x 64 bytes ---- */
+#pragma unroll
+        for (uint32_t i = 0; i < SRE_SCAN_TILE / 16; i++) {
+            const uint32_t piece = i * SRE_SCAN_BLOCK + tid;
+            const uint32_t row = piece / (SRE_SCAN_TILE / 16), col = piece % (SRE_SCAN_TILE / 16);
+            const int64_t  off = (int64_t) r * SRE_SCAN_TILE + col * 16;
+            uint4          v = make_uint4(0, 0, 0, 0);
+            if (row_len[row] - off >= 16) {
+                const uint8_t *src = row_ptr[row] + off;
+                if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+                    v = *reinterpret_cast<const uint4 *>(src);
+                } else {
+                    uint32_t x[4];
+                    for (int q = 0; q < 4; q++) {
+                        x[q] = (uint32_t) src[4 * q] | ((uint32_t) src[4 * q + 1] << 8)
+                               | ((uint32_t) src[4 * q + 2] << 16) | ((uint32_t) src[4 * q + 3] << 24);
+                    }
+                    v = make_uint4(x[0], x[1], x[2], x[3]);
+                }
+            }
+            *reinterpret_cast<uint4 *>(tile + row * ROW_BYTES + col * 16) = v;
+        }
+        __syncthreads();
+
+        if (!active || w.finished) continue;
+        const int64_t base = seg_a + (int64_t) r * SRE_SCAN_TILE;
+        if (base >= seg_b) continue;
+
+#pragma unroll
+        for (uint32_t q = 0; q < SRE_SCAN_TILE / 16; q++) {
+            const int64_t gp = base + q * 16;
+            if (gp >= seg_b || w.finished) break;
+            if (gp + 16 > seg_b) {
+                /* ragged tail of the stream: exact path */
+                const int64_t before = w.count;
+                slow_run<MODE>(w, gp, seg_b, false, 0);
+                if (w.count != before) fc_pending = false;
+                break;
+            }
+            const uint4    v = *reinterpret_cast<const uint4 *>(tile + tid * ROW_BYTES + q * 16);
+            const uint32_t words[4] = {v.x, v.y, v.z, v.w};
+            uint32_t       so = w.st * SRE_FAST_ROW_BYTES, acc = 0, cnt = 0, lastb = 0;
+#pragma unroll
+            for (int b = 0; b < 16; b++) {
+                const uint32_t c = (words[b >> 2] >> ((b & 3) * 8)) & 0xffu;
+                const uint32_t t = fast[(so >> 2) + c];
+                acc |= t;
+                if (MODE == SRE_HIP_PIKE_COUNT) {
+                    cnt += (t >> 1) & 1u;
+                    lastb = (t & SRE_FAST_COUNT) ? (uint32_t) b : lastb;
+                }
+                so = t & ~(SRE_FAST_ROW_BYTES - 1);
+            }
+            if (acc & SRE_FAST_SLOW) {
+                const int64_t before = w.count;
+                slow_run<MODE>(w, gp, gp + 16, false, 0);
+                if (w.count != before) fc_pending = false;
+            } else {
+                if (MODE == SRE_HIP_PIKE_COUNT && cnt) {
+                    /* matches completed inside this group, each followed by a
+                     * restart at the next byte: remember the group, its last
+                     * completing transition is recovered at the end */
+                    fc_gpos = gp;
+                    fc_s0 = w.st;
+                    fc_sp0 = w.cur_sp;
+                    fc_pending = true;
+                    w.count += cnt;
+                    w.has_ev = false;               /* superseded */
+                    w.cur_sp = gp + lastb + 1;
+                }
+                w.st = so / SRE_FAST_ROW_BYTES;
+            }
+        }
+    }
+
+    if (!active) return;
+
+    /* the lane that owns the end of the stream performs the EOF step(s) */
+    if (last_seg && !w.finished) {
+        const int64_t before = w.count;
+        slow_run<MODE>(w, w.n, w.n + 1, false, 0);
+        if (w.count != before) fc_pending = false;
+    }
+    /* the segment's last completed match sits in a pure-fast group: recover it */
+    if (MODE == SRE_HIP_PIKE_COUNT && fc_pending) {
+        const int64_t sp_now = w.cur_sp;
+        resolve_fast_group(w, fc_gpos, fc_s0, fc_sp0, true);
+        w.cur_sp = sp_now;
+    }
+
+    sre_seg_summary_t out;
+    out.s_in = w.unresolved ? 0xffffffffu : s_in;
+    out.s_out = w.st;
+    out.flags = 0;
+    out.pad = 0;
+    out.count = w.count;
+    out.term_pos = w.term_pos;
+    out.cur_sp = w.cur_sp;
+    if (w.finished && w.term_pos >= 0) out.flags |= SRE_SUM_TERM;
+    if (w.error) out.flags |= SRE_SUM_ERROR;
+    if (w.has_ev) out.flags |= SRE_SUM_PENDING;
+    if (w.lm_valid) out.flags |= SRE_SUM_LASTEV;
+    out.pe_state = w.ev_state;
+    out.pe_sym = w.ev_sym;
+    out.pe_pos = w.ev_pos;
+    out.pe_sp = w.ev_sp;
+    out.lm_state = w.lm_state;
+    out.lm_sym = w.lm_sym;
+    out.lm_pos = w.lm_pos;
+    out.lm_sp = w.lm_sp;
+    sum[g] = out;
+}
+
+/* ===================================================================== verify */
+
+/*
+ * One workgroup per stream: check the chain of assumed entry states, find the
+ * first segment that ended the scan, and reduce the verified prefix to the
+ * stream's outcome.
+ */
+__global__ __launch_bounds__(256) void
+sre_k_verify(sre_scan_tables_t T, sre_scan_geom_t G, const sre_seg_summary_t *__restrict__ sum,
+             sre_stream_status_t *__restrict__ status)
+{
+    __shared__ unsigned long long sh_bad, sh_end, sh_evseg, sh_spseg, sh_count;
+    const uint32_t s = blockIdx.x;
+    const uint64_t first = G.seg_first[s], nseg = G.seg_first[s + 1] - first;
+    const bool     count_mode = (T.mode == SRE_HIP_PIKE_COUNT);
+
+    if (threadIdx.x == 0) {
+        sh_bad = nseg;
+        sh_end = nseg;
+        sh_evseg = 0;
+        sh_spseg = 0;
+        sh_count = 0;
+    }
+    __syncthreads();
+    for (uint64_t k = threadIdx.x; k < nseg; k += blockDim.x) {
+        const sre_seg_summary_t &c = sum[first + k];
+        if ((k > 0 && c.s_in != sum[first + k - 1].s_out) || c.s_in == 0xffffffffu) {
+            atomicMin(&sh_bad, (unsigned long long) k);
+        }
+        if (c.flags & SRE_SUM_TERM) atomicMin(&sh_end, (unsigned long long) k);
+    }
+    __syncthreads();
+    const uint64_t bad = sh_bad, end = sh_end;
+    const bool     done = (end < bad) || (bad >= nseg);
+    const uint64_t limit = end < bad ? end + 1 : bad;       /* verified AND needed */
+    for (uint64_t k = threadIdx.x; k < limit; k += blockDim.x) {
+        const sre_seg_summary_t &c = sum[first + k];
+        if (c.count) atomicAdd(&sh_count, (unsigned long long) c.count);
+        if (c.flags & SRE_SUM_LASTEV) atomicMax(&sh_evseg, (unsigned long long) k + 1);
+    }
+    __syncthreads();
+    const uint64_t evseg = sh_evseg;        /* 1 + segment of the final match, 0 none */
+    if (done && evseg > 0 && sum[first + evseg - 1].lm_sp < 0) {
+        /* its search began in an earlier segment: latest known start before it */
+        for (uint64_t k = threadIdx.x; k + 1 < evseg; k += blockDim.x) {
+            if (sum[first + k].cur_sp >= 0) atomicMax(&sh_spseg, (unsigned long long) k + 1);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+
+    sre_stream_status_t st;
+    st.first_bad = (int64_t) bad;
+    st.limit = (int64_t) limit;
+    st.done = done ? 1 : 0;
+    st.error = 0;
+    st.count = (int64_t) sh_count;
+    st.rc = RC_DECLINED;
+    st.ev_pos = st.ev_sp = -1;
+    st.ev_state = st.ev_sym = 0;
+    st.ev_seg = -1;
+    if (done && evseg > 0) {
+        const sre_seg_summary_t &c = sum[first + evseg - 1];
+        st.ev_state = c.lm_state;
+        st.ev_sym = c.lm_sym;
+        st.ev_pos = c.lm_pos;
+        st.ev_sp = c.lm_sp;
+        st.ev_seg = (int64_t) evseg - 1;
+        st.rc = T.trans[(size_t) c.lm_state * (T.ncls + 1) + c.lm_sym].regex;
+        if (!count_mode) st.count = 1;
+        if (st.ev_sp < 0) st.ev_sp = sh_spseg ? sum[first + sh_spseg - 1].cur_sp : 0;
+    }
+    if (done && end < nseg && (sum[first + end].flags & SRE_SUM_ERROR)) st.error = 1;
+    status[s] = st;
+}
+
+/* =================================================================== captures */
+
+/*
+ * One lane per stream.  The winning thread's capture vector is rebuilt by
+ * walking its lineage backwards from the match event (sre_dfa.h).  The state
+ * before a position is recomputed on demand, one segment-sized block at a
+ * time, forwards from that segment's verified entry state (2 B of scratch per
+ * byte); then parent links are followed backwards, collecting the SAVE slots
+ * still unresolved.  The walk ends at the ".*?" thread (nothing saved yet), at
+ * a thread re-seeded by the leading-byte skip, at the start of the search, or
+ * when every slot is known.
+ */
+struct Tracer {
+    const sre_scan_tables_t *T;
+    const sre_seg_summary_t *sum;       /* this stream's summaries */
+    const uint8_t           *data;
+    int64_t                  n, sp;
+    uint32_t                 seg_bytes, init_state;
+    uint16_t                *trace;
+    int64_t                  blk_lo, blk_hi;
+
+    /* state before position q (sp <= q <= n) */
+    __device__ uint32_t state_before(int64_t q)
+    {
+        if (q == sp) return init_state;
+        if (q < blk_lo || q > blk_hi) {
+            const int64_t kq = (q - 1) / seg_bytes;
+            int64_t       lo = kq * (int64_t) seg_bytes, hi = lo + seg_bytes;
+            uint32_t      cur;
+            if (hi > n) hi = n;
+            if (sp >= lo) {
+                lo = sp;
+                cur = init_state;
+            } else {
+                cur = sum[kq].s_in;
+            }
+            const uint32_t nsym = T->ncls + 1;
+            for (int64_t x = lo; x < hi; x++) {
+                trace[x - lo] = (uint16_t) cur;
+                cur = T->trans[(size_t) cur * nsym + T->cls[data[x]]].next;
+            }
+            trace[hi - lo] = (uint16_t) cur;
+            blk_lo = lo;
+            blk_hi = hi;
+        }
+        return trace[q - blk_lo];
+    }
+};
+
+__global__ void
+sre_k_captures(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
+               const sre_seg_summary_t *__restrict__ sum,
+               const sre_stream_status_t *__restrict__ status, uint16_t *__restrict__ scratch,
+               int64_t *__restrict__ records, uint32_t ovec_slots)
+{
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= G.nstreams) return;
+    const sre_scan_tables_t   &T = *tabp;
+    const sre_stream_status_t &st = status[s];
+    int64_t                   *rec = records + (size_t) s * (2 + ovec_slots);
+    const uint32_t             nsym = T.ncls + 1;
+
+    rec[0] = st.rc;
+    rec[1] = st.count;
+    for (uint32_t q = 0; q < ovec_slots; q++) rec[2 + q] = -1;
+    if (!st.done) {
+        rec[0] = RC_ERROR;
+        return;
+    }
+    if (st.error) rec[0] = RC_ERROR;         /* the iteration ended with SRE_ERROR */
+    if (st.ev_pos < 0) return;
+    if (T.mode == 0) {
+        rec[0] = 0;                          /* Thompson: SRE_OK, no captures */
+        return;
+    }
+
+    Tracer tr;
+    tr.T = &T;
+    tr.sum = sum + G.seg_first[s];
+    tr.data = G.streams[s];
+    tr.n = (int64_t) G.lens[s];
+    tr.sp = st.ev_sp;
+    tr.seg_bytes = G.seg_bytes;
+    tr.init_state = T.init[st.ev_sp == 0 ? 0 : 2];
+    tr.trace = scratch + (size_t) s * (G.seg_bytes + 16);
+    tr.blk_lo = 1;
+    tr.blk_hi = 0;
+
+    int64_t  vec[64];
+    uint64_t unresolved = T.nslots >= 64 ? ~0ull : ((1ull << T.nslots) - 1);
+    for (uint32_t q = 0; q < T.nslots; q++) vec[q] = -1;
+
+    const sre_dev_trans_t &te = T.trans[(size_t) st.ev_state * nsym + st.ev_sym];
+    uint32_t               j = te.src;
+    if (te.kind == EV_DONE) {
+        const uint64_t m = te.saves & unresolved;
+        for (uint32_t q = 0; q < T.nslots; q++) {
+            if ((m >> q) & 1) vec[q] = st.ev_pos + 1;
+        }
+        unresolved &= ~m;
+    }
+
+    /* thread j lives in the list at position p */
+    for (int64_t p = st.ev_pos; unresolved; p--) {
+        const uint32_t s_here = (p == st.ev_pos) ? st.ev_state : tr.state_before(p);
+        if (T.list_pcs[T.list_off[s_here] + j] == 1) break;      /* the ".*?" ANY thread */
+        const sre_dev_trans_t *t;
+        int64_t                val;
+        if (p == tr.sp) {
+            t = &T.trans[(size_t) T.nstates * nsym + (tr.sp == 0 ? 0 : 2)];   /* initial closure */
+            val = tr.sp;
+        } else {
+            t = &T.trans[(size_t) tr.state_before(p - 1) * nsym + T.cls[tr.data[p - 1]]];
+            val = p;
+        }
+        const uint64_t m = T.lin_saves[t->lin_off + j] & unresolved;
+        for (uint32_t q = 0; q < T.nslots; q++) {
+            if ((m >> q) & 1) vec[q] = val;
+        }
+        unresolved &= ~m;
+        if (p == tr.sp) break;
+        j = T.lin_parent[t->lin_off + j];
+        if (j == 0xffu) break;              /* re-seeded by the leading-byte skip */
+    }
+
+    /* slice the winning regex's groups (sre_vm_pike.c:945-989) */
+    uint64_t ofs = 0;
+    for (int64_t i = 0; i < st.rc; i++) ofs += T.multi_ncaps[i] + 1;
+    ofs *= 2;
+    const uint64_t ncopy = 2ull * (T.multi_ncaps[st.rc] + 1);
+    for (uint64_t q = 0; q < ovec_slots; q++) rec[2 + q] = q < ncopy ? vec[ofs + q] : -1;
+    rec[0] = st.error ? RC_ERROR : st.rc;
+}
+
+}  // namespace
+
+extern "C" hipError_t
+sre_launch_scan(const sre_scan_tables_t *d_tab, sre_scan_tables_t h_tab, sre_scan_geom_t geom,
+                sre_seg_summary_t *d_sum, const int64_t *d_lo, hipStream_t stream)
+{
+    if (geom.nsegs == 0) return hipSuccess;
+    const uint32_t grid = (uint32_t) ((geom.nsegs + SRE_SCAN_BLOCK - 1) / SRE_SCAN_BLOCK);
+    const size_t   shmem = (size_t) h_tab.fast_bytes + (size_t) SRE_SCAN_BLOCK * (SRE_SCAN_TILE + 16);
+    if (h_tab.mode == SRE_HIP_PIKE_COUNT) {
+        hipLaunchKernelGGL(sre_k_scan<SRE_HIP_PIKE_COUNT>, dim3(grid), dim3(SRE_SCAN_BLOCK), shmem,
+                           stream, d_tab, geom, d_sum, d_lo);
+    } else {
+        hipLaunchKernelGGL(sre_k_scan<1>, dim3(grid), dim3(SRE_SCAN_BLOCK), shmem, stream, d_tab,
+                           geom, d_sum, d_lo);
+    }
+    return hipGetLastError();
+}
+
+extern "C" hipError_t
+sre_launch_verify(sre_scan_tables_t h_tab, sre_scan_geom_t geom, const sre_seg_summary_t *d_sum,
+                  sre_stream_status_t *d_status, hipStream_t stream)
+{
+    if (geom.nstreams == 0) return hipSuccess;
+    hipLaunchKernelGGL(sre_k_verify, dim3(geom.nstreams), dim3(256), 0, stream, h_tab, geom, d_sum,
+                       d_status);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t
+sre_launch_captures(const sre_scan_tables_t *d_tab, sre_scan_tables_t h_tab, sre_scan_geom_t geom,
+                    const sre_seg_summary_t *d_sum, const sre_stream_status_t *d_status,
+                    uint16_t *d_scratch, int64_t *d_records, uint32_t ovec_slots,
+                    hipStream_t stream)
+{
+    (void) h_tab;
+    if (geom.nstreams == 0) return hipSuccess;
+    const uint32_t block = 64, grid = (geom.nstreams + block - 1) / block;
+    hipLaunchKernelGGL(sre_k_captures, dim3(grid), dim3(block), 0, stream, d_tab, geom, d_sum,
+                       d_status, d_scratch, d_records, ovec_slots);
     return hipGetLastError();
 }

@@ -1,0 +1,139 @@
+/*
+ * sre_scan_host.cpp — device tables of the table-driven scanner: the step
+ * automaton (sre_dfa.cpp) flattened for one scan mode and uploaded once per
+ * scanner.
+ */
+#include "sre_scan_host.h"
+#include "sre_hip_runtime.h"
+#include <sregex_hip.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+template <typename T>
+static hipError_t
+upload(const std::vector<T> &v, const T **out, std::vector<void *> &owned)
+{
+    void      *d = NULL;
+    size_t     bytes = (v.size() ? v.size() : 1) * sizeof(T);
+    hipError_t e = hipMalloc(&d, bytes);
+    if (e != hipSuccess) return e;
+    owned.push_back(d);
+    if (v.size()) {
+        e = hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice);
+        if (e != hipSuccess) return e;
+    }
+    *out = static_cast<const T *>(d);
+    return hipSuccess;
+}
+
+void
+sre_scan_tables_release(sre_scan_device_tables_t *t)
+{
+    if (t == NULL) return;
+    for (void *p : t->owned) (void) hipFree(p);
+    if (t->d_tab) (void) hipFree(t->d_tab);
+    delete t;
+}
+
+sre_scan_device_tables_t *
+sre_scan_tables_build(const sre_program_t *prog, const sre_dfa_t *d, int mode, const char **why)
+{
+    static const char *dummy;
+    if (why == NULL) why = &dummy;
+    *why = NULL;
+    if (d->nstates > SRE_SCAN_MAX_STATES) {
+        *why = "automaton has more states than the LDS fast table holds";
+        return NULL;
+    }
+    if (d->max_threads > 254) {
+        *why = "thread lists longer than 254";
+        return NULL;
+    }
+    if (mode == SRE_HIP_PIKE_COUNT && d->has_caret) {
+        *why = "COUNT with ^ or \\A needs the per-context newline flag";
+        return NULL;
+    }
+
+    const uint32_t nsym = d->ncls + 1;
+    sre_scan_device_tables_t *t = new sre_scan_device_tables_t();
+    sre_scan_tables_t        &h = t->h;
+    memset(&h, 0, sizeof(h));
+    h.nstates = d->nstates;
+    h.ncls = d->ncls;
+    h.nslots = d->nslots;
+    h.max_threads = d->max_threads;
+    for (int v = 0; v < SRE_DFA_NINIT; v++) h.init[v] = d->init[v];
+    h.mode = mode;
+    h.fast_bytes = d->nstates * SRE_FAST_ROW_BYTES;
+    h.nregexes = prog->nregexes;
+
+    /* fast table */
+    std::vector<uint32_t> fast((size_t) d->nstates * 256);
+    for (uint32_t s = 0; s < d->nstates; s++) {
+        for (unsigned c = 0; c < 256; c++) {
+            uint32_t next, flags = 0;
+            if (s == SRE_DFA_DEAD) {
+                next = SRE_DFA_DEAD;
+                flags = SRE_FAST_SLOW;
+            } else {
+                const sre_dfa_trans_t &tr = d->t(s, d->cls_map[c]);
+                next = tr.next;
+                if (mode == SRE_HIP_PIKE_COUNT && tr.ev_kind == SRE_DFA_EV_DONE
+                    && tr.next == SRE_DFA_DEAD)
+                {
+                    /* a non-empty match completes and nothing outlives it: the
+                     * next search starts at the next byte (sre_vm_pike.c:624-628) */
+                    next = d->init[SRE_DFA_INIT_RESTART];
+                    flags = SRE_FAST_COUNT;
+                } else if (tr.ev_kind != SRE_DFA_EV_NONE || tr.next == SRE_DFA_DEAD) {
+                    flags = SRE_FAST_SLOW;
+                }
+            }
+            fast[(size_t) s * 256 + c] = next * SRE_FAST_ROW_BYTES | flags;
+        }
+    }
+
+    std::vector<sre_dev_trans_t> trans(d->trans.size());
+    for (size_t i = 0; i < d->trans.size(); i++) {
+        const sre_dfa_trans_t &a = d->trans[i];
+        sre_dev_trans_t       &b = trans[i];
+        memset(&b, 0, sizeof(b));
+        b.next = a.next;
+        b.kind = a.ev_kind;
+        b.src = a.ev_src;
+        b.regex = a.ev_regex;
+        b.lin_off = a.lin_off;
+        b.lin_n = a.lin_n;
+        b.skipped = a.skipped;
+        b.saves = a.ev_saves;
+    }
+    std::vector<uint8_t> cls(d->cls_map, d->cls_map + 256);
+    std::vector<uint8_t> flags(d->nstates);
+    for (uint32_t s = 0; s < d->nstates; s++) {
+        flags[s] = (uint8_t) ((d->matched[s] ? 1 : 0) | (d->seen_start[s] << 1));
+    }
+    std::vector<uint32_t> ncaps(prog->multi_ncaps, prog->multi_ncaps + prog->nregexes);
+    (void) nsym;
+
+    hipError_t e;
+    if ((e = upload(fast, &h.fast, t->owned)) != hipSuccess
+        || (e = upload(cls, &h.cls, t->owned)) != hipSuccess
+        || (e = upload(trans, &h.trans, t->owned)) != hipSuccess
+        || (e = upload(d->lin_parent, &h.lin_parent, t->owned)) != hipSuccess
+        || (e = upload(d->lin_saves, &h.lin_saves, t->owned)) != hipSuccess
+        || (e = upload(flags, &h.state_flags, t->owned)) != hipSuccess
+        || (e = upload(d->list_off, &h.list_off, t->owned)) != hipSuccess
+        || (e = upload(d->list_pcs, &h.list_pcs, t->owned)) != hipSuccess
+        || (e = upload(ncaps, &h.multi_ncaps, t->owned)) != hipSuccess
+        || (e = hipMalloc(reinterpret_cast<void **>(&t->d_tab), sizeof(h))) != hipSuccess
+        || (e = hipMemcpy(t->d_tab, &h, sizeof(h), hipMemcpyHostToDevice)) != hipSuccess)
+    {
+        sre_hip_fail("scanner table upload", e);
+        sre_scan_tables_release(t);
+        *why = "device allocation failed";
+        return NULL;
+    }
+    return t;
+}

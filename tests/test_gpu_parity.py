@@ -52,6 +52,20 @@ def test_findall_iteration_on_one_context(gpu):
             eng.recycle()
 
 
+def _expect(ora, prog, ncaps, data):
+    """(first-match record, count record) the batched API must return."""
+    nov = 2 * (ncaps + 1)
+    allm = harness.findall(ora, prog, ncaps, data)
+    final = allm[-1][0]
+    matches = allm[:-1]
+    first = [matches[0][0], 1] + matches[0][1:] if matches else [S.SRE_DECLINED, 0] + [-1] * nov
+    if matches:
+        cnt = [S.SRE_ERROR if final == S.SRE_ERROR else matches[-1][0], len(matches)] + matches[-1][1:]
+    else:
+        cnt = [final, 0] + [-1] * nov
+    return first, cnt
+
+
 @pytest.mark.parametrize("engine", [S.ENGINE_VM, S.ENGINE_AUTO])
 def test_batched_scan_gen_data_goldens(gpu, engine):
     """Device-resident batched API on gen-data streams vs reference results."""
@@ -92,16 +106,11 @@ def test_batched_count_vs_oracle(gpu, engine):
         with S.Pool() as pool:
             re = S.parse(pool, pats)
             prog = S.compile(pool, re)
-            nov = 2 * (re.ncaps + 1)
-            n, spans = ora.count(prog, data, nov, 1 << 16)
+            first, cnt = _expect(ora, prog, re.ncaps, data)
             buf = S.DeviceBuffer.from_bytes(data)
             rec = S.Scanner(pool, prog, S.HIP_PIKE_COUNT, engine).scan([buf.ptr], [len(data)])[0]
             buf.free()
-            assert rec[1] == n, (pats, rec, n)
-            if n:
-                assert rec[0] == spans[-1][0] and rec[2:] == spans[-1][1:], (pats, rec, spans[-1])
-            else:
-                assert rec[0] == S.SRE_DECLINED
+            assert rec == cnt, (pats, rec, cnt)
 
 
 def test_many_ragged_streams_one_call(gpu):
@@ -134,3 +143,100 @@ def test_gen_data_kernel_matches_host_generator(gpu):
         assert gpu.sre_hip_gen_data(buf.ptr, n, tail, len(tail), None) == 0
         assert buf.to_bytes(n) == S.gen_data_host(n, tail)
         buf.free()
+
+
+# ------------------------------------------------------------ table-driven scanner
+
+def test_scanner_all_admitted_reference_blocks(gpu, blocks):
+    """Every assertion-free block of the reference suite through the scanner
+    engine (device-resident, batched API): first match + captures, and
+    Thompson's yes/no, against the reference CLI's lines."""
+    bad, n = [], 0
+    for blk in blocks:
+        subject = bytes.fromhex(blk["s"])
+        _, regexes, flags, multi, ref = harness.block_variants(blk)[0]
+        if ref["rc"] != 0:
+            continue
+        with S.Pool() as pool:
+            prog = S.compile(pool, S.parse(pool, regexes, flags, multi))
+            try:
+                sc = S.Scanner(pool, prog, S.HIP_PIKE_FIRST, S.ENGINE_AUTO)
+            except RuntimeError:
+                continue
+            if sc.engine != S.ENGINE_SCAN:
+                continue
+            buf = S.DeviceBuffer.from_bytes(subject)
+            rec = sc.scan([buf.ptr], [len(subject)])[0]
+            th = S.Scanner(pool, prog, S.HIP_THOMPSON, S.ENGINE_SCAN).scan([buf.ptr], [len(subject)])[0]
+            buf.free()
+            nov = 2 * (ref["ncaps"] + 1)
+            line = ("pike match %d%s" % (rec[0], harness._fmt_caps(rec[2:], nov)) if rec[0] >= 0
+                    else "pike no match")
+            tl = "thompson " + ("match" if th[0] == 0 else "no match")
+            n += 1
+            if line != ref["res"][4] or tl != ref["res"][0]:
+                bad.append((blk["file"], blk["name"], line, ref["res"][4], tl, ref["res"][0]))
+    assert n > 1300, n
+    assert not bad, (len(bad), bad[:5])
+
+
+@pytest.mark.parametrize("seg", [64, 192, 4096])
+def test_scanner_segments_vs_oracle(gpu, seg):
+    """Small segments force many lanes per stream: speculative entry states,
+    chain verification, fix-up rounds, cross-segment lineage walks."""
+    import random
+    ora = harness.OracleEngine()
+    rng = random.Random(1234 + seg)
+    zoo = [
+        [rb"[a-z]+@[a-z]+\.[a-z]+"], [rb"([a-z]+)://([^/ ]+)(/[^ ?]*)?(\?[^ ]*)?"],
+        [rb"a?a?a?aaa"], [rb"(a+)(b+)?"], [rb"(?:a.*b|a)"], [rb"x*"], [rb"(a|ab)(c|bcd)(d*)"],
+        [b"a", b"ab", b"c", b"a(bc)", b"e(f)", b"gh", b"A", b"b", b"BLAH", rb"\s+", b"abcd", b"bc"],
+        [rb"(a*)*b"], [rb"a.c"], [rb"\Aab|\n^b"], [rb"(x+x+)+y"], [rb"[ab]c?"], [rb"(a|b)*?c"],
+    ]
+    alphabets = [b"abc", b"ab c\n.x@:/?y", b"aaaaab"]
+    for pats in zoo:
+        with S.Pool() as pool:
+            re = S.parse(pool, pats)
+            prog = S.compile(pool, re)
+            scs = {}
+            for mode in (S.HIP_THOMPSON, S.HIP_PIKE_FIRST, S.HIP_PIKE_COUNT):
+                try:
+                    sc = S.Scanner(pool, prog, mode, S.ENGINE_SCAN)
+                except RuntimeError:
+                    continue
+                sc.set_segment_bytes(seg)
+                scs[mode] = sc
+            assert S.HIP_PIKE_FIRST in scs, pats
+            datas = []
+            for i in range(12):
+                alpha = alphabets[i % len(alphabets)]
+                n = rng.choice([0, 1, 63, 64, 65, 200, 1000, 3000])
+                datas.append(bytes(rng.choice(alpha) for _ in range(n)))
+            datas.append(S.gen_data_host(2000, b"@abc.cc "))
+            datas.append(S.gen_data_host(1500, b" abc://abc.cc/ab/c?a=b "))
+            bufs = [S.DeviceBuffer.from_bytes(d) for d in datas]
+            ptrs, lens = [b.ptr for b in bufs], [len(d) for d in datas]
+            got = {m: sc.scan(ptrs, lens) for m, sc in scs.items()}
+            for i, d in enumerate(datas):
+                first, cnt = _expect(ora, prog, re.ncaps, d)
+                assert got[S.HIP_PIKE_FIRST][i] == first, (pats, seg, d[:80], len(d))
+                assert got[S.HIP_THOMPSON][i][0] == (0 if first[0] >= 0 else S.SRE_DECLINED), (pats, d[:80])
+                if S.HIP_PIKE_COUNT in got:
+                    assert got[S.HIP_PIKE_COUNT][i] == cnt, (pats, seg, d[:80], len(d))
+            for b in bufs:
+                b.free()
+
+
+def test_scanner_fixup_rounds_are_reported(gpu):
+    """A match early in a long stream leaves later segments assumed 'idle' while
+    the truth is 'search over': the chain check must catch it."""
+    with S.Pool() as pool:
+        prog = S.compile(pool, S.parse(pool, [rb"(?:a.*b|a)"]))
+        sc = S.Scanner(pool, prog, S.HIP_PIKE_FIRST, S.ENGINE_SCAN)
+        sc.set_segment_bytes(64)
+        data = b"xx a" + b"c" * 500 + b"b" + b"c" * 300
+        buf = S.DeviceBuffer.from_bytes(data)
+        rec = sc.scan([buf.ptr], [len(data)])[0]
+        buf.free()
+        assert rec == [0, 1, 3, 505]
+        assert sc.last_fixups >= 1
