@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""bench.py — GB/s of input scanned per GPU on gen-data.pl-style streams.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json):
+  N == 1  configs[1]: ONE 4 GiB stream  "abccc" x k . "aaabbccb"  (bench/gen-data.pl:9
+          scaled), pattern /[a-z]+@[a-z]+\\.[a-z]+/, Pike semantics (first match +
+          captures), input resident in HBM (generated on device).
+  N  > 1  configs[4] shape: 64*N independent 64 MiB streams of the same pattern,
+          stream i on rank i mod N (64 streams = 4 GiB per GPU, weak scaling),
+          tails alternate matching / non-matching; the only collective is one
+          RCCL all-reduce of the per-rank match counts.
+A step = one complete scan of the rank's resident input through the public
+batched C ABI (sre_hip_scan_enqueue + sre_hip_scan_results), results included.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import ctypes
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PATTERN = rb"[a-z]+@[a-z]+\.[a-z]+"
+GIB = 1 << 30
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(sample_bytes=32 << 20):
+    """The reference's own Pike path on the host cores of this box, one core
+    (the reference is single-threaded; bench/sregex.c times one exec with
+    CLOCK_PROCESS_CPUTIME_ID), on a bounded prefix of the same workload."""
+    import sregex_amd as S
+    data = S.gen_data_host(sample_bytes, b"aaabbccb")
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "sregex-bench")
+    out = {"unit": "GB/s", "cores": 1}
+    if os.path.exists(ref_bin):
+        path = "/tmp/sre_bench_sample.txt"
+        with open(path, "wb") as f:
+            f.write(data)
+        try:
+            txt = subprocess.run([ref_bin, "--pike", PATTERN.decode(), path], capture_output=True,
+                                 text=True, timeout=600).stdout
+            ms = float(txt.split(":")[-1].split("ms")[0].strip().split()[-1])
+            out.update(kind="reference", value=len(data) / ms / 1e6,
+                       sample="%d MiB prefix of the workload, reference bench/sregex.c --pike "
+                              "(oracle/_ref/sregex-bench), 1 core" % (sample_bytes >> 20))
+            txt = subprocess.run([ref_bin, "--thompson", PATTERN.decode(), path], capture_output=True,
+                                 text=True, timeout=600).stdout
+            ms = float(txt.split(":")[-1].split("ms")[0].strip().split()[-1])
+            out["thompson_value"] = len(data) / ms / 1e6
+        except Exception as e:          # noqa: BLE001 - report, do not hide
+            out["reference_error"] = repr(e)
+        finally:
+            os.unlink(path)
+    # the leak-free CPU restatement (oracle/), same sample, for comparison
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import harness
+        with S.Pool() as pool:
+            prog = S.compile(pool, S.parse(pool, [PATTERN]))
+            p = harness.OracleEngine().pike(prog, 0)
+            buf = ctypes.create_string_buffer(data, len(data))
+            t0 = time.process_time()
+            rc = p.exec(None, True, want_pending=False, base=buf, offset=0, length=len(data))
+            dt = time.process_time() - t0
+            p.close()
+        port = len(data) / dt / 1e9
+        if "value" not in out:
+            out.update(kind="port", value=port,
+                       sample="%d MiB prefix of the workload, oracle/ Pike restatement, 1 core"
+                              % (sample_bytes >> 20))
+        else:
+            out["port_value"] = port
+        out["sample_rc"] = rc
+    except Exception as e:              # noqa: BLE001
+        out["port_error"] = repr(e)
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--bytes", type=int, default=4 * GIB, help="bytes per GPU (default 4 GiB)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import sregex_amd as S
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl")          # RCCL
+    lib = S.load_library()
+    assert lib.sre_hip_set_device(local_rank) == 0
+    stream = torch.cuda.current_stream()
+    hstream = ctypes.c_void_p(stream.cuda_stream)
+
+    # ---- resident input -------------------------------------------------
+    if world == 1:
+        tail = b"aaabbccb"
+        n = S.gen_data_length(args.bytes, len(tail))
+        lens = [n]
+        tails = [tail]
+        workload = ("configs[1]: 1 stream x %.2f GiB gen-data (abccc.. + 'aaabbccb'), "
+                    "/[a-z]+@[a-z]+\\.[a-z]+/ Pike first-match + captures" % (n / GIB))
+    else:
+        per = 64 << 20
+        nstreams = max(1, args.bytes // per)
+        # global stream g = j * world + rank: even g carries a matching tail
+        tails = [(b"@abc.cc " if ((j * world + rank) % 2 == 0) else b"aaabbccb") for j in range(nstreams)]
+        lens = [S.gen_data_length(per, len(t)) for t in tails]
+        workload = ("configs[4] shape: %d streams x 64 MiB per GPU (round-robin over %d GPUs), "
+                    "/[a-z]+@[a-z]+\\.[a-z]+/ Pike, RCCL all-reduce of match counts" % (nstreams, world))
+    bufs = [torch.empty(max(n, 16), dtype=torch.uint8, device="cuda") for n in lens]
+    for b, n, t in zip(bufs, lens, tails):
+        assert lib.sre_hip_gen_data(b.data_ptr(), n, t, len(t), hstream) == 0
+    ptrs = [b.data_ptr() for b in bufs]
+    total = sum(lens)
+
+    pool = S.Pool()
+    prog = S.compile(pool, S.parse(pool, [PATTERN]))
+    sc = S.Scanner(pool, prog, S.HIP_PIKE_FIRST, S.ENGINE_SCAN)
+
+    def step():
+        recs = sc.scan(ptrs, lens, hstream)
+        return recs
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        recs = step()
+    # correctness of what is being timed (size-independent property): a stream
+    # matches iff its tail holds the '@' form, and then spans the whole stream
+    for n, t, r in zip(lens, tails, recs):
+        if t.startswith(b"@"):
+            assert r[:4] == [0, 1, 0, n - 1], (r, n)
+        else:
+            assert r[0] == S.SRE_DECLINED and r[1] == 0, r
+
+    kernel_ms = []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        recs = step()
+        kernel_ms.append(sc.last_kernel_ms)
+    barrier()
+    dt = time.perf_counter() - t0
+
+    matches = sum(1 for r in recs if r[0] >= 0)
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+        cnt = torch.tensor([matches, total], dtype=torch.int64, device="cuda")
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)      # the path's only exchange step
+        matches, total_all = int(cnt[0].item()), int(cnt[1].item())
+    else:
+        total_all = total
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        value = total_all * args.steps / dt / 1e9
+        kms = sum(kernel_ms) / len(kernel_ms)
+        achieved = total / (kms * 1e-3) / 1e9           # this rank's kernel: 1 B per input byte
+        line = {
+            "metric": "GB/s input scanned (whole job), gen-data stream resident in HBM",
+            "value": value, "unit": "GB/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": workload, "bytes_per_gpu": total, "streams_per_gpu": len(lens),
+                       "segment_bytes": sc.last_segment_bytes, "fixup_rounds": sc.last_fixups,
+                       "matches": matches, "engine": "scan"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "sre_k_scan<1>", "kernel_ms": kms,
+                         "algorithmic_bytes_per_launch": total},
+        }
+        if world == 1:
+            # measured streaming-read ceiling of this box, same buffer
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            lib.sre_hip_read_ceiling(ptrs[0], lens[0], hstream)
+            ev0.record(stream)
+            for _ in range(5):
+                lib.sre_hip_read_ceiling(ptrs[0], lens[0], hstream)
+            ev1.record(stream)
+            torch.cuda.synchronize()
+            line["roofline"]["measured_read_ceiling"] = lens[0] * 5 / (ev0.elapsed_time(ev1) * 1e-3) / 1e9
+            if not args.no_cpu_baseline:
+                line["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+    pool.destroy()
+
+
+if __name__ == "__main__":
+    main()

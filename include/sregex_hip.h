@@ -70,6 +70,14 @@ SRE_API int sre_hip_scanner_set_segment_bytes(sre_hip_scanner_t *sc, size_t byte
  * entry state was right) */
 SRE_API int sre_hip_scanner_last_fixups(sre_hip_scanner_t *sc);
 
+/* measurement: duration (ms) of the segment-scan kernel of the last enqueued
+ * scan, from hipEvents recorded on the caller's stream around that launch;
+ * -1 when the exact VM engine ran.  Waits for the kernel. */
+SRE_API double sre_hip_scanner_last_kernel_ms(sre_hip_scanner_t *sc);
+
+/* segment size the last scan used (0 for the VM engine) */
+SRE_API size_t sre_hip_scanner_last_segment_bytes(sre_hip_scanner_t *sc);
+
 /*
  * Per-stream result record, in sre_int_t units:
  *     [0] rc     regex id (>= 0; SRE_OK for Thompson) of the (last) match, or

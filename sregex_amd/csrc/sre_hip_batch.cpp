@@ -42,10 +42,13 @@ struct sre_hip_scanner_s {
     sre_seg_summary_t        *d_sum;
     size_t                    sum_cap;
     sre_stream_status_t      *d_status, *h_status;
+    void                     *d_acc;
     int64_t                  *d_lo, *h_lo;
     uint16_t                 *d_scratch;
     size_t                    scratch_cap;
     int                       fixup_rounds;     /* of the last scan (diagnostics) */
+    hipEvent_t                ev0, ev1;         /* around the dominant scan kernel */
+    int                       ev_valid;
 };
 
 static void
@@ -63,9 +66,12 @@ scanner_release(void *data)
     if (sc->d_sum) (void) hipFree(sc->d_sum);
     if (sc->d_status) (void) hipFree(sc->d_status);
     if (sc->h_status) (void) hipHostFree(sc->h_status);
+    if (sc->d_acc) (void) hipFree(sc->d_acc);
     if (sc->d_lo) (void) hipFree(sc->d_lo);
     if (sc->h_lo) (void) hipHostFree(sc->h_lo);
     if (sc->d_scratch) (void) hipFree(sc->d_scratch);
+    if (sc->ev0) (void) hipEventDestroy(sc->ev0);
+    if (sc->ev1) (void) hipEventDestroy(sc->ev1);
     sre_scan_tables_release(sc->tab);
     sre_dfa_free(sc->dfa);
     free(sc);
@@ -143,7 +149,7 @@ sre_hip_scanner_result_slots(sre_hip_scanner_t *sc)
 extern "C" SRE_API int
 sre_hip_scanner_set_segment_bytes(sre_hip_scanner_t *sc, size_t bytes)
 {
-    if (bytes != 0 && (bytes % SRE_SCAN_TILE != 0 || bytes > (1u << 30))) return -1;
+    if (bytes != 0 && (bytes % 64 != 0 || bytes > (1u << 30))) return -1;
     sc->seg_override = (uint32_t) bytes;
     return 0;
 }
@@ -152,6 +158,22 @@ extern "C" SRE_API int
 sre_hip_scanner_last_fixups(sre_hip_scanner_t *sc)
 {
     return sc->fixup_rounds;
+}
+
+extern "C" SRE_API double
+sre_hip_scanner_last_kernel_ms(sre_hip_scanner_t *sc)
+{
+    float ms = 0.0f;
+    if (!sc->ev_valid) return -1.0;
+    if (hipEventSynchronize(sc->ev1) != hipSuccess) return -1.0;
+    if (hipEventElapsedTime(&ms, sc->ev0, sc->ev1) != hipSuccess) return -1.0;
+    return (double) ms;
+}
+
+extern "C" SRE_API size_t
+sre_hip_scanner_last_segment_bytes(sre_hip_scanner_t *sc)
+{
+    return sc->engine == SRE_HIP_ENGINE_SCAN ? sc->geom.seg_bytes : 0;
 }
 
 static int
@@ -167,6 +189,8 @@ scanner_reserve(sre_hip_scanner_t *sc, size_t n)
         if (sc->h_seg_first) (void) hipHostFree(sc->h_seg_first);
         if (sc->d_status) (void) hipFree(sc->d_status);
         if (sc->h_status) (void) hipHostFree(sc->h_status);
+        if (sc->d_acc) (void) hipFree(sc->d_acc);
+        sc->d_acc = NULL;
         if (sc->d_lo) (void) hipFree(sc->d_lo);
         if (sc->h_lo) (void) hipHostFree(sc->h_lo);
         sc->d_ptrs = NULL;
@@ -188,6 +212,7 @@ scanner_reserve(sre_hip_scanner_t *sc, size_t n)
         SRE_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&sc->h_seg_first), (n + 1) * sizeof(uint64_t), 0));
         SRE_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&sc->d_status), n * sizeof(sre_stream_status_t)));
         SRE_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&sc->h_status), n * sizeof(sre_stream_status_t), 0));
+        SRE_HIP_TRY(hipMalloc(&sc->d_acc, sre_scan_verify_acc_bytes((uint32_t) n)));
         SRE_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&sc->d_lo), n * sizeof(int64_t)));
         SRE_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&sc->h_lo), n * sizeof(int64_t), 0));
         sc->cap_streams = n;
@@ -204,18 +229,35 @@ hip_failed:
     return -1;
 }
 
-/* segment geometry: about 256K lanes for the whole batch (256 CUs x 16 waves),
- * segments a multiple of the 64-byte tile and at least 4 KiB so that the
- * 256-byte warm-up stays a few percent */
+/* segment geometry: one lane per segment, 256 lanes per workgroup.  The number
+ * of workgroups is steered towards a whole multiple of what the chip holds at
+ * once (LDS-limited: 160 KiB per CU), so the last round of workgroups is not
+ * mostly empty; segments are a multiple of the 64-byte tile and at least 1 KiB
+ * so that the speculative warm-up stays a few percent. */
 static int
 scan_geometry(sre_hip_scanner_t *sc, size_t nstreams)
 {
     uint64_t total = 0;
     for (size_t i = 0; i < nstreams; i++) total += sc->h_lens[i];
     uint64_t seg = sc->seg_override;
+    uint32_t tile = SRE_SCAN_TILE_DEFAULT;
+    {
+        const char *e = getenv("SRE_HIP_SCAN_TILE");      /* experiment knob: 64 / 128 / 256 */
+        if (e && (atoi(e) == 32 || atoi(e) == 64 || atoi(e) == 128 || atoi(e) == 256)) tile = (uint32_t) atoi(e);
+    }
+    if (seg != 0 && seg % tile != 0) tile = 64;
+    sc->geom.tile = tile;
+    sc->geom.pad = 0;
     if (seg == 0) {
-        seg = (total / 262144 + SRE_SCAN_TILE - 1) / SRE_SCAN_TILE * SRE_SCAN_TILE;
-        if (seg < 4096) seg = 4096;
+        size_t   lds = sre_scan_lds_bytes(&sc->tab->h, tile) + 4352;
+        uint64_t per_cu = (160u * 1024u) / lds;
+        if (per_cu > 8) per_cu = 8;
+        if (per_cu < 1) per_cu = 1;
+        const uint64_t resident = 256 * per_cu * SRE_SCAN_BLOCK;       /* lanes in flight */
+        uint64_t rounds = total / (resident * 4096);                    /* ~4 KiB segments */
+        if (rounds < 1) rounds = 1;
+        seg = (total / (resident * rounds) + SRE_SCAN_SEG_ALIGN - 1) / SRE_SCAN_SEG_ALIGN * SRE_SCAN_SEG_ALIGN;
+        if (seg < 1024) seg = 1024;
     }
     uint64_t nsegs = 0;
     for (size_t i = 0; i < nstreams; i++) {
@@ -259,6 +301,7 @@ sre_hip_scan_enqueue(sre_hip_scanner_t *sc, const void *const *d_streams, const 
 {
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     sc->fixup_rounds = 0;
+    sc->ev_valid = 0;
     if (nstreams == 0) {
         sc->last_n = 0;
         return 0;
@@ -284,8 +327,15 @@ sre_hip_scan_enqueue(sre_hip_scanner_t *sc, const void *const *d_streams, const 
                                    hipMemcpyHostToDevice, stream));
         /* speculative pass, chain check, captures — all queued; results() only
          * has to look at the status words */
+        if (sc->ev0 == NULL) {
+            SRE_HIP_TRY(hipEventCreate(&sc->ev0));
+            SRE_HIP_TRY(hipEventCreate(&sc->ev1));
+        }
+        SRE_HIP_TRY(hipEventRecord(sc->ev0, stream));
         SRE_HIP_TRY(sre_launch_scan(sc->tab->d_tab, sc->tab->h, sc->geom, sc->d_sum, NULL, stream));
-        SRE_HIP_TRY(sre_launch_verify(sc->tab->h, sc->geom, sc->d_sum, sc->d_status, stream));
+        SRE_HIP_TRY(hipEventRecord(sc->ev1, stream));
+        sc->ev_valid = 1;
+        SRE_HIP_TRY(sre_launch_verify(sc->tab->h, sc->geom, sc->d_sum, sc->d_acc, sc->d_status, stream));
         SRE_HIP_TRY(sre_launch_captures(sc->tab->d_tab, sc->tab->h, sc->geom, sc->d_sum, sc->d_status,
                                         sc->d_scratch, sc->d_records, sc->ovec_slots, stream));
     }
@@ -326,7 +376,7 @@ sre_hip_scan_results(sre_hip_scanner_t *sc, sre_int_t *results)
             }
             SRE_HIP_TRY(hipMemcpyAsync(sc->d_lo, sc->h_lo, n * sizeof(int64_t), hipMemcpyHostToDevice, stream));
             SRE_HIP_TRY(sre_launch_scan(sc->tab->d_tab, sc->tab->h, sc->geom, sc->d_sum, sc->d_lo, stream));
-            SRE_HIP_TRY(sre_launch_verify(sc->tab->h, sc->geom, sc->d_sum, sc->d_status, stream));
+            SRE_HIP_TRY(sre_launch_verify(sc->tab->h, sc->geom, sc->d_sum, sc->d_acc, sc->d_status, stream));
             SRE_HIP_TRY(sre_launch_captures(sc->tab->d_tab, sc->tab->h, sc->geom, sc->d_sum,
                                             sc->d_status, sc->d_scratch, sc->d_records,
                                             sc->ovec_slots, stream));

@@ -10,21 +10,29 @@
 
 #define SRE_CEILING_GRID   2048
 
-/* ---- fast table: one 32-bit entry per (state, byte), staged into LDS ----
+/* ---- fast table, staged into LDS: one 32-bit entry per (state, 8-bit index).
+ * The index packs the byte CLASSES of `stride` consecutive input bytes
+ * (class_bits each, stride * class_bits == 8), so one dependent lookup advances
+ * the automaton by 1, 2, 4 or 8 bytes; with more than 16 classes the index is
+ * the byte itself (stride 1).
  *   bits 31..10  byte offset of the next state's row (state * 1024)
- *   bit  0       SLOW: this transition carries a match event or kills the list
- *   bit  1       COUNT mode only: a match completes here and the next search
- *                starts at the next byte (entry already points at its initial
- *                state) — counted in the fast loop */
+ *   bit  0       SLOW: a sub-step carries a match event or kills the list
+ *   bits 1..4    COUNT mode: matches completed inside this step, each followed
+ *                by a restart at the next byte (the entry points at the state
+ *                reached after the last restart)
+ *   bits 5..7    COUNT mode: sub-step index of the last such completion */
 #define SRE_FAST_SLOW       1u
-#define SRE_FAST_COUNT      2u
+#define SRE_FAST_CNT_SHIFT  1u
+#define SRE_FAST_CNT_MASK   0xfu
+#define SRE_FAST_LAST_SHIFT 5u
 #define SRE_FAST_ROW_BYTES  1024u
 
 #define SRE_SCAN_MAX_STATES   64u     /* LDS budget: 64 KiB of fast table */
 #define SRE_SCAN_MAX_THREADS  16u     /* lineage vectors are 16 bytes */
 #define SRE_SCAN_BLOCK        256u    /* lanes = segments per workgroup */
-#define SRE_SCAN_TILE         64u     /* bytes per lane per LDS round */
-#define SRE_SCAN_WARMUP       256u    /* speculative warm-up before a segment */
+#define SRE_SCAN_TILE_DEFAULT 64u     /* bytes per lane per LDS round (measured best of 64/128/256) */
+#define SRE_SCAN_SEG_ALIGN    256u    /* segments are a multiple of every tile size */
+#define SRE_SCAN_WARMUP       64u     /* speculative warm-up before a segment */
 
 /* full transition record (global memory; slow path and lineage kernels) */
 typedef struct {
@@ -44,6 +52,7 @@ typedef struct {
     uint32_t init[4];                   /* SRE_DFA_INIT_* -> state */
     int32_t  mode;                      /* SRE_HIP_* */
     uint32_t fast_bytes;                /* nstates * 1024 */
+    uint32_t stride, class_bits;        /* input bytes per fast-table step */
     const uint32_t        *fast;        /* [nstates][256] */
     const uint8_t         *cls;         /* [256] */
     const sre_dev_trans_t *trans;       /* [nstates][ncls + 1], then 3 pseudo rows for the initial closures */
@@ -53,7 +62,7 @@ typedef struct {
     const uint32_t        *list_off;    /* [nstates + 1] */
     const uint32_t        *list_pcs;
     const uint32_t        *multi_ncaps; /* [nregexes] */
-    uint32_t nregexes, pad;
+    uint32_t nregexes, warmup;          /* speculative warm-up bytes per segment */
 } sre_scan_tables_t;
 
 /* what one lane learnt about its segment */
@@ -98,6 +107,7 @@ typedef struct {
     uint32_t nstreams;
     uint32_t seg_bytes;
     uint64_t nsegs;
+    uint32_t tile, pad;             /* 64 / 128 / 256 bytes per lane per LDS round */
 } sre_scan_geom_t;
 
 #ifdef __cplusplus
@@ -108,12 +118,17 @@ hipError_t sre_launch_gen_data(void *d_dst, uint64_t n, uint64_t tail_len, const
 hipError_t sre_launch_read_ceiling(const void *d_src, uint64_t n, uint32_t *d_sink,
     hipStream_t stream);
 
+/* dynamic LDS one scan workgroup needs (fast table + class map + tile) */
+size_t sre_scan_lds_bytes(const sre_scan_tables_t *h_tab, uint32_t tile);
+
 /* control pass over segments [lo[s], nseg_s) of every stream; lo == NULL: all.
  * carry[s] (with lo) = exact entry of segment lo[s] taken from summaries[lo[s]-1]. */
 hipError_t sre_launch_scan(const sre_scan_tables_t *d_tab, sre_scan_tables_t h_tab,
     sre_scan_geom_t geom, sre_seg_summary_t *d_sum, const int64_t *d_lo, hipStream_t stream);
+size_t sre_scan_verify_acc_bytes(uint32_t nstreams);
 hipError_t sre_launch_verify(sre_scan_tables_t h_tab, sre_scan_geom_t geom,
-    const sre_seg_summary_t *d_sum, sre_stream_status_t *d_status, hipStream_t stream);
+    const sre_seg_summary_t *d_sum, void *d_acc, sre_stream_status_t *d_status,
+    hipStream_t stream);
 /* captures of each stream's final match -> records [rc, count, ovector] */
 hipError_t sre_launch_captures(const sre_scan_tables_t *d_tab, sre_scan_tables_t h_tab,
     sre_scan_geom_t geom, const sre_seg_summary_t *d_sum, const sre_stream_status_t *d_status,

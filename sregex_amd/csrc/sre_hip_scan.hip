@@ -113,7 +113,7 @@ sre_launch_read_ceiling(const void *d_src, uint64_t n, uint32_t *d_sink, hipStre
 
 namespace {
 
-constexpr uint32_t ROW_BYTES = SRE_SCAN_TILE + 16;      /* padded tile row */
+
 
 /* the search a lane is currently following */
 struct Walk {
@@ -271,26 +271,95 @@ __device__ void resolve_fast_group(Walk &w, int64_t gpos, uint32_t s0, int64_t s
     w.cur_sp = sp;
 }
 
-template <int MODE>
+/* stage one round (64 bytes of each of the 256 rows): the four 16-byte pieces
+ * this lane fetches; rows shorter than a whole piece read as zeros (their lanes
+ * finish on the exact path) */
+/* stage one round (TILE bytes of each of the 256 rows): the 16-byte pieces this
+ * lane fetches; pieces outside a row's valid range read as zeros (their lanes
+ * take the exact path there) */
+template <int TILE>
+__device__ inline void
+tile_fetch(uint4 (&regs)[TILE / 16], const uint8_t *const *row_ptr, const int32_t *row_lo,
+           const int32_t *row_hi, uint32_t tid, uint32_t r)
+{
+#pragma unroll
+    for (uint32_t i = 0; i < TILE / 16; i++) {
+        const uint32_t piece = i * SRE_SCAN_BLOCK + tid;
+        const uint32_t row = piece / (TILE / 16), col = piece % (TILE / 16);
+        const int32_t  off = (int32_t) (r * TILE + col * 16);
+        uint4          v = make_uint4(0, 0, 0, 0);
+        if (off >= row_lo[row] && off + 16 <= row_hi[row]) {
+            const uint8_t *src = row_ptr[row] + off;
+            if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+                v = *reinterpret_cast<const uint4 *>(src);
+            } else {
+                uint32_t x[4];
+                for (int q = 0; q < 4; q++) {
+                    x[q] = (uint32_t) src[4 * q] | ((uint32_t) src[4 * q + 1] << 8)
+                           | ((uint32_t) src[4 * q + 2] << 16) | ((uint32_t) src[4 * q + 3] << 24);
+                }
+                v = make_uint4(x[0], x[1], x[2], x[3]);
+            }
+        }
+        regs[i] = v;
+    }
+}
+
+template <int TILE>
+__device__ inline void
+tile_store(const uint4 (&regs)[TILE / 16], uint8_t *tile, uint32_t tid)
+{
+#pragma unroll
+    for (uint32_t i = 0; i < TILE / 16; i++) {
+        const uint32_t piece = i * SRE_SCAN_BLOCK + tid;
+        const uint32_t row = piece / (TILE / 16), col = piece % (TILE / 16);
+        *reinterpret_cast<uint4 *>(tile + row * (TILE + 16) + col * 16) = regs[i];
+    }
+}
+
+/*
+ * BITS = class bits per input byte: one fast-table lookup advances 8 / BITS
+ * bytes (BITS == 8: the index is the byte itself).  TILE = bytes per lane per
+ * LDS round.  Round 0 is the speculative warm-up: the TILE bytes in front of
+ * the segment, walked with the same fast loop, nothing recorded.
+ */
+template <int MODE, int BITS, int TILE>
 __global__ __launch_bounds__(SRE_SCAN_BLOCK) void
 sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
            sre_seg_summary_t *__restrict__ sum, const int64_t *__restrict__ lo)
 {
+    constexpr int      STRIDE = 8 / BITS;
+    constexpr uint32_t ROW_BYTES = TILE + 16;      /* padded tile row: conflict-free b128 reads */
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     __shared__ const uint8_t *row_ptr[SRE_SCAN_BLOCK];
-    __shared__ int64_t        row_len[SRE_SCAN_BLOCK];
+    __shared__ int32_t        row_lo[SRE_SCAN_BLOCK], row_hi[SRE_SCAN_BLOCK];
     __shared__ sre_scan_tables_t Ts;
 
     const uint32_t tid = threadIdx.x;
-    if (tid == 0) Ts = *tabp;
+    /* LDS: [fast table][class map 256][transition records][state flags][tile] */
+    uint32_t *fast = reinterpret_cast<uint32_t *>(lds);
+    uint8_t  *clsl = lds + tabp->fast_bytes;
+    uint8_t  *trl = clsl + 256;
+    const uint32_t tr_bytes = tabp->nstates * (tabp->ncls + 1) * (uint32_t) sizeof(sre_dev_trans_t);
+    uint8_t  *sfl = trl + tr_bytes;
+    uint8_t  *tile = sfl + ((tabp->nstates + 15u) & ~15u);
+    if (tid == 0) {
+        Ts = *tabp;
+        /* the exact path reads its tables from LDS too */
+        Ts.cls = clsl;
+        Ts.trans = reinterpret_cast<const sre_dev_trans_t *>(trl);
+        Ts.state_flags = sfl;
+    }
+    for (uint32_t i = tid; i < tabp->fast_bytes / 16; i += SRE_SCAN_BLOCK) {
+        reinterpret_cast<uint4 *>(fast)[i] = reinterpret_cast<const uint4 *>(tabp->fast)[i];
+    }
+    for (uint32_t i = tid; i < tr_bytes / 8; i += SRE_SCAN_BLOCK) {
+        reinterpret_cast<uint64_t *>(trl)[i] = reinterpret_cast<const uint64_t *>(tabp->trans)[i];
+    }
+    for (uint32_t i = tid; i < tabp->nstates; i += SRE_SCAN_BLOCK) sfl[i] = tabp->state_flags[i];
+    clsl[tid] = tabp->cls[tid];
     __syncthreads();
     const sre_scan_tables_t &T = Ts;
-
-    uint32_t *fast = reinterpret_cast<uint32_t *>(lds);
-    uint8_t  *tile = lds + T.fast_bytes;
-    for (uint32_t i = tid; i < T.fast_bytes / 16; i += SRE_SCAN_BLOCK) {
-        reinterpret_cast<uint4 *>(fast)[i] = reinterpret_cast<const uint4 *>(T.fast)[i];
-    }
 
     /* ---- which segment am I ---- */
     const uint64_t g = (uint64_t) blockIdx.x * SRE_SCAN_BLOCK + tid;
@@ -326,8 +395,11 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
     w.finished = w.error = w.unresolved = false;
 
     int64_t  seg_a = 0, seg_b = 0;
-    uint32_t s_in = 0;
-    bool     last_seg = false;
+    uint32_t s_in = 0, seed = 0;
+    bool     last_seg = false, warm = false;
+    row_ptr[tid] = nullptr;
+    row_lo[tid] = 0;
+    row_hi[tid] = 0;
     if (active) {
         w.data = G.streams[sidx];
         w.n = (int64_t) G.lens[sidx];
@@ -354,32 +426,24 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
                 w.ev_kind = T.trans[(size_t) c.pe_state * (T.ncls + 1) + c.pe_sym].kind;
             }
         } else {
-            /* speculative: warm up over the bytes in front of the segment.  In
-             * a fix-up round the warm-up starts from the state the verified
-             * prefix ended in (it tends to recur), otherwise from the initial
-             * state. */
-            uint32_t seed = T.init[0];
+            /* speculative: assume the state reached by a warm-up over the TILE
+             * bytes in front of the segment.  In a fix-up round the warm-up
+             * starts from the state the verified prefix ended in (it tends to
+             * recur), otherwise from the initial state. */
+            warm = true;
+            seed = T.init[0];
             if (lo != nullptr && lo[sidx] > 0) {
                 const uint32_t cs = sum[G.seg_first[sidx] + lo[sidx] - 1].s_out;
                 /* COUNT cannot resolve a pending match it has not seen */
                 if (cs != 0 && !(MODE == SRE_HIP_PIKE_COUNT && (T.state_flags[cs] & 1))) seed = cs;
             }
-            int64_t from = seg_a - SRE_SCAN_WARMUP;
-            if (from <= 0) {
-                from = 0;
-                seed = T.init[0];
-                w.cur_sp = 0;
-            }
             w.st = seed;
-            slow_run<MODE>(w, from, seg_a, true, seed);
         }
         s_in = w.st;
-        if (w.st == 0) w.finished = true;   /* carried in dead: the scan ended before us */
-        row_ptr[tid] = w.data + seg_a;
-        row_len[tid] = seg_b - seg_a;
-    } else {
-        row_ptr[tid] = nullptr;
-        row_len[tid] = 0;
+        /* row = [seg_a - TILE, seg_b): the warm-up round, then the segment */
+        row_ptr[tid] = w.data + seg_a - TILE;
+        row_lo[tid] = warm ? 0 : TILE;
+        row_hi[tid] = (int32_t) (TILE + (seg_b - seg_a));
     }
 
     /* pure-fast COUNT bookkeeping: the last 16-byte group that completed matches
@@ -389,39 +453,23 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
     uint32_t fc_s0 = 0;
     bool     fc_pending = false;
 
-    const uint32_t nrounds = G.seg_bytes / SRE_SCAN_TILE;
+    const uint32_t nrounds = 1 + G.seg_bytes / TILE;
+    uint4          regs[TILE / 16];
+    __syncthreads();                        /* row tables are complete */
+    tile_fetch<TILE>(regs, row_ptr, row_lo, row_hi, tid, 0);
     for (uint32_t r = 0; r < nrounds; r++) {
+        __syncthreads();                    /* everybody is done with the previous tile */
+        tile_store<TILE>(regs, tile, tid);
         __syncthreads();
-        /* ---- stage 256 rows x 64 bytes ---- */
-#pragma unroll
-        for (uint32_t i = 0; i < SRE_SCAN_TILE / 16; i++) {
-            const uint32_t piece = i * SRE_SCAN_BLOCK + tid;
-            const uint32_t row = piece / (SRE_SCAN_TILE / 16), col = piece % (SRE_SCAN_TILE / 16);
-            const int64_t  off = (int64_t) r * SRE_SCAN_TILE + col * 16;
-            uint4          v = make_uint4(0, 0, 0, 0);
-            if (row_len[row] - off >= 16) {
-                const uint8_t *src = row_ptr[row] + off;
-                if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
-                    v = *reinterpret_cast<const uint4 *>(src);
-                } else {
-                    uint32_t x[4];
-                    for (int q = 0; q < 4; q++) {
-                        x[q] = (uint32_t) src[4 * q] | ((uint32_t) src[4 * q + 1] << 8)
-                               | ((uint32_t) src[4 * q + 2] << 16) | ((uint32_t) src[4 * q + 3] << 24);
-                    }
-                    v = make_uint4(x[0], x[1], x[2], x[3]);
-                }
-            }
-            *reinterpret_cast<uint4 *>(tile + row * ROW_BYTES + col * 16) = v;
-        }
-        __syncthreads();
+        /* next round's HBM loads fly while this round is consumed from LDS */
+        if (r + 1 < nrounds) tile_fetch<TILE>(regs, row_ptr, row_lo, row_hi, tid, r + 1);
 
-        if (!active || w.finished) continue;
-        const int64_t base = seg_a + (int64_t) r * SRE_SCAN_TILE;
+        const bool warm_round = (r == 0);
+        if (!active || w.finished || (warm_round && !warm)) continue;
+        const int64_t base = seg_a + ((int64_t) r - 1) * TILE;
         if (base >= seg_b) continue;
 
-#pragma unroll
-        for (uint32_t q = 0; q < SRE_SCAN_TILE / 16; q++) {
+        for (uint32_t q = 0; q < TILE / 16; q++) {
             const int64_t gp = base + q * 16;
             if (gp >= seg_b || w.finished) break;
             if (gp + 16 > seg_b) {
@@ -433,37 +481,56 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
             }
             const uint4    v = *reinterpret_cast<const uint4 *>(tile + tid * ROW_BYTES + q * 16);
             const uint32_t words[4] = {v.x, v.y, v.z, v.w};
-            uint32_t       so = w.st * SRE_FAST_ROW_BYTES, acc = 0, cnt = 0, lastb = 0;
+            /* byte -> class, independent of the state chain */
+            uint32_t kk[16];
 #pragma unroll
             for (int b = 0; b < 16; b++) {
                 const uint32_t c = (words[b >> 2] >> ((b & 3) * 8)) & 0xffu;
-                const uint32_t t = fast[(so >> 2) + c];
+                kk[b] = BITS == 8 ? c : (uint32_t) clsl[c];
+            }
+            uint32_t so = w.st * SRE_FAST_ROW_BYTES, acc = 0, cnt = 0, lastb = 0;
+#pragma unroll
+            for (int j = 0; j < 16 / STRIDE; j++) {
+                uint32_t idx = 0;
+#pragma unroll
+                for (int u = 0; u < STRIDE; u++) idx |= kk[j * STRIDE + u] << (u * BITS);
+                const uint32_t t = fast[(so >> 2) + idx];
                 acc |= t;
                 if (MODE == SRE_HIP_PIKE_COUNT) {
-                    cnt += (t >> 1) & 1u;
-                    lastb = (t & SRE_FAST_COUNT) ? (uint32_t) b : lastb;
+                    const uint32_t c1 = (t >> SRE_FAST_CNT_SHIFT) & SRE_FAST_CNT_MASK;
+                    cnt += c1;
+                    lastb = c1 ? (uint32_t) (j * STRIDE) + ((t >> SRE_FAST_LAST_SHIFT) & 7u) : lastb;
                 }
                 so = t & ~(SRE_FAST_ROW_BYTES - 1);
             }
             if (acc & SRE_FAST_SLOW) {
                 const int64_t before = w.count;
-                slow_run<MODE>(w, gp, gp + 16, false, 0);
+                slow_run<MODE>(w, gp, gp + 16, warm_round, seed);
                 if (w.count != before) fc_pending = false;
             } else {
                 if (MODE == SRE_HIP_PIKE_COUNT && cnt) {
                     /* matches completed inside this group, each followed by a
-                     * restart at the next byte: remember the group, its last
-                     * completing transition is recovered at the end */
-                    fc_gpos = gp;
-                    fc_s0 = w.st;
-                    fc_sp0 = w.cur_sp;
-                    fc_pending = true;
-                    w.count += cnt;
+                     * restart at the next byte */
                     w.has_ev = false;               /* superseded */
-                    w.cur_sp = gp + lastb + 1;
+                    if (!warm_round) {
+                        /* remember the group: its last completing transition is
+                         * recovered at the end if it stays the segment's last */
+                        fc_gpos = gp;
+                        fc_s0 = w.st;
+                        fc_sp0 = w.cur_sp;
+                        fc_pending = true;
+                        w.count += cnt;
+                        w.cur_sp = gp + lastb + 1;
+                    }
                 }
                 w.st = so / SRE_FAST_ROW_BYTES;
             }
+        }
+        if (warm_round) {
+            /* what this lane assumes about its entry */
+            s_in = w.st;
+            w.cur_sp = -1;                  /* search starts seen in the warm-up are not verified */
+            if (w.st == 0) w.finished = true;
         }
     }
 
@@ -508,60 +575,103 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
 /* ===================================================================== verify */
 
 /*
- * One workgroup per stream: check the chain of assumed entry states, find the
- * first segment that ended the scan, and reduce the verified prefix to the
- * stream's outcome.
+ * Chain check and reduction, grid-wide (one lane per segment), in three small
+ * kernels so that the single-stream case (hundreds of thousands of segments)
+ * is not serialised on one workgroup:
+ *   A  first broken link / first segment that ended the scan   (atomicMin)
+ *   B  over the verified-and-needed prefix: match count, last match's segment
+ *   C  per stream: assemble the status word (+ the search start of the match)
  */
-__global__ __launch_bounds__(256) void
-sre_k_verify(sre_scan_tables_t T, sre_scan_geom_t G, const sre_seg_summary_t *__restrict__ sum,
-             sre_stream_status_t *__restrict__ status)
-{
-    __shared__ unsigned long long sh_bad, sh_end, sh_evseg, sh_spseg, sh_count;
-    const uint32_t s = blockIdx.x;
-    const uint64_t first = G.seg_first[s], nseg = G.seg_first[s + 1] - first;
-    const bool     count_mode = (T.mode == SRE_HIP_PIKE_COUNT);
+struct VerifyAcc {
+    unsigned long long bad, end;        /* init ~0 */
+    unsigned long long count, evseg, spseg;     /* init 0 */
+};
 
+__device__ inline uint32_t
+stream_of(const sre_scan_geom_t &G, uint64_t g)
+{
+    uint32_t a = 0, b = G.nstreams;
+    while (b - a > 1) {
+        uint32_t m = (a + b) >> 1;
+        if (G.seg_first[m] <= g) a = m; else b = m;
+    }
+    return a;
+}
+
+__global__ __launch_bounds__(256) void
+sre_k_verify_a(sre_scan_geom_t G, const sre_seg_summary_t *__restrict__ sum, VerifyAcc *__restrict__ acc)
+{
+    const uint64_t g = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G.nsegs) return;
+    const uint32_t s = stream_of(G, g);
+    const uint64_t k = g - G.seg_first[s];
+    const uint32_t s_in = sum[g].s_in;
+    if ((k > 0 && s_in != sum[g - 1].s_out) || s_in == 0xffffffffu) atomicMin(&acc[s].bad, (unsigned long long) k);
+    if (sum[g].flags & SRE_SUM_TERM) atomicMin(&acc[s].end, (unsigned long long) k);
+}
+
+__global__ __launch_bounds__(256) void
+sre_k_verify_b(sre_scan_geom_t G, const sre_seg_summary_t *__restrict__ sum, VerifyAcc *__restrict__ acc)
+{
+    __shared__ unsigned long long sh_count, sh_ev;
+    const uint64_t g0 = (uint64_t) blockIdx.x * blockDim.x;
+    const uint64_t g = g0 + threadIdx.x;
+    const uint64_t glast = (g0 + blockDim.x - 1 < G.nsegs) ? g0 + blockDim.x - 1 : G.nsegs - 1;
+    const uint32_t s_first = stream_of(G, g0), s_last = stream_of(G, glast);
+    const bool     uniform = (s_first == s_last);       /* whole block inside one stream */
     if (threadIdx.x == 0) {
-        sh_bad = nseg;
-        sh_end = nseg;
-        sh_evseg = 0;
-        sh_spseg = 0;
         sh_count = 0;
+        sh_ev = 0;
     }
     __syncthreads();
-    for (uint64_t k = threadIdx.x; k < nseg; k += blockDim.x) {
-        const sre_seg_summary_t &c = sum[first + k];
-        if ((k > 0 && c.s_in != sum[first + k - 1].s_out) || c.s_in == 0xffffffffu) {
-            atomicMin(&sh_bad, (unsigned long long) k);
+    if (g < G.nsegs) {
+        const uint32_t s = uniform ? s_first : stream_of(G, g);
+        const uint64_t k = g - G.seg_first[s];
+        const uint64_t nseg = G.seg_first[s + 1] - G.seg_first[s];
+        uint64_t       bad = acc[s].bad, end = acc[s].end;
+        if (bad > nseg) bad = nseg;
+        if (end > nseg) end = nseg;
+        const uint64_t limit = end < bad ? end + 1 : bad;
+        if (k < limit) {
+            const sre_seg_summary_t &c = sum[g];
+            if (uniform) {
+                if (c.count) atomicAdd(&sh_count, (unsigned long long) c.count);
+                if (c.flags & SRE_SUM_LASTEV) atomicMax(&sh_ev, (unsigned long long) k + 1);
+            } else {
+                if (c.count) atomicAdd(&acc[s].count, (unsigned long long) c.count);
+                if (c.flags & SRE_SUM_LASTEV) atomicMax(&acc[s].evseg, (unsigned long long) k + 1);
+            }
+            /* latest segment at whose end a search start is known */
+            if (c.cur_sp >= 0) atomicMax(&acc[s].spseg, (unsigned long long) k + 1);
         }
-        if (c.flags & SRE_SUM_TERM) atomicMin(&sh_end, (unsigned long long) k);
     }
     __syncthreads();
-    const uint64_t bad = sh_bad, end = sh_end;
+    if (uniform && threadIdx.x == 0) {
+        if (sh_count) atomicAdd(&acc[s_first].count, sh_count);
+        if (sh_ev) atomicMax(&acc[s_first].evseg, sh_ev);
+    }
+}
+
+__global__ void
+sre_k_verify_c(sre_scan_tables_t T, sre_scan_geom_t G, const sre_seg_summary_t *__restrict__ sum,
+               const VerifyAcc *__restrict__ acc, sre_stream_status_t *__restrict__ status)
+{
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= G.nstreams) return;
+    const uint64_t first = G.seg_first[s], nseg = G.seg_first[s + 1] - first;
+    uint64_t       bad = acc[s].bad, end = acc[s].end;
+    if (bad > nseg) bad = nseg;
+    if (end > nseg) end = nseg;
     const bool     done = (end < bad) || (bad >= nseg);
-    const uint64_t limit = end < bad ? end + 1 : bad;       /* verified AND needed */
-    for (uint64_t k = threadIdx.x; k < limit; k += blockDim.x) {
-        const sre_seg_summary_t &c = sum[first + k];
-        if (c.count) atomicAdd(&sh_count, (unsigned long long) c.count);
-        if (c.flags & SRE_SUM_LASTEV) atomicMax(&sh_evseg, (unsigned long long) k + 1);
-    }
-    __syncthreads();
-    const uint64_t evseg = sh_evseg;        /* 1 + segment of the final match, 0 none */
-    if (done && evseg > 0 && sum[first + evseg - 1].lm_sp < 0) {
-        /* its search began in an earlier segment: latest known start before it */
-        for (uint64_t k = threadIdx.x; k + 1 < evseg; k += blockDim.x) {
-            if (sum[first + k].cur_sp >= 0) atomicMax(&sh_spseg, (unsigned long long) k + 1);
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x != 0) return;
+    const uint64_t limit = end < bad ? end + 1 : bad;
+    const uint64_t evseg = acc[s].evseg;
 
     sre_stream_status_t st;
     st.first_bad = (int64_t) bad;
     st.limit = (int64_t) limit;
     st.done = done ? 1 : 0;
     st.error = 0;
-    st.count = (int64_t) sh_count;
+    st.count = (int64_t) acc[s].count;
     st.rc = RC_DECLINED;
     st.ev_pos = st.ev_sp = -1;
     st.ev_state = st.ev_sym = 0;
@@ -574,8 +684,27 @@ sre_k_verify(sre_scan_tables_t T, sre_scan_geom_t G, const sre_seg_summary_t *__
         st.ev_sp = c.lm_sp;
         st.ev_seg = (int64_t) evseg - 1;
         st.rc = T.trans[(size_t) c.lm_state * (T.ncls + 1) + c.lm_sym].regex;
-        if (!count_mode) st.count = 1;
-        if (st.ev_sp < 0) st.ev_sp = sh_spseg ? sum[first + sh_spseg - 1].cur_sp : 0;
+        if (T.mode != SRE_HIP_PIKE_COUNT) st.count = 1;
+        if (st.ev_sp < 0) {
+            /* the match's search began in an earlier segment: the latest start
+             * known before it.  (A start known at or after the match's own
+             * segment belongs to a later search.) */
+            int64_t        sp = 0;
+            const uint64_t spseg = acc[s].spseg;
+            if (T.mode != SRE_HIP_PIKE_COUNT || spseg == 0) {
+                sp = 0;                     /* one search per stream, from its start */
+            } else if (spseg < evseg) {
+                sp = sum[first + spseg - 1].cur_sp;
+            } else {
+                for (int64_t q = (int64_t) evseg - 2; q >= 0; q--) {
+                    if (sum[first + q].cur_sp >= 0) {
+                        sp = sum[first + q].cur_sp;
+                        break;
+                    }
+                }
+            }
+            st.ev_sp = sp;
+        }
     }
     if (done && end < nseg && (sum[first + end].flags & SRE_SUM_ERROR)) st.error = 1;
     status[s] = st;
@@ -717,30 +846,91 @@ sre_k_captures(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
 
 }  // namespace
 
+template <int MODE, int TILE>
+static void
+launch_scan_bits(uint32_t bits, uint32_t grid, size_t shmem, hipStream_t stream,
+                 const sre_scan_tables_t *d_tab, sre_scan_geom_t geom, sre_seg_summary_t *d_sum,
+                 const int64_t *d_lo)
+{
+    switch (bits) {
+    case 1:
+        hipLaunchKernelGGL((sre_k_scan<MODE, 1, TILE>), dim3(grid), dim3(SRE_SCAN_BLOCK), shmem,
+                           stream, d_tab, geom, d_sum, d_lo);
+        break;
+    case 2:
+        hipLaunchKernelGGL((sre_k_scan<MODE, 2, TILE>), dim3(grid), dim3(SRE_SCAN_BLOCK), shmem,
+                           stream, d_tab, geom, d_sum, d_lo);
+        break;
+    case 4:
+        hipLaunchKernelGGL((sre_k_scan<MODE, 4, TILE>), dim3(grid), dim3(SRE_SCAN_BLOCK), shmem,
+                           stream, d_tab, geom, d_sum, d_lo);
+        break;
+    default:
+        hipLaunchKernelGGL((sre_k_scan<MODE, 8, TILE>), dim3(grid), dim3(SRE_SCAN_BLOCK), shmem,
+                           stream, d_tab, geom, d_sum, d_lo);
+        break;
+    }
+}
+
+template <int MODE>
+static void
+launch_scan_tile(uint32_t tile, uint32_t bits, uint32_t grid, size_t shmem, hipStream_t stream,
+                 const sre_scan_tables_t *d_tab, sre_scan_geom_t geom, sre_seg_summary_t *d_sum,
+                 const int64_t *d_lo)
+{
+    if (tile == 64) launch_scan_bits<MODE, 64>(bits, grid, shmem, stream, d_tab, geom, d_sum, d_lo);
+    else if (tile == 32) launch_scan_bits<MODE, 32>(bits, grid, shmem, stream, d_tab, geom, d_sum, d_lo);
+    else if (tile == 256) launch_scan_bits<MODE, 256>(bits, grid, shmem, stream, d_tab, geom, d_sum, d_lo);
+    else launch_scan_bits<MODE, 128>(bits, grid, shmem, stream, d_tab, geom, d_sum, d_lo);
+}
+
+extern "C" size_t
+sre_scan_lds_bytes(const sre_scan_tables_t *h_tab, uint32_t tile)
+{
+    const size_t tr = (size_t) h_tab->nstates * (h_tab->ncls + 1) * sizeof(sre_dev_trans_t);
+    return (size_t) h_tab->fast_bytes + 256 + tr + ((h_tab->nstates + 15u) & ~15u)
+           + (size_t) SRE_SCAN_BLOCK * (tile + 16);
+}
+
 extern "C" hipError_t
 sre_launch_scan(const sre_scan_tables_t *d_tab, sre_scan_tables_t h_tab, sre_scan_geom_t geom,
                 sre_seg_summary_t *d_sum, const int64_t *d_lo, hipStream_t stream)
 {
     if (geom.nsegs == 0) return hipSuccess;
     const uint32_t grid = (uint32_t) ((geom.nsegs + SRE_SCAN_BLOCK - 1) / SRE_SCAN_BLOCK);
-    const size_t   shmem = (size_t) h_tab.fast_bytes + (size_t) SRE_SCAN_BLOCK * (SRE_SCAN_TILE + 16);
+    const size_t   shmem = sre_scan_lds_bytes(&h_tab, geom.tile);
     if (h_tab.mode == SRE_HIP_PIKE_COUNT) {
-        hipLaunchKernelGGL(sre_k_scan<SRE_HIP_PIKE_COUNT>, dim3(grid), dim3(SRE_SCAN_BLOCK), shmem,
-                           stream, d_tab, geom, d_sum, d_lo);
+        launch_scan_tile<SRE_HIP_PIKE_COUNT>(geom.tile, h_tab.class_bits, grid, shmem, stream, d_tab, geom, d_sum, d_lo);
     } else {
-        hipLaunchKernelGGL(sre_k_scan<1>, dim3(grid), dim3(SRE_SCAN_BLOCK), shmem, stream, d_tab,
-                           geom, d_sum, d_lo);
+        launch_scan_tile<1>(geom.tile, h_tab.class_bits, grid, shmem, stream, d_tab, geom, d_sum, d_lo);
     }
     return hipGetLastError();
 }
 
+extern "C" size_t
+sre_scan_verify_acc_bytes(uint32_t nstreams)
+{
+    return (size_t) nstreams * sizeof(VerifyAcc);
+}
+
 extern "C" hipError_t
 sre_launch_verify(sre_scan_tables_t h_tab, sre_scan_geom_t geom, const sre_seg_summary_t *d_sum,
-                  sre_stream_status_t *d_status, hipStream_t stream)
+                  void *d_acc, sre_stream_status_t *d_status, hipStream_t stream)
 {
     if (geom.nstreams == 0) return hipSuccess;
-    hipLaunchKernelGGL(sre_k_verify, dim3(geom.nstreams), dim3(256), 0, stream, h_tab, geom, d_sum,
-                       d_status);
+    VerifyAcc *acc = static_cast<VerifyAcc *>(d_acc);
+    /* bad/end start at ~0, the counters at 0: two strided memsets */
+    hipError_t e = hipMemset2DAsync(acc, sizeof(VerifyAcc), 0xff, 2 * sizeof(unsigned long long),
+                                    geom.nstreams, stream);
+    if (e != hipSuccess) return e;
+    e = hipMemset2DAsync(reinterpret_cast<char *>(acc) + 2 * sizeof(unsigned long long),
+                         sizeof(VerifyAcc), 0, 3 * sizeof(unsigned long long), geom.nstreams, stream);
+    if (e != hipSuccess) return e;
+    const uint32_t gseg = (uint32_t) ((geom.nsegs + 255) / 256);
+    hipLaunchKernelGGL(sre_k_verify_a, dim3(gseg), dim3(256), 0, stream, geom, d_sum, acc);
+    hipLaunchKernelGGL(sre_k_verify_b, dim3(gseg), dim3(256), 0, stream, geom, d_sum, acc);
+    hipLaunchKernelGGL(sre_k_verify_c, dim3((geom.nstreams + 63) / 64), dim3(64), 0, stream, h_tab,
+                       geom, d_sum, acc, d_status);
     return hipGetLastError();
 }
 

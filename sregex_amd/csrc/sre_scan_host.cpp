@@ -69,29 +69,47 @@ sre_scan_tables_build(const sre_program_t *prog, const sre_dfa_t *d, int mode, c
     h.fast_bytes = d->nstates * SRE_FAST_ROW_BYTES;
     h.nregexes = prog->nregexes;
 
-    /* fast table */
+    /* fast table: `stride` bytes per lookup through packed byte classes */
+    uint32_t bits = 8;
+    if (d->ncls <= 2) bits = 1;
+    else if (d->ncls <= 4) bits = 2;
+    else if (d->ncls <= 16) bits = 4;
+    const uint32_t stride = 8 / bits;
+    h.stride = stride;
+    h.class_bits = bits;
+    h.warmup = 0;      /* the warm-up is one tile round, see sre_k_scan */
     std::vector<uint32_t> fast((size_t) d->nstates * 256);
     for (uint32_t s = 0; s < d->nstates; s++) {
-        for (unsigned c = 0; c < 256; c++) {
-            uint32_t next, flags = 0;
-            if (s == SRE_DFA_DEAD) {
-                next = SRE_DFA_DEAD;
-                flags = SRE_FAST_SLOW;
-            } else {
-                const sre_dfa_trans_t &tr = d->t(s, d->cls_map[c]);
-                next = tr.next;
+        for (unsigned idx = 0; idx < 256; idx++) {
+            uint32_t st = s, flags = 0, cnt = 0, last = 0;
+            for (uint32_t sub = 0; sub < stride && !(flags & SRE_FAST_SLOW); sub++) {
+                /* sub-step `sub` consumes input byte `sub` of the group */
+                const uint32_t k = bits == 8 ? d->cls_map[idx] : ((idx >> (sub * bits)) & ((1u << bits) - 1));
+                if (st == SRE_DFA_DEAD || k >= d->ncls) {
+                    flags |= SRE_FAST_SLOW;
+                    break;
+                }
+                const sre_dfa_trans_t &tr = d->t(st, k);
                 if (mode == SRE_HIP_PIKE_COUNT && tr.ev_kind == SRE_DFA_EV_DONE
                     && tr.next == SRE_DFA_DEAD)
                 {
                     /* a non-empty match completes and nothing outlives it: the
                      * next search starts at the next byte (sre_vm_pike.c:624-628) */
-                    next = d->init[SRE_DFA_INIT_RESTART];
-                    flags = SRE_FAST_COUNT;
+                    st = d->init[SRE_DFA_INIT_RESTART];
+                    cnt++;
+                    last = sub;
                 } else if (tr.ev_kind != SRE_DFA_EV_NONE || tr.next == SRE_DFA_DEAD) {
-                    flags = SRE_FAST_SLOW;
+                    flags |= SRE_FAST_SLOW;
+                } else {
+                    st = tr.next;
                 }
             }
-            fast[(size_t) s * 256 + c] = next * SRE_FAST_ROW_BYTES | flags;
+            if (flags & SRE_FAST_SLOW) {
+                st = s;
+                cnt = last = 0;
+            }
+            fast[(size_t) s * 256 + idx] = st * SRE_FAST_ROW_BYTES | flags
+                                           | (cnt << SRE_FAST_CNT_SHIFT) | (last << SRE_FAST_LAST_SHIFT);
         }
     }
 
