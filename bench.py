@@ -9,8 +9,8 @@ Workload (BASELINE.json):
           captures), input resident in HBM (generated on device).
   N  > 1  configs[4] shape: 64*N independent 64 MiB streams of the same pattern,
           stream i on rank i mod N (64 streams = 4 GiB per GPU, weak scaling),
-          tails alternate matching / non-matching; the only collective is one
-          RCCL all-reduce of the per-rank match counts.
+          tails alternate matching (" a@abc.cc ") / non-matching ("aaabbccb");
+          the only collective is one RCCL all-reduce of the per-rank match counts.
 A step = one complete scan of the rank's resident input through the public
 batched C ABI (sre_hip_scan_enqueue + sre_hip_scan_results), results included.
 Rank 0 prints ONE JSON line.
@@ -90,10 +90,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--bytes", type=int, default=4 * GIB, help="bytes per GPU (default 4 GiB)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--many-streams", action="store_true",
+                    help="use the N>1 workload shape (64 MiB streams) even on one GPU")
     args = ap.parse_args()
 
     import torch
     import sregex_amd as S
+    from sregex_amd import shard
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -110,7 +113,7 @@ def main():
     hstream = ctypes.c_void_p(stream.cuda_stream)
 
     # ---- resident input -------------------------------------------------
-    if world == 1:
+    if world == 1 and not args.many_streams:
         tail = b"aaabbccb"
         n = S.gen_data_length(args.bytes, len(tail))
         lens = [n]
@@ -120,8 +123,9 @@ def main():
     else:
         per = 64 << 20
         nstreams = max(1, args.bytes // per)
-        # global stream g = j * world + rank: even g carries a matching tail
-        tails = [(b"@abc.cc " if ((j * world + rank) % 2 == 0) else b"aaabbccb") for j in range(nstreams)]
+        # stream g lives on rank g mod world; even g carries a matching tail
+        mine = shard.shard_streams(nstreams * world, rank, world)
+        tails = [(b" a@abc.cc " if g % 2 == 0 else b"aaabbccb") for g in mine]
         lens = [S.gen_data_length(per, len(t)) for t in tails]
         workload = ("configs[4] shape: %d streams x 64 MiB per GPU (round-robin over %d GPUs), "
                     "/[a-z]+@[a-z]+\\.[a-z]+/ Pike, RCCL all-reduce of match counts" % (nstreams, world))
@@ -149,8 +153,8 @@ def main():
     # correctness of what is being timed (size-independent property): a stream
     # matches iff its tail holds the '@' form, and then spans the whole stream
     for n, t, r in zip(lens, tails, recs):
-        if t.startswith(b"@"):
-            assert r[:4] == [0, 1, 0, n - 1], (r, n)
+        if b"@" in t:
+            assert r[:4] == [0, 1, n - 9, n - 1], (r, n)      # "a@abc.cc" in front of the last space
         else:
             assert r[0] == S.SRE_DECLINED and r[1] == 0, r
 
@@ -164,15 +168,8 @@ def main():
     dt = time.perf_counter() - t0
 
     matches = sum(1 for r in recs if r[0] >= 0)
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-        cnt = torch.tensor([matches, total], dtype=torch.int64, device="cuda")
-        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)      # the path's only exchange step
-        matches, total_all = int(cnt[0].item()), int(cnt[1].item())
-    else:
-        total_all = total
+    dt = shard.allreduce_max(dt, "cuda")                        # slowest rank
+    matches, total_all = shard.allreduce_counts([matches, total], "cuda")   # the path's only exchange step
 
     if rank == 0:
         ms_per_step = dt / args.steps * 1e3
@@ -192,7 +189,17 @@ def main():
                          "kernel": "sre_k_scan<1>", "kernel_ms": kms,
                          "algorithmic_bytes_per_launch": total},
         }
-        if world == 1:
+        prof = os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")
+        if world == 1 and total == 4 * GIB - 3 and os.path.exists(prof):
+            # HBM bytes per launch from the separate rocprofv3 --pmc passes of this
+            # same command (profiles/README.md): 2 x FETCH_SIZE (gfx950 correction,
+            # MI355X_MICROARCH.md HBM section) + WRITE_SIZE, KB -> bytes
+            pm = {(r["counter"], "sre_k_scan<1, 2, 64>" in r["kernel"]): r["mean_value_KB"]
+                  for r in json.load(open(prof))}
+            if ("FETCH_SIZE", True) in pm:
+                line["roofline"]["traffic"] = (2 * pm[("FETCH_SIZE", True)] + pm[("WRITE_SIZE", True)]) * 1024
+                line["roofline"]["traffic_source"] = "profiles/r01_pmc_hbm.json"
+        if world == 1 and not args.many_streams:
             # measured streaming-read ceiling of this box, same buffer
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             lib.sre_hip_read_ceiling(ptrs[0], lens[0], hstream)

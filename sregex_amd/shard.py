@@ -1,0 +1,36 @@
+"""Multi-GPU partitioning of the path: independent streams, one context each
+("Different data streams MUST use different ctx instances", reference
+README.markdown:376), so stream i simply lives on rank i mod world and the only
+exchange step is one all-reduce of the per-rank match counters.
+One process per GPU; the collective goes through torch.distributed
+(backend "nccl" = RCCL on ROCm, "gloo" on CPU for tests).
+"""
+
+
+def shard_streams(nstreams, rank, world):
+    """Global stream indices owned by `rank`: round-robin i mod world."""
+    return list(range(rank, nstreams, world))
+
+
+def local_stream_count(nstreams, rank, world):
+    return (nstreams - rank + world - 1) // world if nstreams > rank else 0
+
+
+def allreduce_counts(counts, device=None):
+    """Sum a small vector of int64 counters over all ranks (no-op without an
+    initialised process group).  Returns a list of ints."""
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor(list(counts), dtype=torch.int64, device=device or "cpu")
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [int(x) for x in t.tolist()]
+
+
+def allreduce_max(value, device=None):
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([float(value)], dtype=torch.float64, device=device or "cpu")
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
