@@ -70,6 +70,10 @@ SRE_API int sre_hip_scanner_set_segment_bytes(sre_hip_scanner_t *sc, size_t byte
  * entry state was right) */
 SRE_API int sre_hip_scanner_last_fixups(sre_hip_scanner_t *sc);
 
+/* diagnostics: 1 when the last scan had to build per-segment ancestor maps to
+ * reconstruct the captures of a match spanning many segments */
+SRE_API int sre_hip_scanner_last_lineage_passes(sre_hip_scanner_t *sc);
+
 /* measurement: duration (ms) of the segment-scan kernel of the last enqueued
  * scan, from hipEvents recorded on the caller's stream around that launch;
  * -1 when the exact VM engine ran.  Waits for the kernel. */

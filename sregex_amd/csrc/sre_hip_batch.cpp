@@ -46,6 +46,9 @@ struct sre_hip_scanner_s {
     int64_t                  *d_lo, *h_lo;
     uint16_t                 *d_scratch;
     size_t                    scratch_cap;
+    sre_seg_lineage_t        *d_maps, *d_blocks;
+    size_t                    maps_cap;
+    int                       lineage_passes;   /* of the last scan (diagnostics) */
     int                       fixup_rounds;     /* of the last scan (diagnostics) */
     hipEvent_t                ev0, ev1;         /* around the dominant scan kernel */
     int                       ev_valid;
@@ -70,6 +73,8 @@ scanner_release(void *data)
     if (sc->d_lo) (void) hipFree(sc->d_lo);
     if (sc->h_lo) (void) hipHostFree(sc->h_lo);
     if (sc->d_scratch) (void) hipFree(sc->d_scratch);
+    if (sc->d_maps) (void) hipFree(sc->d_maps);
+    if (sc->d_blocks) (void) hipFree(sc->d_blocks);
     if (sc->ev0) (void) hipEventDestroy(sc->ev0);
     if (sc->ev1) (void) hipEventDestroy(sc->ev1);
     sre_scan_tables_release(sc->tab);
@@ -158,6 +163,12 @@ extern "C" SRE_API int
 sre_hip_scanner_last_fixups(sre_hip_scanner_t *sc)
 {
     return sc->fixup_rounds;
+}
+
+extern "C" SRE_API int
+sre_hip_scanner_last_lineage_passes(sre_hip_scanner_t *sc)
+{
+    return sc->lineage_passes;
 }
 
 extern "C" SRE_API double
@@ -301,6 +312,7 @@ sre_hip_scan_enqueue(sre_hip_scanner_t *sc, const void *const *d_streams, const 
 {
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     sc->fixup_rounds = 0;
+    sc->lineage_passes = 0;
     sc->ev_valid = 0;
     if (nstreams == 0) {
         sc->last_n = 0;
@@ -337,7 +349,8 @@ sre_hip_scan_enqueue(sre_hip_scanner_t *sc, const void *const *d_streams, const 
         sc->ev_valid = 1;
         SRE_HIP_TRY(sre_launch_verify(sc->tab->h, sc->geom, sc->d_sum, sc->d_acc, sc->d_status, stream));
         SRE_HIP_TRY(sre_launch_captures(sc->tab->d_tab, sc->tab->h, sc->geom, sc->d_sum, sc->d_status,
-                                        sc->d_scratch, sc->d_records, sc->ovec_slots, stream));
+                                        sc->d_scratch, sc->d_records, sc->ovec_slots,
+                                        NULL, NULL, 0, stream));
     }
     sc->last_n = nstreams;
     sc->last_stream = stream;
@@ -379,7 +392,33 @@ sre_hip_scan_results(sre_hip_scanner_t *sc, sre_int_t *results)
             SRE_HIP_TRY(sre_launch_verify(sc->tab->h, sc->geom, sc->d_sum, sc->d_acc, sc->d_status, stream));
             SRE_HIP_TRY(sre_launch_captures(sc->tab->d_tab, sc->tab->h, sc->geom, sc->d_sum,
                                             sc->d_status, sc->d_scratch, sc->d_records,
-                                            sc->ovec_slots, stream));
+                                            sc->ovec_slots, NULL, NULL, 0, stream));
+        }
+        /* a match whose lineage outran the plain backward walk: build the
+         * per-segment ancestor maps in parallel and walk again, jumping */
+        if (sc->mode != SRE_HIP_THOMPSON) {
+            size_t want = 0;
+            for (size_t i = 0; i < n; i++) want += sc->h_status[i].need_maps != 0;
+            if (want) {
+                if (sc->geom.nsegs > sc->maps_cap) {
+                    if (sc->d_maps) (void) hipFree(sc->d_maps);
+                    if (sc->d_blocks) (void) hipFree(sc->d_blocks);
+                    sc->d_maps = sc->d_blocks = NULL;
+                    sc->maps_cap = 0;
+                    SRE_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&sc->d_maps),
+                                          sc->geom.nsegs * sizeof(sre_seg_lineage_t)));
+                    SRE_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&sc->d_blocks),
+                                          (sc->geom.nsegs / SRE_LINEAGE_BLOCK + 1) * sizeof(sre_seg_lineage_t)));
+                    sc->maps_cap = sc->geom.nsegs;
+                }
+                sc->lineage_passes++;
+                SRE_HIP_TRY(sre_launch_lineage(sc->tab->d_tab, sc->tab->h, sc->geom, sc->d_sum,
+                                               sc->d_status, sc->d_maps, sc->d_blocks, stream));
+                SRE_HIP_TRY(sre_launch_captures(sc->tab->d_tab, sc->tab->h, sc->geom, sc->d_sum,
+                                                sc->d_status, sc->d_scratch, sc->d_records,
+                                                sc->ovec_slots, sc->d_maps, sc->d_blocks,
+                                                1, stream));
+            }
         }
     }
     {

@@ -58,6 +58,9 @@ typedef struct {
     const sre_dev_trans_t *trans;       /* [nstates][ncls + 1], then 3 pseudo rows for the initial closures */
     const uint8_t         *lin_parent;
     const uint64_t        *lin_saves;
+    const uint8_t         *lin_flags;   /* per new thread: bit0 its closure path saved a slot,
+                                           bit1 it is the ".*?" ANY thread (pc 1) */
+    uint32_t               lin_total, pad2;
     const uint8_t         *state_flags; /* [nstates] bit0 matched, bits 1-2 seen_start (2 = reached by a skip) */
     const uint32_t        *list_off;    /* [nstates + 1] */
     const uint32_t        *list_pcs;
@@ -87,6 +90,19 @@ typedef struct {
 #define SRE_SUM_LASTEV    4u
 #define SRE_SUM_ERROR     8u   /* COUNT: ... and the iteration ended with SRE_ERROR */
 
+/* lineage of one segment (sre_k_lineage_maps): for the thread at index j of the
+ * list at the segment's END, which thread of the list at its START it descends
+ * from — valid to jump over the segment only if neither flag bit j is set */
+typedef struct {
+    uint64_t anc;           /* 16 nibbles */
+    uint16_t saved;         /* bit j: the lineage wrote a capture slot inside the segment */
+    uint16_t stop;          /* bit j: it passes through the ".*?" thread or a skip re-seed */
+    uint32_t pad;
+} sre_seg_lineage_t;
+
+#define SRE_LINEAGE_BLOCK  256u     /* segments composed into one block map */
+#define SRE_WALK_BUDGET_SEGS 1      /* plain backward walk before asking for the maps */
+
 /* per-stream outcome of verify + reduce */
 typedef struct {
     int64_t  first_bad;     /* first segment whose assumed entry state was wrong, or nseg */
@@ -98,6 +114,8 @@ typedef struct {
     int64_t  ev_seg;        /* segment holding the event */
     int32_t  done;          /* 1: result final, 0: needs a fix-up round from first_bad */
     int32_t  error;         /* COUNT: the iteration ended with SRE_ERROR */
+    int32_t  need_maps;     /* set by sre_k_captures: lineage too long for the plain walk */
+    int32_t  pad;
 } sre_stream_status_t;
 
 typedef struct {
@@ -129,10 +147,20 @@ size_t sre_scan_verify_acc_bytes(uint32_t nstreams);
 hipError_t sre_launch_verify(sre_scan_tables_t h_tab, sre_scan_geom_t geom,
     const sre_seg_summary_t *d_sum, void *d_acc, sre_stream_status_t *d_status,
     hipStream_t stream);
-/* captures of each stream's final match -> records [rc, count, ovector] */
+/* captures of each stream's final match -> records [rc, count, ovector].
+ * status[s].need_maps is set to 1 when the lineage is too long for the plain walk and the
+ * per-segment maps are required (then call sre_launch_lineage and this again
+ * with use_maps = 1). */
 hipError_t sre_launch_captures(const sre_scan_tables_t *d_tab, sre_scan_tables_t h_tab,
+    sre_scan_geom_t geom, const sre_seg_summary_t *d_sum, sre_stream_status_t *d_status,
+    uint16_t *d_scratch, int64_t *d_records, uint32_t ovec_slots,
+    const sre_seg_lineage_t *d_maps, const sre_seg_lineage_t *d_blocks, int use_maps,
+    hipStream_t stream);
+/* ancestor maps of every segment in front of a flagged stream's match, and
+ * their 256-segment compositions */
+hipError_t sre_launch_lineage(const sre_scan_tables_t *d_tab, sre_scan_tables_t h_tab,
     sre_scan_geom_t geom, const sre_seg_summary_t *d_sum, const sre_stream_status_t *d_status,
-    uint16_t *d_scratch, int64_t *d_records, uint32_t ovec_slots, hipStream_t stream);
+    sre_seg_lineage_t *d_maps, sre_seg_lineage_t *d_blocks, hipStream_t stream);
 #ifdef __cplusplus
 }
 #endif

@@ -671,6 +671,8 @@ sre_k_verify_c(sre_scan_tables_t T, sre_scan_geom_t G, const sre_seg_summary_t *
     st.limit = (int64_t) limit;
     st.done = done ? 1 : 0;
     st.error = 0;
+    st.need_maps = 0;
+    st.pad = 0;
     st.count = (int64_t) acc[s].count;
     st.rc = RC_DECLINED;
     st.ev_pos = st.ev_sp = -1;
@@ -759,19 +761,134 @@ struct Tracer {
     }
 };
 
+/*
+ * Ancestor maps (sre_dfa.h lineage, in parallel): one lane per segment in front
+ * of a flagged stream's match walks its segment forwards from the verified
+ * entry state and tracks, for every thread of the current list, the index of
+ * its ancestor in the segment's entry list plus two sticky bits (a SAVE on the
+ * way; passage through the ".*?" thread / a skip re-seed).  The capture walker
+ * can then jump over whole segments — and, through the 256-segment
+ * compositions, over whole blocks — in which its lineage did nothing.
+ */
+__global__ __launch_bounds__(256) void
+sre_k_lineage_maps(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
+                   const sre_seg_summary_t *__restrict__ sum,
+                   const sre_stream_status_t *__restrict__ status,
+                   sre_seg_lineage_t *__restrict__ maps)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const sre_scan_tables_t &T = *tabp;
+    const uint32_t nsym = T.ncls + 1;
+    /* LDS copies: class map, transition records, parent + flag bytes */
+    uint8_t         *clsl = lds;
+    sre_dev_trans_t *trl = reinterpret_cast<sre_dev_trans_t *>(lds + 256);
+    const uint32_t   ntr = T.nstates * nsym;
+    uint8_t         *parl = reinterpret_cast<uint8_t *>(trl + ntr);
+    uint8_t         *flgl = parl + ((T.lin_total + 15u) & ~15u);
+    for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) clsl[i] = T.cls[i];
+    for (uint32_t i = threadIdx.x; i < ntr; i += blockDim.x) trl[i] = T.trans[i];
+    for (uint32_t i = threadIdx.x; i < T.lin_total; i += blockDim.x) {
+        parl[i] = T.lin_parent[i];
+        flgl[i] = T.lin_flags[i];
+    }
+    __syncthreads();
+
+    const uint64_t g = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G.nsegs) return;
+    const uint32_t s = stream_of(G, g);
+    const sre_stream_status_t &st = status[s];
+    if (!st.need_maps) return;
+    const uint64_t first = G.seg_first[s];
+    const int64_t  k = (int64_t) (g - first);
+    const int64_t  sp = st.ev_sp;
+    if (k > st.ev_seg || (k + 1) * (int64_t) G.seg_bytes <= sp) return;
+
+    const uint8_t *data = G.streams[s];
+    const int64_t  n = (int64_t) G.lens[s];
+    int64_t        lo = k * (int64_t) G.seg_bytes, hi = lo + G.seg_bytes;
+    uint32_t       cur = sum[g].s_in;
+    if (hi > n) hi = n;
+    if (k == st.ev_seg && st.ev_pos < hi) hi = st.ev_pos;      /* list at the event position */
+    if (sp >= lo) {
+        lo = sp;
+        cur = T.init[sp == 0 ? 0 : 2];
+    }
+
+    uint64_t anc = 0xfedcba9876543210ull;       /* identity */
+    uint32_t saved = 0, stop = 0;
+    for (int64_t q = lo; q < hi; q++) {
+        const sre_dev_trans_t &tr = trl[cur * nsym + clsl[data[q]]];
+        uint64_t nanc = 0;
+        uint32_t nsaved = 0, nstop = 0;
+        for (uint32_t j = 0; j < tr.lin_n; j++) {
+            const uint32_t par = parl[tr.lin_off + j], f = flgl[tr.lin_off + j];
+            if (par == 0xffu) {
+                nstop |= 1u << j;
+            } else {
+                nanc |= ((anc >> (4 * par)) & 15ull) << (4 * j);
+                nsaved |= (((saved >> par) & 1u) | (f & 1u)) << j;
+                nstop |= (((stop >> par) & 1u) | ((f >> 1) & 1u)) << j;
+            }
+        }
+        anc = nanc;
+        saved = nsaved;
+        stop = nstop;
+        cur = tr.next;
+    }
+    sre_seg_lineage_t out;
+    out.anc = anc;
+    out.saved = (uint16_t) saved;
+    out.stop = (uint16_t) stop;
+    out.pad = 0;
+    maps[g] = out;
+}
+
+/* compose SRE_LINEAGE_BLOCK consecutive segment maps (global segment ids) */
+__global__ void
+sre_k_lineage_blocks(uint64_t nsegs, const sre_seg_lineage_t *__restrict__ maps,
+                     sre_seg_lineage_t *__restrict__ blocks)
+{
+    const uint64_t b = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t g0 = b * SRE_LINEAGE_BLOCK;
+    if (g0 + SRE_LINEAGE_BLOCK > nsegs) return;
+    uint64_t anc = 0;
+    uint32_t blocked = 0;
+    for (uint32_t j = 0; j < 16; j++) {
+        uint32_t cur = j;
+        bool     bad = false;
+        for (int64_t g = (int64_t) (g0 + SRE_LINEAGE_BLOCK) - 1; g >= (int64_t) g0 && !bad; g--) {
+            const sre_seg_lineage_t &m = maps[g];
+            if (((m.saved | m.stop) >> cur) & 1u) bad = true;
+            else cur = (uint32_t) ((m.anc >> (4 * cur)) & 15ull);
+        }
+        if (bad) blocked |= 1u << j;
+        anc |= (uint64_t) cur << (4 * j);
+    }
+    sre_seg_lineage_t out;
+    out.anc = anc;
+    out.saved = (uint16_t) blocked;
+    out.stop = 0;
+    out.pad = 0;
+    blocks[b] = out;
+}
+
 __global__ void
 sre_k_captures(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
                const sre_seg_summary_t *__restrict__ sum,
-               const sre_stream_status_t *__restrict__ status, uint16_t *__restrict__ scratch,
-               int64_t *__restrict__ records, uint32_t ovec_slots)
+               sre_stream_status_t *__restrict__ status, uint16_t *__restrict__ scratch,
+               int64_t *__restrict__ records, uint32_t ovec_slots,
+               const sre_seg_lineage_t *__restrict__ maps,
+               const sre_seg_lineage_t *__restrict__ blocks, int use_maps)
 {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= G.nstreams) return;
+    if (use_maps && !status[s].need_maps) return;   /* second pass: flagged streams only */
     const sre_scan_tables_t   &T = *tabp;
-    const sre_stream_status_t &st = status[s];
+    const sre_stream_status_t  st = status[s];
     int64_t                   *rec = records + (size_t) s * (2 + ovec_slots);
     const uint32_t             nsym = T.ncls + 1;
 
+    status[s].need_maps = 0;
     rec[0] = st.rc;
     rec[1] = st.count;
     for (uint32_t q = 0; q < ovec_slots; q++) rec[2 + q] = -1;
@@ -812,8 +929,41 @@ sre_k_captures(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
         unresolved &= ~m;
     }
 
+    const uint64_t first = G.seg_first[s];
+    const int64_t  seg = (int64_t) G.seg_bytes;
+    const int64_t  k_sp = tr.sp / seg;
+    const bool     can_jump = use_maps && T.max_threads <= 16;
+    int64_t        budget = (int64_t) SRE_WALK_BUDGET_SEGS * seg;
+
     /* thread j lives in the list at position p */
     for (int64_t p = st.ev_pos; unresolved; p--) {
+        if (can_jump && p > tr.sp && p % seg == 0 && p < st.ev_pos) {
+            /* at a segment start: jump over the segments (blocks) in front of it
+             * in which this lineage neither saved nor restarted */
+            int64_t k2 = p / seg - 1;
+            while (k2 > k_sp) {
+                const uint64_t g2 = first + (uint64_t) k2;
+                if (g2 % SRE_LINEAGE_BLOCK == SRE_LINEAGE_BLOCK - 1
+                    && k2 - (int64_t) SRE_LINEAGE_BLOCK > k_sp)
+                {
+                    const sre_seg_lineage_t &bm = blocks[g2 / SRE_LINEAGE_BLOCK];
+                    if (!((bm.saved >> j) & 1u)) {
+                        j = (uint32_t) ((bm.anc >> (4 * j)) & 15ull);
+                        k2 -= SRE_LINEAGE_BLOCK;
+                        continue;
+                    }
+                }
+                const sre_seg_lineage_t &m = maps[g2];
+                if (((m.saved | m.stop) >> j) & 1u) break;
+                j = (uint32_t) ((m.anc >> (4 * j)) & 15ull);
+                k2--;
+            }
+            p = (k2 + 1) * seg;
+        }
+        if (!can_jump && --budget < 0 && T.max_threads <= 16) {
+            status[s].need_maps = 1;         /* come back with the ancestor maps */
+            return;
+        }
         const uint32_t s_here = (p == st.ev_pos) ? st.ev_state : tr.state_before(p);
         if (T.list_pcs[T.list_off[s_here] + j] == 1) break;      /* the ".*?" ANY thread */
         const sre_dev_trans_t *t;
@@ -936,14 +1086,35 @@ sre_launch_verify(sre_scan_tables_t h_tab, sre_scan_geom_t geom, const sre_seg_s
 
 extern "C" hipError_t
 sre_launch_captures(const sre_scan_tables_t *d_tab, sre_scan_tables_t h_tab, sre_scan_geom_t geom,
-                    const sre_seg_summary_t *d_sum, const sre_stream_status_t *d_status,
+                    const sre_seg_summary_t *d_sum, sre_stream_status_t *d_status,
                     uint16_t *d_scratch, int64_t *d_records, uint32_t ovec_slots,
-                    hipStream_t stream)
+                    const sre_seg_lineage_t *d_maps, const sre_seg_lineage_t *d_blocks,
+                    int use_maps, hipStream_t stream)
 {
     (void) h_tab;
     if (geom.nstreams == 0) return hipSuccess;
     const uint32_t block = 64, grid = (geom.nstreams + block - 1) / block;
     hipLaunchKernelGGL(sre_k_captures, dim3(grid), dim3(block), 0, stream, d_tab, geom, d_sum,
-                       d_status, d_scratch, d_records, ovec_slots);
+                       d_status, d_scratch, d_records, ovec_slots, d_maps, d_blocks, use_maps);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t
+sre_launch_lineage(const sre_scan_tables_t *d_tab, sre_scan_tables_t h_tab, sre_scan_geom_t geom,
+                   const sre_seg_summary_t *d_sum, const sre_stream_status_t *d_status,
+                   sre_seg_lineage_t *d_maps, sre_seg_lineage_t *d_blocks, hipStream_t stream)
+{
+    if (geom.nsegs == 0) return hipSuccess;
+    const uint32_t nsym = h_tab.ncls + 1;
+    const size_t   shmem = 256 + (size_t) h_tab.nstates * nsym * sizeof(sre_dev_trans_t)
+                         + 2 * (size_t) ((h_tab.lin_total + 15u) & ~15u);
+    const uint32_t gseg = (uint32_t) ((geom.nsegs + 255) / 256);
+    hipLaunchKernelGGL(sre_k_lineage_maps, dim3(gseg), dim3(256), shmem, stream, d_tab, geom, d_sum,
+                       d_status, d_maps);
+    const uint64_t nblocks = geom.nsegs / SRE_LINEAGE_BLOCK;
+    if (nblocks) {
+        hipLaunchKernelGGL(sre_k_lineage_blocks, dim3((uint32_t) ((nblocks + 63) / 64)), dim3(64), 0,
+                           stream, geom.nsegs, d_maps, d_blocks);
+    }
     return hipGetLastError();
 }

@@ -133,6 +133,17 @@ sre_scan_tables_build(const sre_program_t *prog, const sre_dfa_t *d, int mode, c
         flags[s] = (uint8_t) ((d->matched[s] ? 1 : 0) | (d->seen_start[s] << 1));
     }
     std::vector<uint32_t> ncaps(prog->multi_ncaps, prog->multi_ncaps + prog->nregexes);
+    /* per new thread of every transition: did its closure path save, is it the ANY thread */
+    std::vector<uint8_t> lin_flags(d->lin_parent.size(), 0);
+    for (size_t i = 0; i < d->trans.size(); i++) {
+        const sre_dfa_trans_t &a = d->trans[i];
+        for (uint32_t j = 0; j < a.lin_n; j++) {
+            uint8_t f = d->lin_saves[a.lin_off + j] ? 1 : 0;
+            if (a.next != SRE_DFA_DEAD && d->list_pcs[d->list_off[a.next] + j] == 1) f |= 2;
+            lin_flags[a.lin_off + j] = f;
+        }
+    }
+    h.lin_total = (uint32_t) d->lin_parent.size();
     (void) nsym;
 
     hipError_t e;
@@ -141,6 +152,7 @@ sre_scan_tables_build(const sre_program_t *prog, const sre_dfa_t *d, int mode, c
         || (e = upload(trans, &h.trans, t->owned)) != hipSuccess
         || (e = upload(d->lin_parent, &h.lin_parent, t->owned)) != hipSuccess
         || (e = upload(d->lin_saves, &h.lin_saves, t->owned)) != hipSuccess
+        || (e = upload(lin_flags, &h.lin_flags, t->owned)) != hipSuccess
         || (e = upload(flags, &h.state_flags, t->owned)) != hipSuccess
         || (e = upload(d->list_off, &h.list_off, t->owned)) != hipSuccess
         || (e = upload(d->list_pcs, &h.list_pcs, t->owned)) != hipSuccess

@@ -240,3 +240,36 @@ def test_scanner_fixup_rounds_are_reported(gpu):
         buf.free()
         assert rec == [0, 1, 3, 505]
         assert sc.last_fixups >= 1
+
+
+@pytest.mark.parametrize("seg", [64, 4096])
+def test_scanner_long_lineage_uses_ancestor_maps(gpu, seg):
+    """A match that starts at offset 0 and ends at the far end of the stream:
+    its captures cannot be found by walking a few segments back.  The scanner
+    must fall back to the parallel per-segment ancestor maps (and their
+    256-segment compositions) and still be bit-exact."""
+    ora = harness.OracleEngine()
+    cases = [
+        ([rb"[a-z]+@[a-z]+\.[a-z]+"], S.gen_data_host(300000, b"@abc.cc ")),
+        ([rb"([a-z]+)@([a-z]+)\.([a-z]+)"], S.gen_data_host(70000, b"@abc.cc ")),
+        ([rb"(a|b|c)+(@)(x)?"], S.gen_data_host(50003, b"@")),
+        ([rb"x(.*)y(.*)z"], b"..x" + b"ab" * 20000 + b"y" + b"cd" * 9000 + b"z.."),
+    ]
+    for pats, data in cases:
+        with S.Pool() as pool:
+            re = S.parse(pool, pats)
+            prog = S.compile(pool, re)
+            first, cnt = _expect(ora, prog, re.ncaps, data)
+            buf = S.DeviceBuffer.from_bytes(data)
+            sc = S.Scanner(pool, prog, S.HIP_PIKE_FIRST, S.ENGINE_SCAN)
+            sc.set_segment_bytes(seg)
+            # several streams in one call, only some of them long-lineage
+            other = S.DeviceBuffer.from_bytes(b"zz a@b.c zz")
+            recs = sc.scan([other.ptr, buf.ptr, buf.ptr], [11, len(data), len(data)])
+            assert recs[1] == first and recs[2] == first, (pats, seg, recs[1], first)
+            assert sc.last_lineage_passes == 1, (pats, seg)
+            sc2 = S.Scanner(pool, prog, S.HIP_PIKE_COUNT, S.ENGINE_SCAN)
+            sc2.set_segment_bytes(seg)
+            assert sc2.scan([buf.ptr], [len(data)])[0] == cnt, (pats, seg)
+            buf.free()
+            other.free()
