@@ -54,6 +54,7 @@ typedef struct {
     uint32_t fast_bytes;                /* nstates * 1024 */
     uint32_t stride, class_bits;        /* input bytes per fast-table step */
     const uint32_t        *fast;        /* [nstates][256] */
+    const uint32_t        *fast_plain;  /* same without COUNT's folded restarts (== fast otherwise) */
     const uint8_t         *cls;         /* [256] */
     const sre_dev_trans_t *trans;       /* [nstates][ncls + 1], then 3 pseudo rows for the initial closures */
     const uint8_t         *lin_parent;

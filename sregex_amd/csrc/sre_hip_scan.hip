@@ -725,33 +725,103 @@ sre_k_verify_c(sre_scan_tables_t T, sre_scan_geom_t G, const sre_seg_summary_t *
  * when every slot is known.
  */
 struct Tracer {
-    const sre_scan_tables_t *T;
+    const sre_scan_tables_t *T;         /* cls / trans / fast point into LDS */
     const sre_seg_summary_t *sum;       /* this stream's summaries */
     const uint8_t           *data;
     int64_t                  n, sp;
     uint32_t                 seg_bytes, init_state;
-    uint16_t                *trace;
+    uint16_t                *ck;        /* checkpoint states of the loaded segment, every 64 bytes */
+    uint16_t                *trace;     /* states before each position of the loaded 64-byte block */
+    int64_t                  seg_lo, seg_hi;    /* loaded segment: [seg_lo, seg_hi], -1 none */
     int64_t                  blk_lo, blk_hi;
+
+    __device__ inline uint32_t step(uint32_t st, int64_t q) const
+    {
+        return T->trans[(size_t) st * (T->ncls + 1) + T->cls[data[q]]].next;
+    }
+
+    /* 16 bytes at a 16-byte aligned position through the packed-class fast
+     * table; groups holding an event fall back to byte steps */
+    __device__ uint32_t step16(uint32_t st, int64_t q) const
+    {
+        const uint32_t bits = T->class_bits, stride = T->stride;
+        const uint4    v = *reinterpret_cast<const uint4 *>(data + q);
+        const uint32_t words[4] = {v.x, v.y, v.z, v.w};
+        uint32_t       so = st * SRE_FAST_ROW_BYTES, acc = 0;
+        for (uint32_t j = 0; j < 16 / stride; j++) {
+            uint32_t idx = 0;
+            for (uint32_t u = 0; u < stride; u++) {
+                const uint32_t b = j * stride + u;
+                const uint32_t c = (words[b >> 2] >> ((b & 3) * 8)) & 0xffu;
+                idx |= (bits == 8 ? c : (uint32_t) T->cls[c]) << (u * bits);
+            }
+            const uint32_t t = T->fast[(so >> 2) + idx];
+            acc |= t;
+            so = t & ~(SRE_FAST_ROW_BYTES - 1);
+        }
+        if (acc & SRE_FAST_SLOW) {
+            for (int b = 0; b < 16; b++) st = step(st, q + b);
+            return st;
+        }
+        return so / SRE_FAST_ROW_BYTES;
+    }
+
+    __device__ void load_segment(int64_t kq)
+    {
+        int64_t  lo = kq * (int64_t) seg_bytes, hi = lo + seg_bytes;
+        uint32_t cur;
+        if (hi > n) hi = n;
+        if (sp >= lo) {
+            lo = sp;
+            cur = init_state;
+        } else {
+            cur = sum[kq].s_in;
+        }
+        seg_lo = lo;
+        seg_hi = hi;
+        /* ck[i] = state before position c0 + 64 * i, c0 = lo rounded up to 64 */
+        const int64_t c0 = (lo + 63) & ~(int64_t) 63;
+        int64_t       q = lo;
+        const bool    aligned = (reinterpret_cast<uintptr_t>(data) & 15) == 0;
+        for (; q < c0 && q < hi; q++) cur = step(cur, q);
+        uint32_t i = 0;
+        while (q < hi) {
+            ck[i++] = (uint16_t) cur;
+            const int64_t stop = q + 64 < hi ? q + 64 : hi;
+            if (aligned && stop - q == 64) {
+                for (int g4 = 0; g4 < 4; g4++) cur = step16(cur, q + 16 * g4);
+                q = stop;
+            } else {
+                for (; q < stop; q++) cur = step(cur, q);
+            }
+        }
+        ck[i] = (uint16_t) cur;
+        blk_lo = 1;
+        blk_hi = 0;
+    }
 
     /* state before position q (sp <= q <= n) */
     __device__ uint32_t state_before(int64_t q)
     {
         if (q == sp) return init_state;
         if (q < blk_lo || q > blk_hi) {
-            const int64_t kq = (q - 1) / seg_bytes;
-            int64_t       lo = kq * (int64_t) seg_bytes, hi = lo + seg_bytes;
+            if (q <= seg_lo || q > seg_hi) load_segment((q - 1) / seg_bytes);
+            /* 64-byte block holding q - 1 and q */
+            const int64_t c0 = (seg_lo + 63) & ~(int64_t) 63;
+            int64_t       lo = (q - 1) & ~(int64_t) 63, hi;
             uint32_t      cur;
-            if (hi > n) hi = n;
-            if (sp >= lo) {
-                lo = sp;
-                cur = init_state;
+            if (lo < c0) {
+                /* in front of the first checkpoint: replay from the segment entry */
+                lo = seg_lo;
+                cur = (seg_lo == sp) ? init_state : sum[seg_lo / seg_bytes].s_in;
+                hi = c0 < seg_hi ? c0 : seg_hi;
             } else {
-                cur = sum[kq].s_in;
+                cur = ck[(lo - c0) / 64];
+                hi = lo + 64 < seg_hi ? lo + 64 : seg_hi;
             }
-            const uint32_t nsym = T->ncls + 1;
             for (int64_t x = lo; x < hi; x++) {
                 trace[x - lo] = (uint16_t) cur;
-                cur = T->trans[(size_t) cur * nsym + T->cls[data[x]]].next;
+                cur = step(cur, x);
             }
             trace[hi - lo] = (uint16_t) cur;
             blk_lo = lo;
@@ -872,7 +942,7 @@ sre_k_lineage_blocks(uint64_t nsegs, const sre_seg_lineage_t *__restrict__ maps,
     blocks[b] = out;
 }
 
-__global__ void
+__global__ __launch_bounds__(64) void
 sre_k_captures(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
                const sre_seg_summary_t *__restrict__ sum,
                sre_stream_status_t *__restrict__ status, uint16_t *__restrict__ scratch,
@@ -880,10 +950,33 @@ sre_k_captures(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
                const sre_seg_lineage_t *__restrict__ maps,
                const sre_seg_lineage_t *__restrict__ blocks, int use_maps)
 {
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    __shared__ sre_scan_tables_t Ts;
+    {
+        /* the walker's tables live in LDS: [fast][class map][transition records] */
+        uint32_t *fast = reinterpret_cast<uint32_t *>(lds);
+        uint8_t  *clsl = lds + tabp->fast_bytes;
+        uint8_t  *trl = clsl + 256;
+        const uint32_t tr_bytes = (tabp->nstates * (tabp->ncls + 1) + 3) * (uint32_t) sizeof(sre_dev_trans_t);
+        if (threadIdx.x == 0) {
+            Ts = *tabp;
+            Ts.fast = fast;
+            Ts.cls = clsl;
+            Ts.trans = reinterpret_cast<const sre_dev_trans_t *>(trl);
+        }
+        for (uint32_t i = threadIdx.x; i < tabp->fast_bytes / 16; i += blockDim.x) {
+            reinterpret_cast<uint4 *>(fast)[i] = reinterpret_cast<const uint4 *>(tabp->fast_plain)[i];
+        }
+        for (uint32_t i = threadIdx.x; i < tr_bytes / 8; i += blockDim.x) {
+            reinterpret_cast<uint64_t *>(trl)[i] = reinterpret_cast<const uint64_t *>(tabp->trans)[i];
+        }
+        for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) clsl[i] = tabp->cls[i];
+        __syncthreads();
+    }
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= G.nstreams) return;
     if (use_maps && !status[s].need_maps) return;   /* second pass: flagged streams only */
-    const sre_scan_tables_t   &T = *tabp;
+    const sre_scan_tables_t   &T = Ts;
     const sre_stream_status_t  st = status[s];
     int64_t                   *rec = records + (size_t) s * (2 + ovec_slots);
     const uint32_t             nsym = T.ncls + 1;
@@ -911,7 +1004,9 @@ sre_k_captures(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
     tr.sp = st.ev_sp;
     tr.seg_bytes = G.seg_bytes;
     tr.init_state = T.init[st.ev_sp == 0 ? 0 : 2];
-    tr.trace = scratch + (size_t) s * (G.seg_bytes + 16);
+    tr.ck = scratch + (size_t) s * (G.seg_bytes + 16);
+    tr.trace = tr.ck + G.seg_bytes / 64 + 4;
+    tr.seg_lo = tr.seg_hi = -1;
     tr.blk_lo = 1;
     tr.blk_hi = 0;
 
@@ -1091,10 +1186,11 @@ sre_launch_captures(const sre_scan_tables_t *d_tab, sre_scan_tables_t h_tab, sre
                     const sre_seg_lineage_t *d_maps, const sre_seg_lineage_t *d_blocks,
                     int use_maps, hipStream_t stream)
 {
-    (void) h_tab;
     if (geom.nstreams == 0) return hipSuccess;
     const uint32_t block = 64, grid = (geom.nstreams + block - 1) / block;
-    hipLaunchKernelGGL(sre_k_captures, dim3(grid), dim3(block), 0, stream, d_tab, geom, d_sum,
+    const size_t   shmem = (size_t) h_tab.fast_bytes + 256
+                         + ((size_t) h_tab.nstates * (h_tab.ncls + 1) + 3) * sizeof(sre_dev_trans_t);
+    hipLaunchKernelGGL(sre_k_captures, dim3(grid), dim3(block), shmem, stream, d_tab, geom, d_sum,
                        d_status, d_scratch, d_records, ovec_slots, d_maps, d_blocks, use_maps);
     return hipGetLastError();
 }

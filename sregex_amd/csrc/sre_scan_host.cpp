@@ -78,6 +78,7 @@ sre_scan_tables_build(const sre_program_t *prog, const sre_dfa_t *d, int mode, c
     h.stride = stride;
     h.class_bits = bits;
     h.warmup = 0;      /* the warm-up is one tile round, see sre_k_scan */
+    auto build_fast = [&](int fmode) {
     std::vector<uint32_t> fast((size_t) d->nstates * 256);
     for (uint32_t s = 0; s < d->nstates; s++) {
         for (unsigned idx = 0; idx < 256; idx++) {
@@ -90,7 +91,7 @@ sre_scan_tables_build(const sre_program_t *prog, const sre_dfa_t *d, int mode, c
                     break;
                 }
                 const sre_dfa_trans_t &tr = d->t(st, k);
-                if (mode == SRE_HIP_PIKE_COUNT && tr.ev_kind == SRE_DFA_EV_DONE
+                if (fmode == SRE_HIP_PIKE_COUNT && tr.ev_kind == SRE_DFA_EV_DONE
                     && tr.next == SRE_DFA_DEAD)
                 {
                     /* a non-empty match completes and nothing outlives it: the
@@ -112,6 +113,10 @@ sre_scan_tables_build(const sre_program_t *prog, const sre_dfa_t *d, int mode, c
                                            | (cnt << SRE_FAST_CNT_SHIFT) | (last << SRE_FAST_LAST_SHIFT);
         }
     }
+    return fast;
+    };
+    std::vector<uint32_t> fast = build_fast(mode);
+    std::vector<uint32_t> fast_plain = mode == SRE_HIP_PIKE_COUNT ? build_fast(SRE_HIP_PIKE_FIRST) : fast;
 
     std::vector<sre_dev_trans_t> trans(d->trans.size());
     for (size_t i = 0; i < d->trans.size(); i++) {
@@ -148,6 +153,7 @@ sre_scan_tables_build(const sre_program_t *prog, const sre_dfa_t *d, int mode, c
 
     hipError_t e;
     if ((e = upload(fast, &h.fast, t->owned)) != hipSuccess
+        || (e = upload(fast_plain, &h.fast_plain, t->owned)) != hipSuccess
         || (e = upload(cls, &h.cls, t->owned)) != hipSuccess
         || (e = upload(trans, &h.trans, t->owned)) != hipSuccess
         || (e = upload(d->lin_parent, &h.lin_parent, t->owned)) != hipSuccess
