@@ -81,6 +81,10 @@ typedef struct {
     /* SRE_SUM_LASTEV: FIRST: last match event seen here; COUNT: last completed match */
     uint32_t lm_state, lm_sym;
     int64_t  lm_pos, lm_sp;
+    /* a known state shortly before that event (start of its 64-byte round), so
+     * the capture walker need not replay the segment: -1 if none */
+    int64_t  lm_apos, pe_apos;
+    uint32_t lm_astate, pe_astate;
     int64_t  term_pos;      /* position where the scan of this stream ended, -1 none */
     int64_t  count;         /* COUNT: searches completed with a match in this segment */
     int64_t  cur_sp;        /* start of the search in flight at the segment end, -1 unknown */
@@ -112,6 +116,8 @@ typedef struct {
     int64_t  rc;            /* regex id / SRE_DECLINED / SRE_ERROR */
     int64_t  ev_pos, ev_sp;
     uint32_t ev_state, ev_sym;
+    int64_t  ev_apos;       /* anchor: a known state shortly before the event, -1 none */
+    uint32_t ev_astate, pad0;
     int64_t  ev_seg;        /* segment holding the event */
     int32_t  done;          /* 1: result final, 0: needs a fix-up round from first_bad */
     int32_t  error;         /* COUNT: the iteration ended with SRE_ERROR */

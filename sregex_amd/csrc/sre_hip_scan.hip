@@ -125,10 +125,15 @@ struct Walk {
     uint8_t  ev_kind;
     uint32_t ev_state, ev_sym;
     int64_t  ev_pos, ev_sp;
+    int64_t  ev_apos;                   /* anchor of that event: known state shortly before it */
+    uint32_t ev_astate;
     int64_t  cur_sp;                    /* start of the search in flight, -1 unknown */
+    int64_t  anchor_pos;                /* start of the tile round being processed and the */
+    uint32_t anchor_state;              /* state there (set by the kernel), -1 none */
     bool     lm_valid;                  /* FIRST: last event seen; COUNT: last completed match */
     uint32_t lm_state, lm_sym;
-    int64_t  lm_pos, lm_sp;
+    int64_t  lm_pos, lm_sp, lm_apos;
+    uint32_t lm_astate;
     int64_t  count;
     int64_t  term_pos;
     bool     finished, error, unresolved;
@@ -141,6 +146,8 @@ struct Walk {
         lm_sym = ev_sym;
         lm_pos = ev_pos;
         lm_sp = ev_sp;
+        lm_apos = ev_apos;
+        lm_astate = ev_astate;
         has_ev = false;
     }
 };
@@ -181,12 +188,25 @@ __device__ void slow_run(Walk &w, int64_t p, int64_t p_to, bool warm, uint32_t w
             w.ev_sym = sym;
             w.ev_pos = p;
             w.ev_sp = w.cur_sp;
+            /* the round's entry state is a usable anchor if it belongs to this
+             * same search and lies at most one round in front of the event */
+            if (w.anchor_pos >= 0 && w.anchor_pos <= p && p - w.anchor_pos <= 256
+                && (w.cur_sp < 0 || w.anchor_pos >= w.cur_sp))
+            {
+                w.ev_apos = w.anchor_pos;
+                w.ev_astate = w.anchor_state;
+            } else {
+                w.ev_apos = -1;
+                w.ev_astate = 0;
+            }
             if (MODE != SRE_HIP_PIKE_COUNT && !warm) {
                 w.lm_valid = true;
                 w.lm_state = w.st;
                 w.lm_sym = sym;
                 w.lm_pos = p;
                 w.lm_sp = w.cur_sp;
+                w.lm_apos = w.ev_apos;
+                w.lm_astate = w.ev_astate;
             }
         }
         w.st = tr.next;
@@ -235,6 +255,7 @@ __device__ void slow_run(Walk &w, int64_t p, int64_t p_to, bool warm, uint32_t w
             }
             w.st = T.init[2];
             p = w.cur_sp;
+            w.anchor_pos = -1;      /* the round's entry state belonged to the previous search */
         }
     }
 }
@@ -267,6 +288,8 @@ __device__ void resolve_fast_group(Walk &w, int64_t gpos, uint32_t s0, int64_t s
         w.lm_state = last_state;
         w.lm_sym = last_sym;
         w.lm_sp = last_sp;
+        w.lm_apos = -1;
+        w.lm_astate = 0;
     }
     w.cur_sp = sp;
 }
@@ -386,10 +409,15 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
     w.ev_kind = 0;
     w.ev_state = w.ev_sym = 0;
     w.ev_pos = w.ev_sp = -1;
+    w.ev_apos = -1;
+    w.ev_astate = 0;
     w.cur_sp = -1;
+    w.anchor_pos = -1;
+    w.anchor_state = 0;
     w.lm_valid = false;
     w.lm_state = w.lm_sym = 0;
-    w.lm_pos = w.lm_sp = -1;
+    w.lm_pos = w.lm_sp = w.lm_apos = -1;
+    w.lm_astate = 0;
     w.count = 0;
     w.term_pos = -1;
     w.finished = w.error = w.unresolved = false;
@@ -423,6 +451,8 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
                 w.ev_sym = c.pe_sym;
                 w.ev_pos = c.pe_pos;
                 w.ev_sp = c.pe_sp;
+                w.ev_apos = c.pe_apos;
+                w.ev_astate = c.pe_astate;
                 w.ev_kind = T.trans[(size_t) c.pe_state * (T.ncls + 1) + c.pe_sym].kind;
             }
         } else {
@@ -468,6 +498,8 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
         if (!active || w.finished || (warm_round && !warm)) continue;
         const int64_t base = seg_a + ((int64_t) r - 1) * TILE;
         if (base >= seg_b) continue;
+        w.anchor_pos = warm_round ? -1 : base;
+        w.anchor_state = w.st;
 
         for (uint32_t q = 0; q < TILE / 16; q++) {
             const int64_t gp = base + q * 16;
@@ -539,6 +571,7 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
     /* the lane that owns the end of the stream performs the EOF step(s) */
     if (last_seg && !w.finished) {
         const int64_t before = w.count;
+        w.anchor_pos = -1;
         slow_run<MODE>(w, w.n, w.n + 1, false, 0);
         if (w.count != before) fc_pending = false;
     }
@@ -569,6 +602,10 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
     out.lm_sym = w.lm_sym;
     out.lm_pos = w.lm_pos;
     out.lm_sp = w.lm_sp;
+    out.lm_apos = w.lm_apos;
+    out.lm_astate = w.lm_astate;
+    out.pe_apos = w.ev_apos;
+    out.pe_astate = w.ev_astate;
     sum[g] = out;
 }
 
@@ -677,9 +714,14 @@ sre_k_verify_c(sre_scan_tables_t T, sre_scan_geom_t G, const sre_seg_summary_t *
     st.rc = RC_DECLINED;
     st.ev_pos = st.ev_sp = -1;
     st.ev_state = st.ev_sym = 0;
+    st.ev_apos = -1;
+    st.ev_astate = 0;
+    st.pad0 = 0;
     st.ev_seg = -1;
     if (done && evseg > 0) {
         const sre_seg_summary_t &c = sum[first + evseg - 1];
+        st.ev_apos = c.lm_apos;
+        st.ev_astate = c.lm_astate;
         st.ev_state = c.lm_state;
         st.ev_sym = c.lm_sym;
         st.ev_pos = c.lm_pos;
@@ -730,6 +772,8 @@ struct Tracer {
     const uint8_t           *data;
     int64_t                  n, sp;
     uint32_t                 seg_bytes, init_state;
+    int64_t                  apos;      /* anchor: state `astate` holds before position apos (-1 none) */
+    uint32_t                 astate;
     uint16_t                *ck;        /* checkpoint states of the loaded segment, every 64 bytes */
     uint16_t                *trace;     /* states before each position of the loaded 64-byte block */
     int64_t                  seg_lo, seg_hi;    /* loaded segment: [seg_lo, seg_hi], -1 none */
@@ -766,11 +810,13 @@ struct Tracer {
         return so / SRE_FAST_ROW_BYTES;
     }
 
-    __device__ void load_segment(int64_t kq)
+    /* checkpoint segment kq up to (and including the block of) position upto */
+    __device__ void load_segment(int64_t kq, int64_t upto)
     {
         int64_t  lo = kq * (int64_t) seg_bytes, hi = lo + seg_bytes;
         uint32_t cur;
         if (hi > n) hi = n;
+        if (((upto + 64) & ~(int64_t) 63) < hi) hi = (upto + 64) & ~(int64_t) 63;
         if (sp >= lo) {
             lo = sp;
             cur = init_state;
@@ -804,8 +850,20 @@ struct Tracer {
     __device__ uint32_t state_before(int64_t q)
     {
         if (q == sp) return init_state;
+        if ((q < blk_lo || q > blk_hi) && apos >= 0 && q > apos && q <= apos + 64) {
+            /* the block right behind the anchor: no segment replay needed */
+            int64_t  hi = apos + 64 < n ? apos + 64 : n;
+            uint32_t cur = astate;
+            for (int64_t x = apos; x < hi; x++) {
+                trace[x - apos] = (uint16_t) cur;
+                cur = step(cur, x);
+            }
+            trace[hi - apos] = (uint16_t) cur;
+            blk_lo = apos;
+            blk_hi = hi;
+        }
         if (q < blk_lo || q > blk_hi) {
-            if (q <= seg_lo || q > seg_hi) load_segment((q - 1) / seg_bytes);
+            if (q <= seg_lo || q > seg_hi) load_segment((q - 1) / seg_bytes, q);
             /* 64-byte block holding q - 1 and q */
             const int64_t c0 = (seg_lo + 63) & ~(int64_t) 63;
             int64_t       lo = (q - 1) & ~(int64_t) 63, hi;
@@ -1004,6 +1062,8 @@ sre_k_captures(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
     tr.sp = st.ev_sp;
     tr.seg_bytes = G.seg_bytes;
     tr.init_state = T.init[st.ev_sp == 0 ? 0 : 2];
+    tr.apos = (st.ev_apos >= st.ev_sp) ? st.ev_apos : -1;
+    tr.astate = st.ev_astate;
     tr.ck = scratch + (size_t) s * (G.seg_bytes + 16);
     tr.trace = tr.ck + G.seg_bytes / 64 + 4;
     tr.seg_lo = tr.seg_hi = -1;
