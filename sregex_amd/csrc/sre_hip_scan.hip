@@ -115,6 +115,17 @@ namespace {
 
 
 
+__device__ inline uint32_t
+stream_of(const sre_scan_geom_t &G, uint64_t g)
+{
+    uint32_t a = 0, b = G.nstreams;
+    while (b - a > 1) {
+        uint32_t m = (a + b) >> 1;
+        if (G.seg_first[m] <= g) a = m; else b = m;
+    }
+    return a;
+}
+
 /* the search a lane is currently following */
 struct Walk {
     const sre_scan_tables_t *T;
@@ -305,10 +316,13 @@ __device__ inline void
 tile_fetch(uint4 (&regs)[TILE / 16], const uint8_t *const *row_ptr, const int32_t *row_lo,
            const int32_t *row_hi, uint32_t tid, uint32_t r)
 {
+    /* wave-private staging: the 64 lanes of a wave fetch the 64 rows of that
+     * same wave, so no workgroup barrier is needed between rounds */
+    const uint32_t wbase = tid & ~63u, lane = tid & 63u;
 #pragma unroll
     for (uint32_t i = 0; i < TILE / 16; i++) {
-        const uint32_t piece = i * SRE_SCAN_BLOCK + tid;
-        const uint32_t row = piece / (TILE / 16), col = piece % (TILE / 16);
+        const uint32_t piece = i * 64 + lane;
+        const uint32_t row = wbase + piece / (TILE / 16), col = piece % (TILE / 16);
         const int32_t  off = (int32_t) (r * TILE + col * 16);
         uint4          v = make_uint4(0, 0, 0, 0);
         if (off >= row_lo[row] && off + 16 <= row_hi[row]) {
@@ -332,10 +346,11 @@ template <int TILE>
 __device__ inline void
 tile_store(const uint4 (&regs)[TILE / 16], uint8_t *tile, uint32_t tid)
 {
+    const uint32_t wbase = tid & ~63u, lane = tid & 63u;
 #pragma unroll
     for (uint32_t i = 0; i < TILE / 16; i++) {
-        const uint32_t piece = i * SRE_SCAN_BLOCK + tid;
-        const uint32_t row = piece / (TILE / 16), col = piece % (TILE / 16);
+        const uint32_t piece = i * 64 + lane;
+        const uint32_t row = wbase + piece / (TILE / 16), col = piece % (TILE / 16);
         *reinterpret_cast<uint4 *>(tile + row * (TILE + 16) + col * 16) = regs[i];
     }
 }
@@ -365,7 +380,7 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
     uint8_t  *trl = clsl + 256;
     const uint32_t tr_bytes = tabp->nstates * (tabp->ncls + 1) * (uint32_t) sizeof(sre_dev_trans_t);
     uint8_t  *sfl = trl + tr_bytes;
-    uint8_t  *tile = sfl + ((tabp->nstates + 15u) & ~15u);
+    uint8_t  *tile = lds + (((size_t) (sfl - lds) + tabp->nstates + 15u) & ~(size_t) 15u);
     if (tid == 0) {
         Ts = *tabp;
         /* the exact path reads its tables from LDS too */
@@ -488,9 +503,13 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
     __syncthreads();                        /* row tables are complete */
     tile_fetch<TILE>(regs, row_ptr, row_lo, row_hi, tid, 0);
     for (uint32_t r = 0; r < nrounds; r++) {
-        __syncthreads();                    /* everybody is done with the previous tile */
+        /* LDS operations of one wave execute in order; the fences only stop the
+         * compiler from moving tile reads across the stores */
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         tile_store<TILE>(regs, tile, tid);
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         /* next round's HBM loads fly while this round is consumed from LDS */
         if (r + 1 < nrounds) tile_fetch<TILE>(regs, row_ptr, row_lo, row_hi, tid, r + 1);
 
@@ -623,17 +642,6 @@ struct VerifyAcc {
     unsigned long long bad, end;        /* init ~0 */
     unsigned long long count, evseg, spseg;     /* init 0 */
 };
-
-__device__ inline uint32_t
-stream_of(const sre_scan_geom_t &G, uint64_t g)
-{
-    uint32_t a = 0, b = G.nstreams;
-    while (b - a > 1) {
-        uint32_t m = (a + b) >> 1;
-        if (G.seg_first[m] <= g) a = m; else b = m;
-    }
-    return a;
-}
 
 __global__ __launch_bounds__(256) void
 sre_k_verify_a(sre_scan_geom_t G, const sre_seg_summary_t *__restrict__ sum, VerifyAcc *__restrict__ acc)
@@ -1193,7 +1201,7 @@ extern "C" size_t
 sre_scan_lds_bytes(const sre_scan_tables_t *h_tab, uint32_t tile)
 {
     const size_t tr = (size_t) h_tab->nstates * (h_tab->ncls + 1) * sizeof(sre_dev_trans_t);
-    return (size_t) h_tab->fast_bytes + 256 + tr + ((h_tab->nstates + 15u) & ~15u)
+    return (size_t) h_tab->fast_bytes + 256 + tr + ((h_tab->nstates + 15u) & ~15u) + 16
            + (size_t) SRE_SCAN_BLOCK * (tile + 16);
 }
 
