@@ -49,6 +49,7 @@ struct sre_hip_scanner_s {
     sre_seg_lineage_t        *d_maps, *d_blocks;
     size_t                    maps_cap;
     int                       lineage_passes;   /* of the last scan (diagnostics) */
+    uint32_t                  next_init_variant;    /* compat path: a re-armed context's search */
     int                       fixup_rounds;     /* of the last scan (diagnostics) */
     hipEvent_t                ev0, ev1;         /* around the dominant scan kernel */
     int                       ev_valid;
@@ -258,7 +259,6 @@ scan_geometry(sre_hip_scanner_t *sc, size_t nstreams)
     }
     if (seg != 0 && seg % tile != 0) tile = 64;
     sc->geom.tile = tile;
-    sc->geom.pad = 0;
     if (seg == 0) {
         size_t   lds = sre_scan_lds_bytes(&sc->tab->h, tile) + 4352;
         uint64_t per_cu = (160u * 1024u) / lds;
@@ -314,6 +314,8 @@ sre_hip_scan_enqueue(sre_hip_scanner_t *sc, const void *const *d_streams, const 
     sc->fixup_rounds = 0;
     sc->lineage_passes = 0;
     sc->ev_valid = 0;
+    sc->geom.init_variant = sc->next_init_variant;
+    sc->next_init_variant = 0;
     if (nstreams == 0) {
         sc->last_n = 0;
         return 0;
@@ -437,6 +439,23 @@ sre_hip_scan_batch(sre_hip_scanner_t *sc, const void *const *d_streams, const si
 {
     if (sre_hip_scan_enqueue(sc, d_streams, lens, nstreams, hip_stream) != 0) return -1;
     return sre_hip_scan_results(sc, results);
+}
+
+/* One device-resident buffer through the scanner, for sre_vm_*_exec on large
+ * whole-buffer calls.  `init_variant` is the SRE_DFA_INIT_* of a search on a
+ * re-armed context; *poisoned reports the "threads still listed at eof" state
+ * (sre_vm_pike.c:616-622). */
+extern "C" int
+sre_hip_scan_one(sre_hip_scanner_t *sc, const void *d_buf, size_t len, int init_variant,
+    sre_int_t *rec, int *poisoned, hipStream_t stream)
+{
+    const void *ptrs[1] = {d_buf};
+    size_t      lens[1] = {len};
+    sc->next_init_variant = (uint32_t) init_variant;
+    if (sre_hip_scan_enqueue(sc, ptrs, lens, 1, stream) != 0) return -1;
+    if (sre_hip_scan_results(sc, rec) != 0) return -1;
+    if (poisoned) *poisoned = sc->engine == SRE_HIP_ENGINE_SCAN ? sc->h_status[0].error : 0;
+    return 0;
 }
 
 /* ------------------------------------------------------------------ helpers */

@@ -75,7 +75,17 @@ typedef struct {
     void          *ctx;         /* device stream state, see sre_hip_vm.hip     */
     void          *result;      /* sre_dev_result_t + ovector, host-visible    */
     uint64_t       ovec_slots;  /* caller ovector length in slots              */
+    /* state of a context whose previous searches ran on the scanner: applied
+     * when the VM kernel first touches the (still zero-filled) device context */
+    int64_t        preset_processed;
+    uint32_t       preset_valid;
+    uint32_t       preset_flags;    /* SRE_PRESET_* */
 } sre_dev_req_t;
+
+#define SRE_PRESET_EMPTY_CAPTURE 1u
+#define SRE_PRESET_SEEN_NEWLINE  2u
+#define SRE_PRESET_SEEN_WORD     4u
+#define SRE_PRESET_EOF           8u
 
 typedef struct {
     int64_t   rc;               /* regex id >= 0, SRE_AGAIN, SRE_DECLINED, SRE_ERROR */

@@ -183,8 +183,14 @@ __device__ void slow_run(Walk &w, int64_t p, int64_t p_to, bool warm, uint32_t w
              * still listed, which poisons the context (sre_vm_pike.c:304-306,
              * 616-622): a pending match is returned, the next exec fails */
             w.term_pos = p;
-            if (MODE == SRE_HIP_PIKE_COUNT && w.has_ev) {
-                w.complete_match();
+            if (MODE == SRE_HIP_PIKE_COUNT) {
+                if (w.has_ev) {
+                    w.complete_match();
+                    w.error = true;
+                }
+            } else if (w.has_ev || (T.state_flags[w.st] & 1)) {
+                /* a speculative lane may not have seen the event itself; the
+                 * state says that a match is pending */
                 w.error = true;
             }
             w.finished = true;
@@ -453,7 +459,7 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
         if (seg_b > w.n) seg_b = w.n;
 
         if (k == 0) {
-            w.st = T.init[0];
+            w.st = T.init[G.init_variant];
             w.cur_sp = 0;
         } else if (lo != nullptr && (int64_t) k == lo[sidx]) {
             /* exact carry from the verified predecessor */
@@ -947,7 +953,7 @@ sre_k_lineage_maps(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G
     if (k == st.ev_seg && st.ev_pos < hi) hi = st.ev_pos;      /* list at the event position */
     if (sp >= lo) {
         lo = sp;
-        cur = T.init[sp == 0 ? 0 : 2];
+        cur = T.init[sp == 0 ? G.init_variant : 2];
     }
 
     uint64_t anc = 0xfedcba9876543210ull;       /* identity */
@@ -1055,7 +1061,7 @@ sre_k_captures(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
         rec[0] = RC_ERROR;
         return;
     }
-    if (st.error) rec[0] = RC_ERROR;         /* the iteration ended with SRE_ERROR */
+    if (st.error && T.mode == SRE_HIP_PIKE_COUNT) rec[0] = RC_ERROR;   /* iteration ended with SRE_ERROR */
     if (st.ev_pos < 0) return;
     if (T.mode == 0) {
         rec[0] = 0;                          /* Thompson: SRE_OK, no captures */
@@ -1069,7 +1075,7 @@ sre_k_captures(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
     tr.n = (int64_t) G.lens[s];
     tr.sp = st.ev_sp;
     tr.seg_bytes = G.seg_bytes;
-    tr.init_state = T.init[st.ev_sp == 0 ? 0 : 2];
+    tr.init_state = T.init[st.ev_sp == 0 ? G.init_variant : 2];
     tr.apos = (st.ev_apos >= st.ev_sp) ? st.ev_apos : -1;
     tr.astate = st.ev_astate;
     tr.ck = scratch + (size_t) s * (G.seg_bytes + 16);
@@ -1132,7 +1138,7 @@ sre_k_captures(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
         const sre_dev_trans_t *t;
         int64_t                val;
         if (p == tr.sp) {
-            t = &T.trans[(size_t) T.nstates * nsym + (tr.sp == 0 ? 0 : 2)];   /* initial closure */
+            t = &T.trans[(size_t) T.nstates * nsym + (tr.sp == 0 ? G.init_variant : 2)];   /* initial closure */
             val = tr.sp;
         } else {
             t = &T.trans[(size_t) tr.state_before(p - 1) * nsym + T.cls[tr.data[p - 1]]];
@@ -1154,7 +1160,7 @@ sre_k_captures(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
     ofs *= 2;
     const uint64_t ncopy = 2ull * (T.multi_ncaps[st.rc] + 1);
     for (uint64_t q = 0; q < ovec_slots; q++) rec[2 + q] = q < ncopy ? vec[ofs + q] : -1;
-    rec[0] = st.error ? RC_ERROR : st.rc;
+    rec[0] = (st.error && T.mode == SRE_HIP_PIKE_COUNT) ? RC_ERROR : st.rc;
 }
 
 }  // namespace

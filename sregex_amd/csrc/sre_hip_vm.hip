@@ -366,9 +366,11 @@ struct Pike {
     }
 
     __device__ int64_t exec(uint64_t size, unsigned eof, bool want_pending,
-                            sre_dev_result_t *res, int64_t *ov, uint64_t ovec_slots)
+                            sre_dev_result_t *res, int64_t *ov, uint64_t ovec_slots,
+                            const sre_dev_req_t *preset = nullptr)
     {
-        if (h->magic != PIKE_MAGIC) {
+        const bool fresh = (h->magic != PIKE_MAGIC);
+        if (fresh) {
             /* fresh (zero-filled) context: sre_vm_pike.c:94-145 */
             h->magic = PIKE_MAGIC;
             h->processed_bytes = 0;
@@ -382,6 +384,14 @@ struct Pike {
             h->initial_count = 0;
             list_reset(0);
             list_reset(1);
+            if (preset && preset->preset_valid) {
+                /* earlier searches of this context ran on the scanner */
+                h->processed_bytes = preset->preset_processed;
+                h->empty_capture = (preset->preset_flags & SRE_PRESET_EMPTY_CAPTURE) ? 1 : 0;
+                h->seen_newline = (preset->preset_flags & SRE_PRESET_SEEN_NEWLINE) ? 1 : 0;
+                h->seen_word = (preset->preset_flags & SRE_PRESET_SEEN_WORD) ? 1 : 0;
+                h->eof = (preset->preset_flags & SRE_PRESET_EOF) ? 1 : 0;
+            }
         }
 
         res->has_pending = 0;
@@ -724,7 +734,7 @@ sre_k_pike_exec(const uint8_t *__restrict__ blob, const sre_dev_req_t *__restric
 
     sre_dev_result_t *res = static_cast<sre_dev_result_t *>(rq.result);
     int64_t          *ov = reinterpret_cast<int64_t *>(res + 1);
-    res->rc = vm.exec(rq.size, rq.eof, rq.want_pending != 0, res, ov, rq.ovec_slots);
+    res->rc = vm.exec(rq.size, rq.eof, rq.want_pending != 0, res, ov, rq.ovec_slots, &rq);
 }
 
 extern "C" __global__ void

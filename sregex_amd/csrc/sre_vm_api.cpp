@@ -17,9 +17,18 @@
  * returns SRE_ERROR after a diagnostic on stderr.
  */
 #include "sre_hip_runtime.h"
+#include <sregex_hip.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+
+/* sre_hip_batch.cpp */
+extern "C" int sre_hip_scan_one(sre_hip_scanner_t *sc, const void *d_buf, size_t len,
+    int init_variant, sre_int_t *rec, int *poisoned, hipStream_t stream);
+
+/* whole-buffer calls at least this long go through the table-driven scanner
+ * when the program admits one; shorter ones are cheaper on the VM kernel */
+#define SRE_COMPAT_SCAN_MIN_BYTES  (32u * 1024u)
 
 namespace {
 
@@ -40,6 +49,9 @@ struct DeviceStream {
     HostBlock         *d_blk;       /* device alias of h_blk */
     hipStream_t        stream;
     int                failed;
+    /* context state accumulated while its searches ran on the scanner */
+    uint32_t           preset_valid, preset_flags;
+    int64_t            preset_processed;
 };
 
 void
@@ -95,6 +107,9 @@ device_stream_exec(DeviceStream *ds, const sre_char *input, size_t len, unsigned
     rq->ovec_slots = ovec_slots;
     rq->input = NULL;
     rq->inline_bytes = 0;
+    rq->preset_valid = ds->preset_valid;
+    rq->preset_processed = ds->preset_processed;
+    rq->preset_flags = ds->preset_flags;
     if (len > 0 && len <= 8) {
         memcpy(&rq->inline_bytes, input, len);
     } else if (len > 8) {
@@ -131,7 +146,93 @@ struct sre_vm_pike_ctx_s {
     size_t         ovec_slots;
     sre_int_t      pending[2];
     DeviceStream  *ds;
+    /* host shadow of the context between searches (sre_vm_pike.c:47-76): valid
+     * while the device context has not been touched by the VM kernel */
+    int            at_boundary;     /* no search in flight on the device context */
+    int            vm_touched;      /* the VM kernel owns the state from now on */
+    int            eof, empty_capture, seen_newline, seen_word;
+    sre_int_t      processed_bytes;
+    sre_hip_scanner_t *scanner;     /* lazily created, NULL if the program is not admitted */
+    int            scanner_tried;
+    sre_int_t     *rec;
 };
+
+static int
+pike_scan_route(sre_vm_pike_ctx_t *ctx, sre_char *input, size_t len, sre_int_t *prc)
+{
+    /* one reference exec() of a context that sits between two searches, on a
+     * whole buffer (eof): sre_vm_pike.c:165-233 prologue, scan, :586-636 epilogue */
+    if (ctx->eof) {
+        *prc = SRE_ERROR;                                   /* :165-168 */
+        return 1;
+    }
+    if (!ctx->scanner_tried) {
+        ctx->scanner_tried = 1;
+        ctx->scanner = sre_hip_scanner_create(ctx->pool, ctx->prog, SRE_HIP_PIKE_FIRST, SRE_HIP_ENGINE_AUTO);
+        if (ctx->scanner && sre_hip_scanner_engine(ctx->scanner) != SRE_HIP_ENGINE_SCAN) ctx->scanner = NULL;
+        if (ctx->scanner) {
+            ctx->rec = static_cast<sre_int_t *>(
+                sre_palloc(ctx->pool, sre_hip_scanner_result_slots(ctx->scanner) * sizeof(sre_int_t)));
+            if (ctx->rec == NULL) ctx->scanner = NULL;
+        }
+    }
+    if (ctx->scanner == NULL) return 0;
+
+    size_t skip = 0;
+    int    variant;
+    if (ctx->empty_capture) {                               /* :179-196 */
+        skip = 1;
+        variant = input[0] == '\n' ? 1 : 2;
+    } else if (ctx->processed_bytes == 0) {
+        variant = 0;
+    } else {
+        variant = ctx->seen_newline ? 1 : 2;
+    }
+
+    DeviceStream *ds = ctx->ds;
+    if (len > ds->in_cap) {
+        if (ds->d_in) (void) hipFree(ds->d_in);
+        ds->d_in = NULL;
+        ds->in_cap = 0;
+        if (hipMalloc(&ds->d_in, len + 4096) != hipSuccess) return 0;
+        ds->in_cap = len + 4096;
+    }
+    if (hipMemcpyAsync(ds->d_in, input, len, hipMemcpyHostToDevice, ds->stream) != hipSuccess) return 0;
+    int poisoned = 0;
+    if (sre_hip_scan_one(ctx->scanner, static_cast<const uint8_t *>(ds->d_in) + skip, len - skip,
+                         variant, ctx->rec, &poisoned, ds->stream) != 0)
+    {
+        *prc = SRE_ERROR;
+        return 1;
+    }
+    ctx->empty_capture = 0;
+    const sre_int_t rc = ctx->rec[0];
+    if (rc < 0) {                                           /* no match at eof: :660-666 */
+        ctx->eof = 1;
+        *prc = rc == SRE_DECLINED ? SRE_DECLINED : SRE_ERROR;
+        return 1;
+    }
+    /* buffer-relative offsets -> absolute (sre_vm_pike.c:826-828) */
+    const sre_int_t base = ctx->processed_bytes + (sre_int_t) skip;
+    const size_t have = sre_hip_scanner_result_slots(ctx->scanner) - 2;
+    for (size_t k = 0; k < ctx->ovec_slots; k++) {
+        sre_int_t v = k < have ? ctx->rec[2 + k] : -1;
+        ctx->ovector[k] = v < 0 ? -1 : v + base;
+    }
+    /* :586-601 — only a match of regex 0 carries slot 1 */
+    if (rc == 0) {
+        const sre_int_t p = ctx->ovector[1] - ctx->processed_bytes;     /* chunk-relative end */
+        if (p > 0) {
+            ctx->seen_newline = input[p - 1] == '\n';
+            ctx->seen_word = sre_isword(input[p - 1]);
+        }
+    }
+    if (poisoned) ctx->eof = 1;                              /* :616-622 */
+    ctx->processed_bytes = ctx->ovector[1];                  /* :624-628 */
+    ctx->empty_capture = (ctx->ovector[0] == ctx->ovector[1]);
+    *prc = rc;
+    return 1;
+}
 
 extern "C" SRE_API sre_vm_pike_ctx_t *
 sre_vm_pike_create_ctx(sre_pool_t *pool, sre_program_t *prog, sre_int_t *ovector,
@@ -145,6 +246,7 @@ sre_vm_pike_create_ctx(sre_pool_t *pool, sre_program_t *prog, sre_int_t *ovector
     ctx->ovector = ovector;
     ctx->ovec_slots = ovecsize / sizeof(sre_int_t);
     ctx->ds = NULL;     /* device state is opened by the first exec() */
+    ctx->at_boundary = 1;
     return ctx;
 }
 
@@ -161,6 +263,27 @@ sre_vm_pike_exec(sre_vm_pike_ctx_t *ctx, sre_char *input, size_t len, unsigned e
     DeviceStream *ds = ctx->ds;
     if (ds->failed) return SRE_ERROR;
 
+    /* large whole-buffer call on a context that sits between two searches: the
+     * table-driven scanner does it at device speed; the context's state stays
+     * on the host until the VM kernel is needed */
+    if (!ctx->vm_touched && ctx->at_boundary && eof && len >= SRE_COMPAT_SCAN_MIN_BYTES
+        && ctx->ovec_slots >= 2)
+    {
+        sre_int_t rc;
+        if (pike_scan_route(ctx, input, len, &rc)) return rc;
+    }
+    if (!ctx->vm_touched) {
+        ctx->vm_touched = 1;
+        if (ctx->processed_bytes || ctx->eof || ctx->empty_capture || ctx->seen_newline || ctx->seen_word) {
+            ds->preset_valid = 1;
+            ds->preset_processed = ctx->processed_bytes;
+            ds->preset_flags = (ctx->empty_capture ? SRE_PRESET_EMPTY_CAPTURE : 0)
+                               | (ctx->seen_newline ? SRE_PRESET_SEEN_NEWLINE : 0)
+                               | (ctx->seen_word ? SRE_PRESET_SEEN_WORD : 0)
+                               | (ctx->eof ? SRE_PRESET_EOF : 0);
+        }
+    }
+
     if (device_stream_exec(ds, input, len, eof, pending_matched ? 1u : 0u, ctx->ovec_slots,
                            sre_launch_pike_exec) != 0)
     {
@@ -169,6 +292,7 @@ sre_vm_pike_exec(sre_vm_pike_ctx_t *ctx, sre_char *input, size_t len, unsigned e
 
     const sre_dev_result_t *res = &ds->h_blk->res;
     sre_int_t               rc = (sre_int_t) res->rc;
+    ctx->at_boundary = 0;       /* from here on the device context is authoritative */
 
     if (rc >= 0) {
         /* complete match: the whole caller ovector is defined (reference
@@ -198,6 +322,9 @@ struct sre_vm_thompson_ctx_s {
     sre_pool_t    *pool;
     sre_program_t *prog;
     DeviceStream  *ds;
+    int            started;
+    sre_hip_scanner_t *scanner;
+    int            scanner_tried;
 };
 
 extern "C" SRE_API sre_vm_thompson_ctx_t *
@@ -221,6 +348,35 @@ sre_vm_thompson_exec(sre_vm_thompson_ctx_t *ctx, sre_char *input, size_t len, un
         if (ctx->ds == NULL) return SRE_ERROR;
     }
     if (ctx->ds->failed) return SRE_ERROR;
+    if (!ctx->started && eof && len >= SRE_COMPAT_SCAN_MIN_BYTES) {
+        /* first and only chunk of a large stream: match / no match from the scanner */
+        if (!ctx->scanner_tried) {
+            ctx->scanner_tried = 1;
+            ctx->scanner = sre_hip_scanner_create(ctx->pool, ctx->prog, SRE_HIP_THOMPSON, SRE_HIP_ENGINE_AUTO);
+            if (ctx->scanner && sre_hip_scanner_engine(ctx->scanner) != SRE_HIP_ENGINE_SCAN) ctx->scanner = NULL;
+        }
+        DeviceStream *ds = ctx->ds;
+        if (ctx->scanner) {
+            if (len > ds->in_cap) {
+                if (ds->d_in) (void) hipFree(ds->d_in);
+                ds->d_in = NULL;
+                ds->in_cap = 0;
+                if (hipMalloc(&ds->d_in, len + 4096) == hipSuccess) ds->in_cap = len + 4096;
+            }
+            sre_int_t *rec = static_cast<sre_int_t *>(
+                sre_palloc(ctx->pool, sre_hip_scanner_result_slots(ctx->scanner) * sizeof(sre_int_t)));
+            if (rec == NULL) return SRE_ERROR;
+            rec[0] = SRE_ERROR;
+            if (ds->in_cap >= len
+                && hipMemcpyAsync(ds->d_in, input, len, hipMemcpyHostToDevice, ds->stream) == hipSuccess
+                && sre_hip_scan_one(ctx->scanner, ds->d_in, len, 0, rec, NULL, ds->stream) == 0)
+            {
+                ctx->started = 1;
+                return rec[0] == SRE_OK ? SRE_OK : (rec[0] == SRE_DECLINED ? SRE_DECLINED : SRE_ERROR);
+            }
+        }
+    }
+    ctx->started = 1;
     if (device_stream_exec(ctx->ds, input, len, eof, 0, 0, sre_launch_thompson_exec) != 0) {
         return SRE_ERROR;
     }

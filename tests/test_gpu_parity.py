@@ -273,3 +273,44 @@ def test_scanner_long_lineage_uses_ancestor_maps(gpu, seg):
             assert sc2.scan([buf.ptr], [len(data)])[0] == cnt, (pats, seg)
             buf.free()
             other.free()
+
+
+def test_compat_api_large_buffers_take_the_scanner(gpu):
+    """sre_vm_pike_exec / sre_vm_thompson_exec on large whole buffers (what the
+    reference's bench/sregex.c does): routed through the scanner, same answers
+    as the reference; the find-all iteration keeps working on the same context,
+    including the hand-over to the VM kernel for the short remainder."""
+    ora = harness.OracleEngine()
+    eng = harness.ProductEngine()
+    for rec in harness.load_jsonl("gen_data.jsonl"):
+        if rec["n"] < 60000:
+            continue
+        pats = [bytes.fromhex(h) for h in rec["re"]]
+        data = S.gen_data_host(rec["n"], bytes.fromhex(rec["tail"]))
+        with S.Pool() as pool:
+            prog = S.compile(pool, S.parse(pool, pats))
+            t = eng.thompson(prog)
+            assert t.exec(data, True) == rec["thompson"], (rec["cfg"], rec["n"])
+            p = eng.pike(prog, rec["ncaps"])
+            rc = p.exec(data, True, want_pending=False)
+            assert rc == rec["pike_rc"], (rec["cfg"], rec["n"], rc)
+            if rc >= 0:
+                assert list(p.ovector) == rec["pike_ov"], (rec["cfg"], rec["n"])
+            eng.recycle()
+    # iteration: many matches spread over a large buffer, empty matches, ^ after newline
+    chunk = S.gen_data_host(50000, b" bob@example.com\n")
+    cases = [
+        ([rb"([a-z]+)@([a-z]+)\.[a-z]+"], chunk * 4 + b"x@y.z"),
+        ([rb"^abc"], (b"abccc" * 9000 + b"\n") * 3),
+        ([rb"x*"], b"ab" * 20000),
+        ([rb"(a+)(b+)?"], b"b a\nca" + b" " * 40000 + b"a\nc" + b"." * 40000),
+    ]
+    for pats, data in cases:
+        with S.Pool() as pool:
+            re = S.parse(pool, pats)
+            prog = S.compile(pool, re)
+            limit = 200
+            want = harness.findall(ora, prog, re.ncaps, data, limit)
+            got = harness.findall(eng, prog, re.ncaps, data, limit)
+            assert got == want, (pats, got[:3], want[:3], len(got), len(want))
+            eng.recycle()
