@@ -50,6 +50,7 @@ struct sre_hip_scanner_s {
     size_t                    maps_cap;
     int                       lineage_passes;   /* of the last scan (diagnostics) */
     uint32_t                  next_init_variant;    /* compat path: a re-armed context's search */
+    int                       blocks_per_cu;
     int                       fixup_rounds;     /* of the last scan (diagnostics) */
     hipEvent_t                ev0, ev1;         /* around the dominant scan kernel */
     int                       ev_valid;
@@ -257,18 +258,24 @@ scan_geometry(sre_hip_scanner_t *sc, size_t nstreams)
         const char *e = getenv("SRE_HIP_SCAN_TILE");      /* experiment knob: 64 / 128 / 256 */
         if (e && (atoi(e) == 32 || atoi(e) == 64 || atoi(e) == 128 || atoi(e) == 256)) tile = (uint32_t) atoi(e);
     }
+    {
+        const char *e = getenv("SRE_HIP_SEG_BYTES");        /* experiment knob */
+        if (seg == 0 && e && atoi(e) > 0 && atoi(e) % 256 == 0) seg = (uint64_t) atoi(e);
+    }
     if (seg != 0 && seg % tile != 0) tile = 64;
     sc->geom.tile = tile;
     if (seg == 0) {
-        size_t   lds = sre_scan_lds_bytes(&sc->tab->h, tile) + 4352;
-        uint64_t per_cu = (160u * 1024u) / lds;
-        if (per_cu > 8) per_cu = 8;
-        if (per_cu < 1) per_cu = 1;
-        const uint64_t resident = 256 * per_cu * SRE_SCAN_BLOCK;       /* lanes in flight */
-        uint64_t rounds = total / (resident * 4096);                    /* ~4 KiB segments */
+        /* as few rounds of resident workgroups as keep a segment <= ~16 KiB:
+         * longer segments mean fewer summaries to verify, shorter ones keep
+         * every CU busy; measured flat between 5.5 and 16 KiB on MI355X */
+        if (sc->blocks_per_cu == 0) sc->blocks_per_cu = sre_scan_blocks_per_cu(&sc->tab->h, tile);
+        const uint64_t resident = 256ull * (uint64_t) sc->blocks_per_cu * SRE_SCAN_BLOCK;
+        uint64_t       rounds = (total + resident * 16384 - 1) / (resident * 16384);
         if (rounds < 1) rounds = 1;
         seg = (total / (resident * rounds) + SRE_SCAN_SEG_ALIGN - 1) / SRE_SCAN_SEG_ALIGN * SRE_SCAN_SEG_ALIGN;
         if (seg < 1024) seg = 1024;
+        /* rows that are a multiple of 4 KiB apart land on the same HBM channels */
+        if (seg % 4096 == 0) seg += SRE_SCAN_SEG_ALIGN;
     }
     uint64_t nsegs = 0;
     for (size_t i = 0; i < nstreams; i++) {

@@ -146,6 +146,7 @@ hipError_t sre_launch_read_ceiling(const void *d_src, uint64_t n, uint32_t *d_si
 
 /* dynamic LDS one scan workgroup needs (fast table + class map + tile) */
 size_t sre_scan_lds_bytes(const sre_scan_tables_t *h_tab, uint32_t tile);
+int sre_scan_blocks_per_cu(const sre_scan_tables_t *h_tab, uint32_t tile);
 
 /* control pass over segments [lo[s], nseg_s) of every stream; lo == NULL: all.
  * carry[s] (with lo) = exact entry of segment lo[s] taken from summaries[lo[s]-1]. */

@@ -348,16 +348,47 @@ tile_fetch(uint4 (&regs)[TILE / 16], const uint8_t *const *row_ptr, const int32_
     }
 }
 
-template <int TILE>
+/* Stage one round into LDS.  The raw bytes are classified and packed HERE, by
+ * the lane that fetched them (16 independent class lookups per piece), so the
+ * tile holds ready-made fast-table indices — 8 / BITS input bytes per index
+ * byte — and the consuming lane's dependent chain is table lookups only.  A row
+ * is TILE * BITS / 8 bytes; rows are contiguous, which makes the consumer's
+ * wide read conflict-free without padding (BITS == 4 and 8 keep a 16-byte pad). */
+template <int TILE, int BITS>
 __device__ inline void
-tile_store(const uint4 (&regs)[TILE / 16], uint8_t *tile, uint32_t tid)
+tile_store(const uint4 (&regs)[TILE / 16], uint8_t *tile, const uint8_t *clsl, uint32_t tid)
 {
+    constexpr int      STRIDE = 8 / BITS;
+    constexpr uint32_t ROWB = (BITS == 8) ? (TILE + 16) : (BITS == 4) ? (TILE / 2 + 16) : (TILE * BITS / 8);
     const uint32_t wbase = tid & ~63u, lane = tid & 63u;
 #pragma unroll
     for (uint32_t i = 0; i < TILE / 16; i++) {
         const uint32_t piece = i * 64 + lane;
         const uint32_t row = wbase + piece / (TILE / 16), col = piece % (TILE / 16);
-        *reinterpret_cast<uint4 *>(tile + row * (TILE + 16) + col * 16) = regs[i];
+        const uint32_t words[4] = {regs[i].x, regs[i].y, regs[i].z, regs[i].w};
+        if (BITS == 8) {
+            *reinterpret_cast<uint4 *>(tile + row * ROWB + col * 16) = regs[i];
+        } else {
+            uint32_t kk[16];
+#pragma unroll
+            for (int b = 0; b < 16; b++) {
+                const uint32_t c = (words[b >> 2] >> ((b & 3) * 8)) & 0xffu;
+                kk[b] = (uint32_t) clsl[c];
+            }
+            /* 16 / STRIDE index bytes */
+            uint32_t out[2] = {0, 0};
+#pragma unroll
+            for (int j = 0; j < 16 / STRIDE; j++) {
+                uint32_t idx = 0;
+#pragma unroll
+                for (int u = 0; u < STRIDE; u++) idx |= kk[j * STRIDE + u] << (u * BITS);
+                out[j >> 2] |= idx << ((j & 3) * 8);
+            }
+            uint8_t *dst = tile + row * ROWB + col * (16 / STRIDE);
+            if (BITS == 1) *reinterpret_cast<uint16_t *>(dst) = (uint16_t) out[0];
+            else if (BITS == 2) *reinterpret_cast<uint32_t *>(dst) = out[0];
+            else *reinterpret_cast<uint2 *>(dst) = make_uint2(out[0], out[1]);
+        }
     }
 }
 
@@ -373,7 +404,8 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
            sre_seg_summary_t *__restrict__ sum, const int64_t *__restrict__ lo)
 {
     constexpr int      STRIDE = 8 / BITS;
-    constexpr uint32_t ROW_BYTES = TILE + 16;      /* padded tile row: conflict-free b128 reads */
+    constexpr uint32_t ROWB = (BITS == 8) ? (TILE + 16) : (BITS == 4) ? (TILE / 2 + 16) : (TILE * BITS / 8);   /* see tile_store */
+    constexpr int      GIDX = 16 / STRIDE;           /* index bytes per 16 input bytes */
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     __shared__ const uint8_t *row_ptr[SRE_SCAN_BLOCK];
     __shared__ int32_t        row_lo[SRE_SCAN_BLOCK], row_hi[SRE_SCAN_BLOCK];
@@ -513,7 +545,7 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
          * compiler from moving tile reads across the stores */
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        tile_store<TILE>(regs, tile, tid);
+        tile_store<TILE, BITS>(regs, tile, clsl, tid);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         /* next round's HBM loads fly while this round is consumed from LDS */
@@ -536,21 +568,26 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
                 if (w.count != before) fc_pending = false;
                 break;
             }
-            const uint4    v = *reinterpret_cast<const uint4 *>(tile + tid * ROW_BYTES + q * 16);
-            const uint32_t words[4] = {v.x, v.y, v.z, v.w};
-            /* byte -> class, independent of the state chain */
-            uint32_t kk[16];
-#pragma unroll
-            for (int b = 0; b < 16; b++) {
-                const uint32_t c = (words[b >> 2] >> ((b & 3) * 8)) & 0xffu;
-                kk[b] = BITS == 8 ? c : (uint32_t) clsl[c];
+            /* this group's ready-made indices */
+            uint32_t iw[4] = {0, 0, 0, 0};
+            {
+                const uint8_t *src = tile + tid * ROWB + q * GIDX;
+                if (GIDX == 16) {
+                    const uint4 v = *reinterpret_cast<const uint4 *>(src);
+                    iw[0] = v.x; iw[1] = v.y; iw[2] = v.z; iw[3] = v.w;
+                } else if (GIDX == 8) {
+                    const uint2 v = *reinterpret_cast<const uint2 *>(src);
+                    iw[0] = v.x; iw[1] = v.y;
+                } else if (GIDX == 4) {
+                    iw[0] = *reinterpret_cast<const uint32_t *>(src);
+                } else {
+                    iw[0] = *reinterpret_cast<const uint16_t *>(src);
+                }
             }
             uint32_t so = w.st * SRE_FAST_ROW_BYTES, acc = 0, cnt = 0, lastb = 0;
 #pragma unroll
-            for (int j = 0; j < 16 / STRIDE; j++) {
-                uint32_t idx = 0;
-#pragma unroll
-                for (int u = 0; u < STRIDE; u++) idx |= kk[j * STRIDE + u] << (u * BITS);
+            for (int j = 0; j < GIDX; j++) {
+                const uint32_t idx = (iw[j >> 2] >> ((j & 3) * 8)) & 0xffu;
                 const uint32_t t = fast[(so >> 2) + idx];
                 acc |= t;
                 if (MODE == SRE_HIP_PIKE_COUNT) {
@@ -1207,8 +1244,30 @@ extern "C" size_t
 sre_scan_lds_bytes(const sre_scan_tables_t *h_tab, uint32_t tile)
 {
     const size_t tr = (size_t) h_tab->nstates * (h_tab->ncls + 1) * sizeof(sre_dev_trans_t);
+    const size_t rowb = h_tab->class_bits == 8 ? tile + 16 : h_tab->class_bits == 4 ? tile / 2 + 16
+                        : (size_t) tile * h_tab->class_bits / 8;
     return (size_t) h_tab->fast_bytes + 256 + tr + ((h_tab->nstates + 15u) & ~15u) + 16
-           + (size_t) SRE_SCAN_BLOCK * (tile + 16);
+           + (size_t) SRE_SCAN_BLOCK * rowb;
+}
+
+/* workgroups of the scan kernel one CU can hold (registers and LDS), for the
+ * geometry heuristic */
+extern "C" int
+sre_scan_blocks_per_cu(const sre_scan_tables_t *h_tab, uint32_t tile)
+{
+    int          n = 0;
+    const size_t shmem = sre_scan_lds_bytes(h_tab, tile);
+    hipError_t   e;
+    /* the variants differ little in registers: query the common one per mode */
+    if (h_tab->mode == SRE_HIP_PIKE_COUNT) {
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, sre_k_scan<SRE_HIP_PIKE_COUNT, 2, 64>,
+                                                         SRE_SCAN_BLOCK, shmem);
+    } else {
+        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, sre_k_scan<1, 2, 64>, SRE_SCAN_BLOCK, shmem);
+    }
+    if (e != hipSuccess || n < 1) n = 1;
+    if (n > 8) n = 8;
+    return n;
 }
 
 extern "C" hipError_t
