@@ -256,7 +256,7 @@ scan_geometry(sre_hip_scanner_t *sc, size_t nstreams)
     uint32_t tile = SRE_SCAN_TILE_DEFAULT;
     {
         const char *e = getenv("SRE_HIP_SCAN_TILE");      /* experiment knob: 64 / 128 / 256 */
-        if (e && (atoi(e) == 32 || atoi(e) == 64 || atoi(e) == 128 || atoi(e) == 256)) tile = (uint32_t) atoi(e);
+        if (e && (atoi(e) == 64 || atoi(e) == 128)) tile = (uint32_t) atoi(e);
     }
     {
         const char *e = getenv("SRE_HIP_SEG_BYTES");        /* experiment knob */

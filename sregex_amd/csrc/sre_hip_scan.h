@@ -132,7 +132,7 @@ typedef struct {
     uint32_t nstreams;
     uint32_t seg_bytes;
     uint64_t nsegs;
-    uint32_t tile;                  /* 32 / 64 / 128 / 256 bytes per lane per LDS round */
+    uint32_t tile;                  /* 64 or 128 bytes per lane per LDS round */
     uint32_t init_variant;          /* SRE_DFA_INIT_* of the search that starts at offset 0 */
 } sre_scan_geom_t;
 

@@ -353,13 +353,14 @@ tile_fetch(uint4 (&regs)[TILE / 16], const uint8_t *const *row_ptr, const int32_
  * tile holds ready-made fast-table indices — 8 / BITS input bytes per index
  * byte — and the consuming lane's dependent chain is table lookups only.  A row
  * is TILE * BITS / 8 bytes; rows are contiguous, which makes the consumer's
- * wide read conflict-free without padding (BITS == 4 and 8 keep a 16-byte pad). */
+ * wide read conflict-free without padding (rows longer than 16 bytes keep a
+ * 16-byte pad). */
 template <int TILE, int BITS>
 __device__ inline void
 tile_store(const uint4 (&regs)[TILE / 16], uint8_t *tile, const uint8_t *clsl, uint32_t tid)
 {
     constexpr int      STRIDE = 8 / BITS;
-    constexpr uint32_t ROWB = (BITS == 8) ? (TILE + 16) : (BITS == 4) ? (TILE / 2 + 16) : (TILE * BITS / 8);
+    constexpr uint32_t ROWB = (TILE * BITS / 8 > 16) ? (TILE * BITS / 8 + 16) : (TILE * BITS / 8);
     const uint32_t wbase = tid & ~63u, lane = tid & 63u;
 #pragma unroll
     for (uint32_t i = 0; i < TILE / 16; i++) {
@@ -404,7 +405,7 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
            sre_seg_summary_t *__restrict__ sum, const int64_t *__restrict__ lo)
 {
     constexpr int      STRIDE = 8 / BITS;
-    constexpr uint32_t ROWB = (BITS == 8) ? (TILE + 16) : (BITS == 4) ? (TILE / 2 + 16) : (TILE * BITS / 8);   /* see tile_store */
+    constexpr uint32_t ROWB = (TILE * BITS / 8 > 16) ? (TILE * BITS / 8 + 16) : (TILE * BITS / 8);   /* see tile_store */
     constexpr int      GIDX = 16 / STRIDE;           /* index bytes per 16 input bytes */
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     __shared__ const uint8_t *row_ptr[SRE_SCAN_BLOCK];
@@ -558,6 +559,26 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
         w.anchor_pos = warm_round ? -1 : base;
         w.anchor_state = w.st;
 
+        /* the lane's whole row of indices in one go: rows are contiguous 16-byte
+         * multiples, so these wide reads are bank-conflict free */
+        constexpr int ROWW = (TILE * BITS / 8 + 3) / 4;         /* dwords of indices per round */
+        uint32_t      roww[ROWW < 4 ? 4 : ROWW];
+        {
+            const uint8_t *src = tile + tid * ROWB;
+            if (ROWW >= 4) {
+#pragma unroll
+                for (int x = 0; x < ROWW / 4; x++) {
+                    const uint4 v = *reinterpret_cast<const uint4 *>(src + 16 * x);
+                    roww[4 * x] = v.x; roww[4 * x + 1] = v.y; roww[4 * x + 2] = v.z; roww[4 * x + 3] = v.w;
+                }
+            } else if (ROWW == 2) {
+                const uint2 v = *reinterpret_cast<const uint2 *>(src);
+                roww[0] = v.x; roww[1] = v.y;
+            } else {
+                roww[0] = *reinterpret_cast<const uint32_t *>(src);
+            }
+        }
+#pragma unroll
         for (uint32_t q = 0; q < TILE / 16; q++) {
             const int64_t gp = base + q * 16;
             if (gp >= seg_b || w.finished) break;
@@ -568,21 +589,13 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
                 if (w.count != before) fc_pending = false;
                 break;
             }
-            /* this group's ready-made indices */
+            /* this group's ready-made indices: GIDX bytes starting at byte q * GIDX */
             uint32_t iw[4] = {0, 0, 0, 0};
-            {
-                const uint8_t *src = tile + tid * ROWB + q * GIDX;
-                if (GIDX == 16) {
-                    const uint4 v = *reinterpret_cast<const uint4 *>(src);
-                    iw[0] = v.x; iw[1] = v.y; iw[2] = v.z; iw[3] = v.w;
-                } else if (GIDX == 8) {
-                    const uint2 v = *reinterpret_cast<const uint2 *>(src);
-                    iw[0] = v.x; iw[1] = v.y;
-                } else if (GIDX == 4) {
-                    iw[0] = *reinterpret_cast<const uint32_t *>(src);
-                } else {
-                    iw[0] = *reinterpret_cast<const uint16_t *>(src);
-                }
+#pragma unroll
+            for (int j = 0; j < GIDX; j++) {
+                const int      byte = (int) q * GIDX + j;
+                const uint32_t b = (roww[byte >> 2] >> ((byte & 3) * 8)) & 0xffu;
+                iw[j >> 2] |= b << ((j & 3) * 8);
             }
             uint32_t so = w.st * SRE_FAST_ROW_BYTES, acc = 0, cnt = 0, lastb = 0;
 #pragma unroll
@@ -1234,18 +1247,16 @@ launch_scan_tile(uint32_t tile, uint32_t bits, uint32_t grid, size_t shmem, hipS
                  const sre_scan_tables_t *d_tab, sre_scan_geom_t geom, sre_seg_summary_t *d_sum,
                  const int64_t *d_lo)
 {
-    if (tile == 64) launch_scan_bits<MODE, 64>(bits, grid, shmem, stream, d_tab, geom, d_sum, d_lo);
-    else if (tile == 32) launch_scan_bits<MODE, 32>(bits, grid, shmem, stream, d_tab, geom, d_sum, d_lo);
-    else if (tile == 256) launch_scan_bits<MODE, 256>(bits, grid, shmem, stream, d_tab, geom, d_sum, d_lo);
-    else launch_scan_bits<MODE, 128>(bits, grid, shmem, stream, d_tab, geom, d_sum, d_lo);
+    if (tile == 128) launch_scan_bits<MODE, 128>(bits, grid, shmem, stream, d_tab, geom, d_sum, d_lo);
+    else launch_scan_bits<MODE, 64>(bits, grid, shmem, stream, d_tab, geom, d_sum, d_lo);
 }
 
 extern "C" size_t
 sre_scan_lds_bytes(const sre_scan_tables_t *h_tab, uint32_t tile)
 {
     const size_t tr = (size_t) h_tab->nstates * (h_tab->ncls + 1) * sizeof(sre_dev_trans_t);
-    const size_t rowb = h_tab->class_bits == 8 ? tile + 16 : h_tab->class_bits == 4 ? tile / 2 + 16
-                        : (size_t) tile * h_tab->class_bits / 8;
+    size_t rowb = (size_t) tile * h_tab->class_bits / 8;
+    if (rowb > 16) rowb += 16;
     return (size_t) h_tab->fast_bytes + 256 + tr + ((h_tab->nstates + 15u) & ~15u) + 16
            + (size_t) SRE_SCAN_BLOCK * rowb;
 }
