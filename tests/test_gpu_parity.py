@@ -314,3 +314,44 @@ def test_compat_api_large_buffers_take_the_scanner(gpu):
             got = harness.findall(eng, prog, re.ncaps, data, limit)
             assert got == want, (pats, got[:3], want[:3], len(got), len(want))
             eng.recycle()
+
+
+def test_full_size_streams_closed_form_properties(gpu):
+    """BASELINE.json's full-size configurations (4 GiB gen-data streams).  The
+    oracle cannot run there, so the expected records are closed forms in the
+    stream length — each closed form is first checked against the oracle at a
+    size the oracle handles, then the scanner must reproduce it at 4 GiB."""
+    ora = harness.OracleEngine()
+    cfg3 = [b"a", b"ab", b"c", b"a(bc)", b"e(f)", b"gh", b"A", b"b", b"BLAH", rb"\s+", b"abcd", b"bc"]
+    uri_tail = b" abc://abc.cc/ab/c?a=b "
+    cases = [
+        # (patterns, mode, tail, expected(L) -> record)
+        ([rb"[a-z]+@[a-z]+\.[a-z]+"], S.HIP_PIKE_FIRST, b"aaabbccb", lambda L: [S.SRE_DECLINED, 0, -1, -1]),
+        ([rb"[a-z]+@[a-z]+\.[a-z]+"], S.HIP_PIKE_FIRST, b"@abc.cc ", lambda L: [0, 1, 0, L - 1]),
+        ([rb"([a-z]+)://([^/ ]+)(/[^ ?]*)?(\?[^ ]*)?"], S.HIP_PIKE_FIRST, uri_tail,
+         lambda L: [0, 1, L - 22, L - 1, L - 22, L - 19, L - 16, L - 10, L - 10, L - 5, L - 5, L - 1]),
+        (cfg3, S.HIP_PIKE_COUNT, b"aaabbccb", lambda L: [7, L, L - 1, L, -1, -1]),
+        ([rb"a?a?a?aaa"], S.HIP_THOMPSON, b"aaabbccb", lambda L: [0, 1, -1, -1]),
+        ([rb"a?a?a?aaa"], S.HIP_PIKE_FIRST, b"aaabbccb", lambda L: [0, 1, L - 8, L - 5]),
+    ]
+    big = 4 << 30
+    buf = S.DeviceBuffer(big)
+    for pats, mode, tail, expect in cases:
+        with S.Pool() as pool:
+            re = S.parse(pool, pats)
+            prog = S.compile(pool, re)
+            # the closed form against the oracle
+            small = S.gen_data_host(20000, tail)
+            first, cnt = _expect(ora, prog, re.ncaps, small)
+            want_small = {S.HIP_PIKE_FIRST: first, S.HIP_PIKE_COUNT: cnt,
+                          S.HIP_THOMPSON: [0 if first[0] >= 0 else S.SRE_DECLINED, 1 if first[0] >= 0 else 0]
+                          + [-1] * (2 * (re.ncaps + 1))}[mode]
+            assert expect(len(small)) == want_small, (pats, tail, expect(len(small)), want_small)
+            # the real thing
+            L = S.gen_data_length(big, len(tail))
+            assert gpu.sre_hip_gen_data(buf.ptr, L, tail, len(tail), None) == 0
+            sc = S.Scanner(pool, prog, mode, S.ENGINE_SCAN)
+            rec = sc.scan([buf.ptr], [L])[0]
+            assert rec == expect(L), (pats, tail, rec, expect(L))
+            assert sc.last_fixups == 0
+    buf.free()
