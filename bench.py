@@ -90,6 +90,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--bytes", type=int, default=4 * GIB, help="bytes per GPU (default 4 GiB)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--config", default="cfg2", choices=["cfg1", "cfg2", "cfg2m", "cfg3", "cfg4"],
+                    help="N=1 workload: cfg2 = BASELINE configs[1] (default, the headline); cfg2m = "
+                         "same with a matching tail (captures span the whole stream); cfg3 = "
+                         "configs[2] multi-regex find-all count; cfg4 = configs[3] URI, 4 groups; "
+                         "cfg1 = configs[0]'s pattern, Thompson")
     ap.add_argument("--many-streams", action="store_true",
                     help="use the N>1 workload shape (64 MiB streams) even on one GPU")
     args = ap.parse_args()
@@ -113,13 +118,24 @@ def main():
     hstream = ctypes.c_void_p(stream.cuda_stream)
 
     # ---- resident input -------------------------------------------------
+    pats, mode = [PATTERN], S.HIP_PIKE_FIRST
     if world == 1 and not args.many_streams:
         tail = b"aaabbccb"
+        name = "configs[1]: /[a-z]+@[a-z]+\\.[a-z]+/ Pike first-match + captures"
+        if args.config == "cfg2m":
+            tail, name = b"@abc.cc ", name + ", matching tail '@abc.cc '"
+        elif args.config == "cfg3":
+            pats = [b"a", b"ab", b"c", b"a(bc)", b"e(f)", b"gh", b"A", b"b", b"BLAH", rb"\s+", b"abcd", b"bc"]
+            mode, name = S.HIP_PIKE_COUNT, "configs[2]: 12 regexes of t/04-multi.t combined, find-all count"
+        elif args.config == "cfg4":
+            pats = [rb"([a-z]+)://([^/ ]+)(/[^ ?]*)?(\?[^ ]*)?"]
+            tail, name = b" abc://abc.cc/ab/c?a=b ", "configs[3]: URI pattern, 4 capture groups, matching tail"
+        elif args.config == "cfg1":
+            pats, mode, name = [b"a?a?a?aaa"], S.HIP_THOMPSON, "configs[0] pattern a?a?a?aaa, Thompson"
         n = S.gen_data_length(args.bytes, len(tail))
         lens = [n]
         tails = [tail]
-        workload = ("configs[1]: 1 stream x %.2f GiB gen-data (abccc.. + 'aaabbccb'), "
-                    "/[a-z]+@[a-z]+\\.[a-z]+/ Pike first-match + captures" % (n / GIB))
+        workload = "%s; 1 stream x %.2f GiB gen-data (abccc.. + %r)" % (name, n / GIB, tail.decode())
     else:
         per = 64 << 20
         nstreams = max(1, args.bytes // per)
@@ -136,8 +152,8 @@ def main():
     total = sum(lens)
 
     pool = S.Pool()
-    prog = S.compile(pool, S.parse(pool, [PATTERN]))
-    sc = S.Scanner(pool, prog, S.HIP_PIKE_FIRST, S.ENGINE_SCAN)
+    prog = S.compile(pool, S.parse(pool, pats))
+    sc = S.Scanner(pool, prog, mode, S.ENGINE_SCAN)
 
     def step():
         recs = sc.scan(ptrs, lens, hstream)
@@ -153,7 +169,15 @@ def main():
     # correctness of what is being timed (size-independent property): a stream
     # matches iff its tail holds the '@' form, and then spans the whole stream
     for n, t, r in zip(lens, tails, recs):
-        if b"@" in t:
+        if args.config == "cfg3":
+            assert r == [7, n, n - 1, n, -1, -1], (r, n)     # every byte is a match of a / b / c
+        elif args.config == "cfg4":
+            assert r == [0, 1, n - 22, n - 1, n - 22, n - 19, n - 16, n - 10, n - 10, n - 5, n - 5, n - 1], r
+        elif args.config == "cfg1":
+            assert r[:2] == [0, 1], r
+        elif t == b"@abc.cc ":
+            assert r[:4] == [0, 1, 0, n - 1], (r, n)         # the match spans the whole stream
+        elif b"@" in t:
             assert r[:4] == [0, 1, n - 9, n - 1], (r, n)      # "a@abc.cc" in front of the last space
         else:
             assert r[0] == S.SRE_DECLINED and r[1] == 0, r
@@ -183,14 +207,15 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": workload, "bytes_per_gpu": total, "streams_per_gpu": len(lens),
                        "segment_bytes": sc.last_segment_bytes, "fixup_rounds": sc.last_fixups,
-                       "matches": matches, "engine": "scan"},
+                       "matches": matches, "engine": "scan", "lineage_passes": sc.last_lineage_passes},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "sre_k_scan<1>", "kernel_ms": kms,
+                         "kernel": "sre_k_scan<%d>" % (2 if mode == S.HIP_PIKE_COUNT else 1), "kernel_ms": kms,
                          "algorithmic_bytes_per_launch": total},
         }
         prof = os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")
-        if world == 1 and total == 4 * GIB - 3 and os.path.exists(prof):
+        if world == 1 and args.config == "cfg2" and not args.many_streams and total == 4 * GIB - 3 \
+                and os.path.exists(prof):
             # HBM bytes per launch from the separate rocprofv3 --pmc passes of this
             # same command (profiles/README.md): 2 x FETCH_SIZE (gfx950 correction,
             # MI355X_MICROARCH.md HBM section) + WRITE_SIZE, KB -> bytes

@@ -61,7 +61,7 @@ typedef struct {
     const uint64_t        *lin_saves;
     const uint8_t         *lin_flags;   /* per new thread: bit0 its closure path saved a slot,
                                            bit1 it is the ".*?" ANY thread (pc 1) */
-    uint32_t               lin_total, pad2;
+    uint32_t               lin_total, list_total;  /* entries of lin_* / list_pcs */
     const uint8_t         *state_flags; /* [nstates] bit0 matched, bits 1-2 seen_start (2 = reached by a skip) */
     const uint32_t        *list_off;    /* [nstates + 1] */
     const uint32_t        *list_pcs;
@@ -106,7 +106,7 @@ typedef struct {
 } sre_seg_lineage_t;
 
 #define SRE_LINEAGE_BLOCK  256u     /* segments composed into one block map */
-#define SRE_WALK_BUDGET_SEGS 1      /* plain backward walk before asking for the maps */
+#define SRE_WALK_BUDGET    2048     /* positions of plain backward walk before asking for the maps */
 
 /* per-stream outcome of verify + reduce */
 typedef struct {

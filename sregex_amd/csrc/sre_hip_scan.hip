@@ -714,7 +714,7 @@ sre_k_verify_a(sre_scan_geom_t G, const sre_seg_summary_t *__restrict__ sum, Ver
 __global__ __launch_bounds__(256) void
 sre_k_verify_b(sre_scan_geom_t G, const sre_seg_summary_t *__restrict__ sum, VerifyAcc *__restrict__ acc)
 {
-    __shared__ unsigned long long sh_count, sh_ev;
+    __shared__ unsigned long long sh_count, sh_ev, sh_sp;
     const uint64_t g0 = (uint64_t) blockIdx.x * blockDim.x;
     const uint64_t g = g0 + threadIdx.x;
     const uint64_t glast = (g0 + blockDim.x - 1 < G.nsegs) ? g0 + blockDim.x - 1 : G.nsegs - 1;
@@ -723,6 +723,7 @@ sre_k_verify_b(sre_scan_geom_t G, const sre_seg_summary_t *__restrict__ sum, Ver
     if (threadIdx.x == 0) {
         sh_count = 0;
         sh_ev = 0;
+        sh_sp = 0;
     }
     __syncthreads();
     if (g < G.nsegs) {
@@ -743,13 +744,17 @@ sre_k_verify_b(sre_scan_geom_t G, const sre_seg_summary_t *__restrict__ sum, Ver
                 if (c.flags & SRE_SUM_LASTEV) atomicMax(&acc[s].evseg, (unsigned long long) k + 1);
             }
             /* latest segment at whose end a search start is known */
-            if (c.cur_sp >= 0) atomicMax(&acc[s].spseg, (unsigned long long) k + 1);
+            if (c.cur_sp >= 0) {
+                if (uniform) atomicMax(&sh_sp, (unsigned long long) k + 1);
+                else atomicMax(&acc[s].spseg, (unsigned long long) k + 1);
+            }
         }
     }
     __syncthreads();
     if (uniform && threadIdx.x == 0) {
         if (sh_count) atomicAdd(&acc[s_first].count, sh_count);
         if (sh_ev) atomicMax(&acc[s_first].evseg, sh_ev);
+        if (sh_sp) atomicMax(&acc[s_first].spseg, sh_sp);
     }
 }
 
@@ -1008,8 +1013,8 @@ sre_k_lineage_maps(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G
 
     uint64_t anc = 0xfedcba9876543210ull;       /* identity */
     uint32_t saved = 0, stop = 0;
-    for (int64_t q = lo; q < hi; q++) {
-        const sre_dev_trans_t &tr = trl[cur * nsym + clsl[data[q]]];
+    auto step = [&](uint32_t c) {
+        const sre_dev_trans_t &tr = trl[cur * nsym + clsl[c]];
         uint64_t nanc = 0;
         uint32_t nsaved = 0, nstop = 0;
         for (uint32_t j = 0; j < tr.lin_n; j++) {
@@ -1026,7 +1031,18 @@ sre_k_lineage_maps(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G
         saved = nsaved;
         stop = nstop;
         cur = tr.next;
+    };
+    int64_t q = lo;
+    if ((reinterpret_cast<uintptr_t>(data) & 15) == 0) {
+        for (; q < hi && (q & 15); q++) step(data[q]);
+        for (; q + 16 <= hi; q += 16) {
+            const uint4    v = *reinterpret_cast<const uint4 *>(data + q);
+            const uint32_t words[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int b = 0; b < 16; b++) step((words[b >> 2] >> ((b & 3) * 8)) & 0xffu);
+        }
     }
+    for (; q < hi; q++) step(data[q]);
     sre_seg_lineage_t out;
     out.anc = anc;
     out.saved = (uint16_t) saved;
@@ -1075,16 +1091,31 @@ sre_k_captures(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     __shared__ sre_scan_tables_t Ts;
     {
-        /* the walker's tables live in LDS: [fast][class map][transition records] */
+        /* the walker's tables live in LDS:
+         * [fast][class map][transition records][lineage saves][lineage parents] */
         uint32_t *fast = reinterpret_cast<uint32_t *>(lds);
         uint8_t  *clsl = lds + tabp->fast_bytes;
         uint8_t  *trl = clsl + 256;
         const uint32_t tr_bytes = (tabp->nstates * (tabp->ncls + 1) + 3) * (uint32_t) sizeof(sre_dev_trans_t);
+        uint64_t *savl = reinterpret_cast<uint64_t *>(trl + tr_bytes);
+        uint32_t *lofl = reinterpret_cast<uint32_t *>(savl + tabp->lin_total);
+        uint32_t *lpcl = lofl + tabp->nstates + 1;
+        uint8_t  *parl = reinterpret_cast<uint8_t *>(lpcl + tabp->list_total);
         if (threadIdx.x == 0) {
             Ts = *tabp;
             Ts.fast = fast;
             Ts.cls = clsl;
             Ts.trans = reinterpret_cast<const sre_dev_trans_t *>(trl);
+            Ts.lin_saves = savl;
+            Ts.lin_parent = parl;
+            Ts.list_off = lofl;
+            Ts.list_pcs = lpcl;
+        }
+        for (uint32_t i = threadIdx.x; i <= tabp->nstates; i += blockDim.x) lofl[i] = tabp->list_off[i];
+        for (uint32_t i = threadIdx.x; i < tabp->list_total; i += blockDim.x) lpcl[i] = tabp->list_pcs[i];
+        for (uint32_t i = threadIdx.x; i < tabp->lin_total; i += blockDim.x) {
+            savl[i] = tabp->lin_saves[i];
+            parl[i] = tabp->lin_parent[i];
         }
         for (uint32_t i = threadIdx.x; i < tabp->fast_bytes / 16; i += blockDim.x) {
             reinterpret_cast<uint4 *>(fast)[i] = reinterpret_cast<const uint4 *>(tabp->fast_plain)[i];
@@ -1152,7 +1183,7 @@ sre_k_captures(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
     const int64_t  seg = (int64_t) G.seg_bytes;
     const int64_t  k_sp = tr.sp / seg;
     const bool     can_jump = use_maps && T.max_threads <= 16;
-    int64_t        budget = (int64_t) SRE_WALK_BUDGET_SEGS * seg;
+    int64_t        budget = SRE_WALK_BUDGET;
 
     /* thread j lives in the list at position p */
     for (int64_t p = st.ev_pos; unresolved; p--) {
@@ -1333,7 +1364,8 @@ sre_launch_captures(const sre_scan_tables_t *d_tab, sre_scan_tables_t h_tab, sre
     if (geom.nstreams == 0) return hipSuccess;
     const uint32_t block = 64, grid = (geom.nstreams + block - 1) / block;
     const size_t   shmem = (size_t) h_tab.fast_bytes + 256
-                         + ((size_t) h_tab.nstates * (h_tab.ncls + 1) + 3) * sizeof(sre_dev_trans_t);
+                         + ((size_t) h_tab.nstates * (h_tab.ncls + 1) + 3) * sizeof(sre_dev_trans_t)
+                         + (size_t) h_tab.lin_total * 9 + ((size_t) h_tab.nstates + 1 + h_tab.list_total) * 4 + 16;
     hipLaunchKernelGGL(sre_k_captures, dim3(grid), dim3(block), shmem, stream, d_tab, geom, d_sum,
                        d_status, d_scratch, d_records, ovec_slots, d_maps, d_blocks, use_maps);
     return hipGetLastError();

@@ -149,6 +149,7 @@ sre_scan_tables_build(const sre_program_t *prog, const sre_dfa_t *d, int mode, c
         }
     }
     h.lin_total = (uint32_t) d->lin_parent.size();
+    h.list_total = (uint32_t) d->list_pcs.size();
     (void) nsym;
 
     hipError_t e;
