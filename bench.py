@@ -108,12 +108,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
-    torch.cuda.set_device(local_rank)
+    # rehearsal knobs (one-GPU box): SRE_BENCH_DEVICE pins every rank to one
+    # device, SRE_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one GPU)
+    device = int(os.environ.get("SRE_BENCH_DEVICE", local_rank))
+    torch.cuda.set_device(device)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl")          # RCCL
+        dist.init_process_group(os.environ.get("SRE_BENCH_BACKEND", "nccl"))    # "nccl" == RCCL
     lib = S.load_library()
-    assert lib.sre_hip_set_device(local_rank) == 0
+    assert lib.sre_hip_set_device(device) == 0
     stream = torch.cuda.current_stream()
     hstream = ctypes.c_void_p(stream.cuda_stream)
 

@@ -28,11 +28,9 @@
 #define SRE_FAST_ROW_BYTES  1024u
 
 #define SRE_SCAN_MAX_STATES   64u     /* LDS budget: 64 KiB of fast table */
-#define SRE_SCAN_MAX_THREADS  16u     /* lineage vectors are 16 bytes */
 #define SRE_SCAN_BLOCK        256u    /* lanes = segments per workgroup */
 #define SRE_SCAN_TILE_DEFAULT 64u     /* bytes per lane per LDS round (measured best of 64/128/256) */
 #define SRE_SCAN_SEG_ALIGN    256u    /* segments are a multiple of every tile size */
-#define SRE_SCAN_WARMUP       64u     /* speculative warm-up before a segment */
 
 /* full transition record (global memory; slow path and lineage kernels) */
 typedef struct {
@@ -66,7 +64,7 @@ typedef struct {
     const uint32_t        *list_off;    /* [nstates + 1] */
     const uint32_t        *list_pcs;
     const uint32_t        *multi_ncaps; /* [nregexes] */
-    uint32_t nregexes, warmup;          /* speculative warm-up bytes per segment */
+    uint32_t nregexes, pad3;
 } sre_scan_tables_t;
 
 /* what one lane learnt about its segment */

@@ -77,7 +77,6 @@ sre_scan_tables_build(const sre_program_t *prog, const sre_dfa_t *d, int mode, c
     const uint32_t stride = 8 / bits;
     h.stride = stride;
     h.class_bits = bits;
-    h.warmup = 0;      /* the warm-up is one tile round, see sre_k_scan */
     auto build_fast = [&](int fmode) {
     std::vector<uint32_t> fast((size_t) d->nstates * 256);
     for (uint32_t s = 0; s < d->nstates; s++) {
