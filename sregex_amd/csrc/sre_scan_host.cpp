@@ -149,7 +149,20 @@ sre_scan_tables_build(const sre_program_t *prog, const sre_dfa_t *d, int mode, c
     }
     h.lin_total = (uint32_t) d->lin_parent.size();
     h.list_total = (uint32_t) d->list_pcs.size();
-    (void) nsym;
+
+    {
+        /* both LDS-resident kernels must fit the 64 KiB a launch may ask for
+         * without opting in; otherwise the exact VM engine takes the program */
+        const size_t tr = ((size_t) d->nstates * nsym + 3) * sizeof(sre_dev_trans_t);
+        const size_t scan_lds = sre_scan_lds_bytes(&h, 128) + 4352;
+        const size_t cap_lds = (size_t) h.fast_bytes + 256 + tr + (size_t) h.lin_total * 9
+                               + ((size_t) d->nstates + 1 + h.list_total) * 4 + 16 + 512;
+        if (scan_lds > 64 * 1024 || cap_lds > 64 * 1024) {
+            *why = "automaton tables exceed the LDS budget of the scanner";
+            delete t;
+            return NULL;
+        }
+    }
 
     hipError_t e;
     if ((e = upload(fast, &h.fast, t->owned)) != hipSuccess
