@@ -142,6 +142,18 @@ SRE_API int sre_hip_gen_data(void *d_dst, size_t n, const void *h_tail,
  */
 SRE_API int sre_hip_read_ceiling(const void *d_src, size_t n, void *hip_stream);
 
+/*
+ * The scanner's staging access pattern with no automaton work: the first
+ * n / seg_bytes rows of seg_bytes (a multiple of 128) each, one row per lane,
+ * tile (64, 128 or 256) bytes of every row per round, fetched one round ahead.
+ * lds_bytes of dynamic LDS are requested only to pin the workgroups per CU to
+ * what the scanner gets.  The rate this reaches is the ceiling the access
+ * pattern itself allows; bench.py reports it next to the plain read ceiling.
+ * Asynchronous.
+ */
+SRE_API int sre_hip_read_pattern(const void *d_src, size_t n, unsigned seg_bytes,
+    unsigned tile, unsigned lds_bytes, void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

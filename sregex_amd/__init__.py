@@ -72,6 +72,7 @@ API = {
     "sre_hip_synchronize": (ctypes.c_int, [_vp]),
     "sre_hip_gen_data": (ctypes.c_int, [_vp, _sz, ctypes.c_char_p, _sz, _vp]),
     "sre_hip_read_ceiling": (ctypes.c_int, [_vp, _sz, _vp]),
+    "sre_hip_read_pattern": (ctypes.c_int, [_vp, _sz, ctypes.c_uint, ctypes.c_uint, ctypes.c_uint, _vp]),
 }
 
 _lib = None

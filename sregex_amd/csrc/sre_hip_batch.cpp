@@ -526,14 +526,38 @@ hip_failed:
     return rc;
 }
 
+static uint32_t *
+ceiling_sink(void)
+{
+    static uint32_t *d_sink = NULL;
+    if (d_sink == NULL
+        && hipMalloc(reinterpret_cast<void **>(&d_sink), SRE_CEILING_GRID * sizeof(uint32_t)) != hipSuccess)
+    {
+        d_sink = NULL;
+    }
+    return d_sink;
+}
+
+extern "C" SRE_API int
+sre_hip_read_pattern(const void *d_src, size_t n, unsigned seg_bytes, unsigned tile,
+                     unsigned lds_bytes, void *hip_stream)
+{
+    if (sre_hip_ready() != 0) return -1;
+    uint32_t *d_sink = ceiling_sink();
+    if (d_sink == NULL) return -1;
+    SRE_HIP_TRY(sre_launch_read_pattern(d_src, n, seg_bytes, tile, lds_bytes, d_sink,
+                                        static_cast<hipStream_t>(hip_stream)));
+    return 0;
+hip_failed:
+    return -1;
+}
+
 extern "C" SRE_API int
 sre_hip_read_ceiling(const void *d_src, size_t n, void *hip_stream)
 {
-    static uint32_t *d_sink = NULL;
     if (sre_hip_ready() != 0) return -1;
-    if (d_sink == NULL) {
-        SRE_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_sink), SRE_CEILING_GRID * sizeof(uint32_t)));
-    }
+    uint32_t *d_sink = ceiling_sink();
+    if (d_sink == NULL) return -1;
     SRE_HIP_TRY(sre_launch_read_ceiling(d_src, n, d_sink, static_cast<hipStream_t>(hip_stream)));
     return 0;
 hip_failed:

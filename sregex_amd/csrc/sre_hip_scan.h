@@ -141,6 +141,8 @@ hipError_t sre_launch_gen_data(void *d_dst, uint64_t n, uint64_t tail_len, const
     hipStream_t stream);
 hipError_t sre_launch_read_ceiling(const void *d_src, uint64_t n, uint32_t *d_sink,
     hipStream_t stream);
+hipError_t sre_launch_read_pattern(const void *d_src, uint64_t n, uint32_t seg_bytes,
+    uint32_t tile, uint32_t lds_bytes, uint32_t *d_sink, hipStream_t stream);
 
 /* dynamic LDS one scan workgroup needs (fast table + class map + tile) */
 size_t sre_scan_lds_bytes(const sre_scan_tables_t *h_tab, uint32_t tile);

@@ -109,6 +109,66 @@ sre_launch_read_ceiling(const void *d_src, uint64_t n, uint32_t *d_sink, hipStre
     return hipGetLastError();
 }
 
+/* ---- the scanner's staging pattern alone: one row of seg_bytes per lane,
+ * TILE bytes of every row per round, the wave's 64 rows fetched as 16-byte
+ * pieces one round ahead — no automaton work.  Its rate is the ceiling the
+ * access pattern itself allows (rows far apart: part-line requests). ---- */
+
+template <int TILE>
+__global__ __launch_bounds__(256) void
+sre_k_read_pattern(const uint8_t *__restrict__ src, uint64_t n, uint32_t seg_bytes,
+                   uint32_t *__restrict__ sink)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t occupancy_pad[];
+    const uint32_t tid = threadIdx.x, wbase = tid & ~63u, lane = tid & 63u;
+    const uint64_t nsegs = n / seg_bytes;
+    const uint64_t row0 = (uint64_t) blockIdx.x * 256 + wbase;
+    const uint32_t nrounds = seg_bytes / TILE;
+    uint32_t       acc = 0;
+    uint4          regs[TILE / 16];
+    auto fetch = [&](uint32_t r) {
+#pragma unroll
+        for (uint32_t i = 0; i < TILE / 16; i++) {
+            const uint32_t piece = i * 64 + lane;
+            const uint64_t row = row0 + piece / (TILE / 16);
+            const uint32_t col = piece % (TILE / 16);
+            regs[i] = make_uint4(0, 0, 0, 0);
+            if (row < nsegs) {
+                regs[i] = *reinterpret_cast<const uint4 *>(src + row * seg_bytes + (uint64_t) r * TILE + col * 16);
+            }
+        }
+    };
+    fetch(0);
+    for (uint32_t r = 0; r < nrounds; r++) {
+#pragma unroll
+        for (uint32_t i = 0; i < TILE / 16; i++) acc += regs[i].x ^ regs[i].y ^ regs[i].z ^ regs[i].w;
+        if (r + 1 < nrounds) fetch(r + 1);
+        /* a little dependent work between rounds, as the consumer has */
+        acc = acc * 0x9e3779b1u + r;
+    }
+    if (acc == 0x9e3779b9u) sink[blockIdx.x % SRE_CEILING_GRID] = acc + occupancy_pad[0];
+}
+
+extern "C" hipError_t
+sre_launch_read_pattern(const void *d_src, uint64_t n, uint32_t seg_bytes, uint32_t tile,
+                        uint32_t lds_bytes, uint32_t *d_sink, hipStream_t stream)
+{
+    if (seg_bytes == 0 || seg_bytes % 128 != 0 || n < seg_bytes) return hipErrorInvalidValue;
+    const uint64_t nsegs = n / seg_bytes;
+    const uint32_t grid = (uint32_t) ((nsegs + 255) / 256);
+    const uint8_t *p = static_cast<const uint8_t *>(d_src);
+    if (tile == 64) {
+        hipLaunchKernelGGL(sre_k_read_pattern<64>, dim3(grid), dim3(256), lds_bytes, stream, p, n, seg_bytes, d_sink);
+    } else if (tile == 128) {
+        hipLaunchKernelGGL(sre_k_read_pattern<128>, dim3(grid), dim3(256), lds_bytes, stream, p, n, seg_bytes, d_sink);
+    } else if (tile == 256) {
+        hipLaunchKernelGGL(sre_k_read_pattern<256>, dim3(grid), dim3(256), lds_bytes, stream, p, n, seg_bytes, d_sink);
+    } else {
+        return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
 /* ======================================================================= scan */
 
 namespace {
@@ -311,16 +371,25 @@ __device__ void resolve_fast_group(Walk &w, int64_t gpos, uint32_t s0, int64_t s
     w.cur_sp = sp;
 }
 
-/* stage one round (64 bytes of each of the 256 rows): the four 16-byte pieces
- * this lane fetches; rows shorter than a whole piece read as zeros (their lanes
- * finish on the exact path) */
+/* one row of a workgroup's staging: where the lane's segment (with its warm-up
+ * round in front) starts and which byte range of it may be read */
+struct __attribute__((aligned(16))) RowDesc {
+    uint64_t addr;      /* device address of row offset 0 */
+    int32_t  lo;        /* first readable offset */
+    int32_t  hi16;      /* last offset at which a whole 16-byte piece may start */
+};
+
+typedef uint32_t sre_u32x4 __attribute__((ext_vector_type(4)));
+typedef sre_u32x4 __attribute__((aligned(1))) sre_u32x4_unaligned;
+
 /* stage one round (TILE bytes of each of the 256 rows): the 16-byte pieces this
  * lane fetches; pieces outside a row's valid range read as zeros (their lanes
- * take the exact path there) */
+ * take the exact path there).  The loads are GLOBAL loads (address space 1) on
+ * purpose: a flat load also counts on lgkmcnt, so every wait for an LDS lookup
+ * in the consumer would wait for the prefetch as well. */
 template <int TILE>
 __device__ inline void
-tile_fetch(uint4 (&regs)[TILE / 16], const uint8_t *const *row_ptr, const int32_t *row_lo,
-           const int32_t *row_hi, uint32_t tid, uint32_t r)
+tile_fetch(uint4 (&regs)[TILE / 16], const RowDesc *rows, uint32_t tid, uint32_t r)
 {
     /* wave-private staging: the 64 lanes of a wave fetch the 64 rows of that
      * same wave, so no workgroup barrier is needed between rounds */
@@ -330,21 +399,15 @@ tile_fetch(uint4 (&regs)[TILE / 16], const uint8_t *const *row_ptr, const int32_
         const uint32_t piece = i * 64 + lane;
         const uint32_t row = wbase + piece / (TILE / 16), col = piece % (TILE / 16);
         const int32_t  off = (int32_t) (r * TILE + col * 16);
-        uint4          v = make_uint4(0, 0, 0, 0);
-        if (off >= row_lo[row] && off + 16 <= row_hi[row]) {
-            const uint8_t *src = row_ptr[row] + off;
-            if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
-                v = *reinterpret_cast<const uint4 *>(src);
-            } else {
-                uint32_t x[4];
-                for (int q = 0; q < 4; q++) {
-                    x[q] = (uint32_t) src[4 * q] | ((uint32_t) src[4 * q + 1] << 8)
-                           | ((uint32_t) src[4 * q + 2] << 16) | ((uint32_t) src[4 * q + 3] << 24);
-                }
-                v = make_uint4(x[0], x[1], x[2], x[3]);
-            }
+        const uint4    d = *reinterpret_cast<const uint4 *>(&rows[row]);
+        sre_u32x4      v = {0, 0, 0, 0};
+        if ((off >= (int32_t) d.z) & (off <= (int32_t) d.w)) {
+            const uint64_t a = (((uint64_t) d.y << 32) | d.x) + (uint64_t) (int64_t) off;
+            /* rows start wherever the stream does: the load may be unaligned,
+             * which the hardware handles */
+            v = *reinterpret_cast<const __attribute__((address_space(1))) sre_u32x4_unaligned *>(a);
         }
-        regs[i] = v;
+        regs[i] = make_uint4(v.x, v.y, v.z, v.w);
     }
 }
 
@@ -408,8 +471,7 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
     constexpr uint32_t ROWB = (TILE * BITS / 8 > 16) ? (TILE * BITS / 8 + 16) : (TILE * BITS / 8);   /* see tile_store */
     constexpr int      GIDX = 16 / STRIDE;           /* index bytes per 16 input bytes */
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    __shared__ const uint8_t *row_ptr[SRE_SCAN_BLOCK];
-    __shared__ int32_t        row_lo[SRE_SCAN_BLOCK], row_hi[SRE_SCAN_BLOCK];
+    __shared__ RowDesc rows[SRE_SCAN_BLOCK];
     __shared__ sre_scan_tables_t Ts;
 
     const uint32_t tid = threadIdx.x;
@@ -479,9 +541,10 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
     int64_t  seg_a = 0, seg_b = 0;
     uint32_t s_in = 0, seed = 0;
     bool     last_seg = false, warm = false;
-    row_ptr[tid] = nullptr;
-    row_lo[tid] = 0;
-    row_hi[tid] = 0;
+    RowDesc mine;
+    mine.addr = 0;
+    mine.lo = 0;
+    mine.hi16 = -1;                         /* nothing readable */
     if (active) {
         w.data = G.streams[sidx];
         w.n = (int64_t) G.lens[sidx];
@@ -525,10 +588,11 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
         }
         s_in = w.st;
         /* row = [seg_a - TILE, seg_b): the warm-up round, then the segment */
-        row_ptr[tid] = w.data + seg_a - TILE;
-        row_lo[tid] = warm ? 0 : TILE;
-        row_hi[tid] = (int32_t) (TILE + (seg_b - seg_a));
+        mine.addr = (uint64_t) reinterpret_cast<uintptr_t>(w.data) + (uint64_t) (seg_a - TILE);
+        mine.lo = warm ? 0 : TILE;
+        mine.hi16 = (int32_t) (TILE + (seg_b - seg_a)) - 16;
     }
+    rows[tid] = mine;
 
     /* pure-fast COUNT bookkeeping: the last 16-byte group that completed matches
      * without leaving the fast loop, while it still holds the segment's last
@@ -540,7 +604,7 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
     const uint32_t nrounds = 1 + G.seg_bytes / TILE;
     uint4          regs[TILE / 16];
     __syncthreads();                        /* row tables are complete */
-    tile_fetch<TILE>(regs, row_ptr, row_lo, row_hi, tid, 0);
+    tile_fetch<TILE>(regs, rows, tid, 0);
     for (uint32_t r = 0; r < nrounds; r++) {
         /* LDS operations of one wave execute in order; the fences only stop the
          * compiler from moving tile reads across the stores */
@@ -550,7 +614,7 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         /* next round's HBM loads fly while this round is consumed from LDS */
-        if (r + 1 < nrounds) tile_fetch<TILE>(regs, row_ptr, row_lo, row_hi, tid, r + 1);
+        if (r + 1 < nrounds) tile_fetch<TILE>(regs, rows, tid, r + 1);
 
         const bool warm_round = (r == 0);
         if (!active || w.finished || (warm_round && !warm)) continue;
@@ -1246,40 +1310,31 @@ sre_k_captures(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
 
 }  // namespace
 
+typedef void (*sre_scan_kernel_t)(const sre_scan_tables_t *, sre_scan_geom_t, sre_seg_summary_t *,
+                                  const int64_t *);
+
 template <int MODE, int TILE>
-static void
-launch_scan_bits(uint32_t bits, uint32_t grid, size_t shmem, hipStream_t stream,
-                 const sre_scan_tables_t *d_tab, sre_scan_geom_t geom, sre_seg_summary_t *d_sum,
-                 const int64_t *d_lo)
+static sre_scan_kernel_t
+scan_kernel_bits(uint32_t bits)
 {
     switch (bits) {
-    case 1:
-        hipLaunchKernelGGL((sre_k_scan<MODE, 1, TILE>), dim3(grid), dim3(SRE_SCAN_BLOCK), shmem,
-                           stream, d_tab, geom, d_sum, d_lo);
-        break;
-    case 2:
-        hipLaunchKernelGGL((sre_k_scan<MODE, 2, TILE>), dim3(grid), dim3(SRE_SCAN_BLOCK), shmem,
-                           stream, d_tab, geom, d_sum, d_lo);
-        break;
-    case 4:
-        hipLaunchKernelGGL((sre_k_scan<MODE, 4, TILE>), dim3(grid), dim3(SRE_SCAN_BLOCK), shmem,
-                           stream, d_tab, geom, d_sum, d_lo);
-        break;
-    default:
-        hipLaunchKernelGGL((sre_k_scan<MODE, 8, TILE>), dim3(grid), dim3(SRE_SCAN_BLOCK), shmem,
-                           stream, d_tab, geom, d_sum, d_lo);
-        break;
+    case 1: return sre_k_scan<MODE, 1, TILE>;
+    case 2: return sre_k_scan<MODE, 2, TILE>;
+    case 4: return sre_k_scan<MODE, 4, TILE>;
+    default: return sre_k_scan<MODE, 8, TILE>;
     }
 }
 
-template <int MODE>
-static void
-launch_scan_tile(uint32_t tile, uint32_t bits, uint32_t grid, size_t shmem, hipStream_t stream,
-                 const sre_scan_tables_t *d_tab, sre_scan_geom_t geom, sre_seg_summary_t *d_sum,
-                 const int64_t *d_lo)
+/* the variant that runs for these tables: [mode][class bits][tile] */
+static sre_scan_kernel_t
+scan_kernel(const sre_scan_tables_t *h_tab, uint32_t tile)
 {
-    if (tile == 128) launch_scan_bits<MODE, 128>(bits, grid, shmem, stream, d_tab, geom, d_sum, d_lo);
-    else launch_scan_bits<MODE, 64>(bits, grid, shmem, stream, d_tab, geom, d_sum, d_lo);
+    if (h_tab->mode == SRE_HIP_PIKE_COUNT) {
+        return tile == 128 ? scan_kernel_bits<SRE_HIP_PIKE_COUNT, 128>(h_tab->class_bits)
+                           : scan_kernel_bits<SRE_HIP_PIKE_COUNT, 64>(h_tab->class_bits);
+    }
+    return tile == 128 ? scan_kernel_bits<1, 128>(h_tab->class_bits)
+                       : scan_kernel_bits<1, 64>(h_tab->class_bits);
 }
 
 extern "C" size_t
@@ -1300,13 +1355,7 @@ sre_scan_blocks_per_cu(const sre_scan_tables_t *h_tab, uint32_t tile)
     int          n = 0;
     const size_t shmem = sre_scan_lds_bytes(h_tab, tile);
     hipError_t   e;
-    /* the variants differ little in registers: query the common one per mode */
-    if (h_tab->mode == SRE_HIP_PIKE_COUNT) {
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, sre_k_scan<SRE_HIP_PIKE_COUNT, 2, 64>,
-                                                         SRE_SCAN_BLOCK, shmem);
-    } else {
-        e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, sre_k_scan<1, 2, 64>, SRE_SCAN_BLOCK, shmem);
-    }
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, scan_kernel(h_tab, tile), SRE_SCAN_BLOCK, shmem);
     if (e != hipSuccess || n < 1) n = 1;
     if (n > 8) n = 8;
     return n;
@@ -1319,11 +1368,8 @@ sre_launch_scan(const sre_scan_tables_t *d_tab, sre_scan_tables_t h_tab, sre_sca
     if (geom.nsegs == 0) return hipSuccess;
     const uint32_t grid = (uint32_t) ((geom.nsegs + SRE_SCAN_BLOCK - 1) / SRE_SCAN_BLOCK);
     const size_t   shmem = sre_scan_lds_bytes(&h_tab, geom.tile);
-    if (h_tab.mode == SRE_HIP_PIKE_COUNT) {
-        launch_scan_tile<SRE_HIP_PIKE_COUNT>(geom.tile, h_tab.class_bits, grid, shmem, stream, d_tab, geom, d_sum, d_lo);
-    } else {
-        launch_scan_tile<1>(geom.tile, h_tab.class_bits, grid, shmem, stream, d_tab, geom, d_sum, d_lo);
-    }
+    hipLaunchKernelGGL(scan_kernel(&h_tab, geom.tile), dim3(grid), dim3(SRE_SCAN_BLOCK), shmem, stream,
+                       d_tab, geom, d_sum, d_lo);
     return hipGetLastError();
 }
 
