@@ -420,10 +420,10 @@ tile_fetch(uint4 (&regs)[TILE / 16], const RowDesc *rows, uint32_t tid, uint32_t
  * 16-byte pad). */
 template <int TILE, int BITS>
 __device__ inline void
-tile_store(const uint4 (&regs)[TILE / 16], uint8_t *tile, const uint8_t *clsl, uint32_t tid)
+tile_store(const uint4 (&regs)[TILE / 16], uint8_t *tile, const uint16_t (*clsx)[256], uint32_t tid)
 {
-    constexpr int      STRIDE = 8 / BITS;
     constexpr uint32_t ROWB = (TILE * BITS / 8 > 16) ? (TILE * BITS / 8 + 16) : (TILE * BITS / 8);
+    constexpr int      PER16 = 16 / BITS;       /* input bytes whose classes fill 16 bits */
     const uint32_t wbase = tid & ~63u, lane = tid & 63u;
 #pragma unroll
     for (uint32_t i = 0; i < TILE / 16; i++) {
@@ -433,25 +433,25 @@ tile_store(const uint4 (&regs)[TILE / 16], uint8_t *tile, const uint8_t *clsl, u
         if (BITS == 8) {
             *reinterpret_cast<uint4 *>(tile + row * ROWB + col * 16) = regs[i];
         } else {
-            uint32_t kk[16];
+            /* the class of byte b belongs at bit BITS * b of the piece's index
+             * word: table u already holds the class shifted to its place within
+             * a 16-bit half, so a half is the OR of its lookups */
+            uint32_t half[BITS];
 #pragma unroll
-            for (int b = 0; b < 16; b++) {
-                const uint32_t c = (words[b >> 2] >> ((b & 3) * 8)) & 0xffu;
-                kk[b] = (uint32_t) clsl[c];
+            for (int h = 0; h < BITS; h++) {
+                uint32_t v = 0;
+#pragma unroll
+                for (int u = 0; u < PER16; u++) {
+                    const int      b = h * PER16 + u;
+                    const uint32_t c = (words[b >> 2] >> ((b & 3) * 8)) & 0xffu;
+                    v |= (uint32_t) clsx[u][c];
+                }
+                half[h] = v;
             }
-            /* 16 / STRIDE index bytes */
-            uint32_t out[2] = {0, 0};
-#pragma unroll
-            for (int j = 0; j < 16 / STRIDE; j++) {
-                uint32_t idx = 0;
-#pragma unroll
-                for (int u = 0; u < STRIDE; u++) idx |= kk[j * STRIDE + u] << (u * BITS);
-                out[j >> 2] |= idx << ((j & 3) * 8);
-            }
-            uint8_t *dst = tile + row * ROWB + col * (16 / STRIDE);
-            if (BITS == 1) *reinterpret_cast<uint16_t *>(dst) = (uint16_t) out[0];
-            else if (BITS == 2) *reinterpret_cast<uint32_t *>(dst) = out[0];
-            else *reinterpret_cast<uint2 *>(dst) = make_uint2(out[0], out[1]);
+            uint8_t *dst = tile + row * ROWB + col * (2 * BITS);
+            if (BITS == 1) *reinterpret_cast<uint16_t *>(dst) = (uint16_t) half[0];
+            else if (BITS == 2) *reinterpret_cast<uint32_t *>(dst) = half[0] | (half[1] << 16);
+            else *reinterpret_cast<uint2 *>(dst) = make_uint2(half[0] | (half[1] << 16), half[2 % BITS] | (half[3 % BITS] << 16));
         }
     }
 }
@@ -472,6 +472,8 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
     constexpr int      GIDX = 16 / STRIDE;           /* index bytes per 16 input bytes */
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     __shared__ RowDesc rows[SRE_SCAN_BLOCK];
+    /* class map pre-shifted for each byte position of a 16-bit index half */
+    __shared__ uint16_t clsx[BITS == 8 ? 1 : 16 / BITS][256];
     __shared__ sre_scan_tables_t Ts;
 
     const uint32_t tid = threadIdx.x;
@@ -497,6 +499,10 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
     }
     for (uint32_t i = tid; i < tabp->nstates; i += SRE_SCAN_BLOCK) sfl[i] = tabp->state_flags[i];
     clsl[tid] = tabp->cls[tid];
+    if (BITS != 8) {
+#pragma unroll
+        for (int u = 0; u < 16 / BITS; u++) clsx[u][tid] = (uint16_t) ((uint32_t) tabp->cls[tid] << (BITS * u));
+    }
     __syncthreads();
     const sre_scan_tables_t &T = Ts;
 
@@ -610,7 +616,7 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
          * compiler from moving tile reads across the stores */
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        tile_store<TILE, BITS>(regs, tile, clsl, tid);
+        tile_store<TILE, BITS>(regs, tile, clsx, tid);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         /* next round's HBM loads fly while this round is consumed from LDS */
@@ -640,6 +646,29 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
                 roww[0] = v.x; roww[1] = v.y;
             } else {
                 roww[0] = *reinterpret_cast<const uint32_t *>(src);
+            }
+        }
+        /* the common round: every byte in range, no transition needs the exact
+         * path, (COUNT) no match completes — one straight chain of lookups */
+        if (base + TILE <= seg_b) {
+            uint32_t so = w.st * SRE_FAST_ROW_BYTES, acc = 0;
+#pragma unroll
+            for (int j = 0; j < TILE * BITS / 8; j++) {
+                const uint32_t idx = (roww[j >> 2] >> ((j & 3) * 8)) & 0xffu;
+                const uint32_t t = fast[(so >> 2) + idx];
+                acc |= t;
+                so = t & ~(SRE_FAST_ROW_BYTES - 1);
+            }
+            constexpr uint32_t EVENTS = SRE_FAST_SLOW
+                | (MODE == SRE_HIP_PIKE_COUNT ? (SRE_FAST_CNT_MASK << SRE_FAST_CNT_SHIFT) : 0u);
+            if (!(acc & EVENTS)) {
+                w.st = so / SRE_FAST_ROW_BYTES;
+                if (warm_round) {
+                    s_in = w.st;
+                    w.cur_sp = -1;
+                    if (w.st == 0) w.finished = true;
+                }
+                continue;
             }
         }
 #pragma unroll
