@@ -263,6 +263,10 @@ scan_geometry(sre_hip_scanner_t *sc, size_t nstreams)
         if (seg == 0 && e && atoi(e) > 0 && atoi(e) % 256 == 0) seg = (uint64_t) atoi(e);
     }
     if (seg != 0 && seg % tile != 0) tile = 64;
+    /* the wider tile must still fit the LDS budget the tables were admitted under */
+    if (tile != SRE_SCAN_TILE_DEFAULT && sre_scan_lds_bytes(&sc->tab->h, tile) + 8704 > 64 * 1024) {
+        tile = SRE_SCAN_TILE_DEFAULT;
+    }
     sc->geom.tile = tile;
     if (seg == 0) {
         /* as few rounds of resident workgroups as keep a segment <= ~16 KiB:

@@ -422,8 +422,9 @@ template <int TILE, int BITS>
 __device__ inline void
 tile_store(const uint4 (&regs)[TILE / 16], uint8_t *tile, const uint16_t (*clsx)[256], uint32_t tid)
 {
-    constexpr uint32_t ROWB = (TILE * BITS / 8 > 16) ? (TILE * BITS / 8 + 16) : (TILE * BITS / 8);
-    constexpr int      PER16 = 16 / BITS;       /* input bytes whose classes fill 16 bits */
+    constexpr int      STRIDE = 8 / BITS;                       /* input bytes per index */
+    constexpr uint32_t ROWRAW = (BITS == 8) ? TILE : TILE * BITS / 4;
+    constexpr uint32_t ROWB = ROWRAW > 16 ? ROWRAW + 16 : ROWRAW;
     const uint32_t wbase = tid & ~63u, lane = tid & 63u;
 #pragma unroll
     for (uint32_t i = 0; i < TILE / 16; i++) {
@@ -433,25 +434,26 @@ tile_store(const uint4 (&regs)[TILE / 16], uint8_t *tile, const uint16_t (*clsx)
         if (BITS == 8) {
             *reinterpret_cast<uint4 *>(tile + row * ROWB + col * 16) = regs[i];
         } else {
-            /* the class of byte b belongs at bit BITS * b of the piece's index
-             * word: table u already holds the class shifted to its place within
-             * a 16-bit half, so a half is the OR of its lookups */
-            uint32_t half[BITS];
+            /* one index per STRIDE input bytes, as a 16-bit word already scaled
+             * to a byte offset into a fast-table row: table u holds the class
+             * shifted to its place, so an index is the OR of its lookups */
+            constexpr int NIDX = 16 / STRIDE;                   /* indices per piece: 2 * BITS */
+            uint32_t      out[NIDX / 2];
 #pragma unroll
-            for (int h = 0; h < BITS; h++) {
+            for (int k = 0; k < NIDX; k++) {
                 uint32_t v = 0;
 #pragma unroll
-                for (int u = 0; u < PER16; u++) {
-                    const int      b = h * PER16 + u;
+                for (int u = 0; u < STRIDE; u++) {
+                    const int      b = k * STRIDE + u;
                     const uint32_t c = (words[b >> 2] >> ((b & 3) * 8)) & 0xffu;
                     v |= (uint32_t) clsx[u][c];
                 }
-                half[h] = v;
+                if (k & 1) out[k >> 1] |= v << 16; else out[k >> 1] = v;
             }
-            uint8_t *dst = tile + row * ROWB + col * (2 * BITS);
-            if (BITS == 1) *reinterpret_cast<uint16_t *>(dst) = (uint16_t) half[0];
-            else if (BITS == 2) *reinterpret_cast<uint32_t *>(dst) = half[0] | (half[1] << 16);
-            else *reinterpret_cast<uint2 *>(dst) = make_uint2(half[0] | (half[1] << 16), half[2 % BITS] | (half[3 % BITS] << 16));
+            uint8_t *dst = tile + row * ROWB + col * (2 * NIDX);
+            if (BITS == 1) *reinterpret_cast<uint32_t *>(dst) = out[0];
+            else if (BITS == 2) *reinterpret_cast<uint2 *>(dst) = make_uint2(out[0], out[1 % (NIDX / 2)]);
+            else *reinterpret_cast<uint4 *>(dst) = make_uint4(out[0], out[1 % (NIDX / 2)], out[2 % (NIDX / 2)], out[3 % (NIDX / 2)]);
         }
     }
 }
@@ -468,12 +470,15 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
            sre_seg_summary_t *__restrict__ sum, const int64_t *__restrict__ lo)
 {
     constexpr int      STRIDE = 8 / BITS;
-    constexpr uint32_t ROWB = (TILE * BITS / 8 > 16) ? (TILE * BITS / 8 + 16) : (TILE * BITS / 8);   /* see tile_store */
-    constexpr int      GIDX = 16 / STRIDE;           /* index bytes per 16 input bytes */
+    constexpr bool     WIDE = (BITS != 8);           /* 16-bit pre-scaled indices (see tile_store) */
+    constexpr uint32_t ROWRAW = WIDE ? TILE * BITS / 4 : TILE;
+    constexpr uint32_t ROWB = ROWRAW > 16 ? ROWRAW + 16 : ROWRAW;
+    constexpr int      GIDX = 16 / STRIDE;           /* indices per 16 input bytes */
+    typedef const __attribute__((address_space(3))) uint32_t *lds_u32_t;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     __shared__ RowDesc rows[SRE_SCAN_BLOCK];
-    /* class map pre-shifted for each byte position of a 16-bit index half */
-    __shared__ uint16_t clsx[BITS == 8 ? 1 : 16 / BITS][256];
+    /* class map pre-shifted for each byte position of an index, scaled by 4 */
+    __shared__ uint16_t clsx[BITS == 8 ? 1 : 8 / BITS][256];
     __shared__ sre_scan_tables_t Ts;
 
     const uint32_t tid = threadIdx.x;
@@ -491,8 +496,17 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
         Ts.trans = reinterpret_cast<const sre_dev_trans_t *>(trl);
         Ts.state_flags = sfl;
     }
+    /* In LDS an entry is [flags : 16][LDS byte address of the next state's row : 16]
+     * (the launch keeps all LDS below 64 KiB): a lookup address is then one add
+     * of two 16-bit fields, which the hardware selects in the add itself. */
+    const uint32_t fast_lds = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) uint8_t *) lds;
     for (uint32_t i = tid; i < tabp->fast_bytes / 16; i += SRE_SCAN_BLOCK) {
-        reinterpret_cast<uint4 *>(fast)[i] = reinterpret_cast<const uint4 *>(tabp->fast)[i];
+        uint4 e = reinterpret_cast<const uint4 *>(tabp->fast)[i];
+        e.x = ((e.x & 0xffu) << 16) | (fast_lds + (e.x & ~(SRE_FAST_ROW_BYTES - 1)));
+        e.y = ((e.y & 0xffu) << 16) | (fast_lds + (e.y & ~(SRE_FAST_ROW_BYTES - 1)));
+        e.z = ((e.z & 0xffu) << 16) | (fast_lds + (e.z & ~(SRE_FAST_ROW_BYTES - 1)));
+        e.w = ((e.w & 0xffu) << 16) | (fast_lds + (e.w & ~(SRE_FAST_ROW_BYTES - 1)));
+        reinterpret_cast<uint4 *>(fast)[i] = e;
     }
     for (uint32_t i = tid; i < tr_bytes / 8; i += SRE_SCAN_BLOCK) {
         reinterpret_cast<uint64_t *>(trl)[i] = reinterpret_cast<const uint64_t *>(tabp->trans)[i];
@@ -501,7 +515,7 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
     clsl[tid] = tabp->cls[tid];
     if (BITS != 8) {
 #pragma unroll
-        for (int u = 0; u < 16 / BITS; u++) clsx[u][tid] = (uint16_t) ((uint32_t) tabp->cls[tid] << (BITS * u));
+        for (int u = 0; u < 8 / BITS; u++) clsx[u][tid] = (uint16_t) ((uint32_t) tabp->cls[tid] << (BITS * u + 2));
     }
     __syncthreads();
     const sre_scan_tables_t &T = Ts;
@@ -631,7 +645,7 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
 
         /* the lane's whole row of indices in one go: rows are contiguous 16-byte
          * multiples, so these wide reads are bank-conflict free */
-        constexpr int ROWW = (TILE * BITS / 8 + 3) / 4;         /* dwords of indices per round */
+        constexpr int ROWW = (ROWRAW + 3) / 4;                  /* dwords of indices per round */
         uint32_t      roww[ROWW < 4 ? 4 : ROWW];
         {
             const uint8_t *src = tile + tid * ROWB;
@@ -648,21 +662,24 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
                 roww[0] = *reinterpret_cast<const uint32_t *>(src);
             }
         }
+        /* index j of the round as a byte offset into a fast-table row */
+        auto sidx = [&](int j) -> uint32_t {
+            return WIDE ? (roww[j >> 1] >> ((j & 1) * 16)) & 0xffffu
+                        : ((roww[j >> 2] >> ((j & 3) * 8)) & 0xffu) << 2;
+        };
         /* the common round: every byte in range, no transition needs the exact
          * path, (COUNT) no match completes — one straight chain of lookups */
         if (base + TILE <= seg_b) {
-            uint32_t so = w.st * SRE_FAST_ROW_BYTES, acc = 0;
+            uint32_t t = fast_lds + w.st * SRE_FAST_ROW_BYTES, acc = 0;
 #pragma unroll
             for (int j = 0; j < TILE * BITS / 8; j++) {
-                const uint32_t idx = (roww[j >> 2] >> ((j & 3) * 8)) & 0xffu;
-                const uint32_t t = fast[(so >> 2) + idx];
+                t = *(lds_u32_t) (uintptr_t) ((t & 0xffffu) + sidx(j));
                 acc |= t;
-                so = t & ~(SRE_FAST_ROW_BYTES - 1);
             }
-            constexpr uint32_t EVENTS = SRE_FAST_SLOW
-                | (MODE == SRE_HIP_PIKE_COUNT ? (SRE_FAST_CNT_MASK << SRE_FAST_CNT_SHIFT) : 0u);
+            constexpr uint32_t EVENTS = (SRE_FAST_SLOW
+                | (MODE == SRE_HIP_PIKE_COUNT ? (SRE_FAST_CNT_MASK << SRE_FAST_CNT_SHIFT) : 0u)) << 16;
             if (!(acc & EVENTS)) {
-                w.st = so / SRE_FAST_ROW_BYTES;
+                w.st = ((t & 0xffffu) - fast_lds) / SRE_FAST_ROW_BYTES;
                 if (warm_round) {
                     s_in = w.st;
                     w.cur_sp = -1;
@@ -682,28 +699,19 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
                 if (w.count != before) fc_pending = false;
                 break;
             }
-            /* this group's ready-made indices: GIDX bytes starting at byte q * GIDX */
-            uint32_t iw[4] = {0, 0, 0, 0};
+            /* this group's ready-made indices: GIDX of them starting at q * GIDX */
+            uint32_t t = fast_lds + w.st * SRE_FAST_ROW_BYTES, acc = 0, cnt = 0, lastb = 0;
 #pragma unroll
             for (int j = 0; j < GIDX; j++) {
-                const int      byte = (int) q * GIDX + j;
-                const uint32_t b = (roww[byte >> 2] >> ((byte & 3) * 8)) & 0xffu;
-                iw[j >> 2] |= b << ((j & 3) * 8);
-            }
-            uint32_t so = w.st * SRE_FAST_ROW_BYTES, acc = 0, cnt = 0, lastb = 0;
-#pragma unroll
-            for (int j = 0; j < GIDX; j++) {
-                const uint32_t idx = (iw[j >> 2] >> ((j & 3) * 8)) & 0xffu;
-                const uint32_t t = fast[(so >> 2) + idx];
+                t = *(lds_u32_t) (uintptr_t) ((t & 0xffffu) + sidx((int) q * GIDX + j));
                 acc |= t;
                 if (MODE == SRE_HIP_PIKE_COUNT) {
-                    const uint32_t c1 = (t >> SRE_FAST_CNT_SHIFT) & SRE_FAST_CNT_MASK;
+                    const uint32_t c1 = (t >> (16 + SRE_FAST_CNT_SHIFT)) & SRE_FAST_CNT_MASK;
                     cnt += c1;
-                    lastb = c1 ? (uint32_t) (j * STRIDE) + ((t >> SRE_FAST_LAST_SHIFT) & 7u) : lastb;
+                    lastb = c1 ? (uint32_t) (j * STRIDE) + ((t >> (16 + SRE_FAST_LAST_SHIFT)) & 7u) : lastb;
                 }
-                so = t & ~(SRE_FAST_ROW_BYTES - 1);
             }
-            if (acc & SRE_FAST_SLOW) {
+            if (acc & (SRE_FAST_SLOW << 16)) {
                 const int64_t before = w.count;
                 slow_run<MODE>(w, gp, gp + 16, warm_round, seed);
                 if (w.count != before) fc_pending = false;
@@ -723,7 +731,7 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
                         w.cur_sp = gp + lastb + 1;
                     }
                 }
-                w.st = so / SRE_FAST_ROW_BYTES;
+                w.st = ((t & 0xffffu) - fast_lds) / SRE_FAST_ROW_BYTES;
             }
         }
         if (warm_round) {
@@ -1370,7 +1378,8 @@ extern "C" size_t
 sre_scan_lds_bytes(const sre_scan_tables_t *h_tab, uint32_t tile)
 {
     const size_t tr = (size_t) h_tab->nstates * (h_tab->ncls + 1) * sizeof(sre_dev_trans_t);
-    size_t rowb = (size_t) tile * h_tab->class_bits / 8;
+    /* index tile row: raw bytes (8 class bits) or 16-bit scaled indices */
+    size_t rowb = h_tab->class_bits == 8 ? (size_t) tile : (size_t) tile * h_tab->class_bits / 4;
     if (rowb > 16) rowb += 16;
     return (size_t) h_tab->fast_bytes + 256 + tr + ((h_tab->nstates + 15u) & ~15u) + 16
            + (size_t) SRE_SCAN_BLOCK * rowb;

@@ -154,7 +154,7 @@ sre_scan_tables_build(const sre_program_t *prog, const sre_dfa_t *d, int mode, c
         /* both LDS-resident kernels must fit the 64 KiB a launch may ask for
          * without opting in; otherwise the exact VM engine takes the program */
         const size_t tr = ((size_t) d->nstates * nsym + 3) * sizeof(sre_dev_trans_t);
-        const size_t scan_lds = sre_scan_lds_bytes(&h, 128) + 4096 + 8192 + 512;   /* + static: rows, class tables, header */
+        const size_t scan_lds = sre_scan_lds_bytes(&h, SRE_SCAN_TILE_DEFAULT) + 4096 + 4096 + 512;   /* + static: rows, class tables, header */
         const size_t cap_lds = (size_t) h.fast_bytes + 256 + tr + (size_t) h.lin_total * 9
                                + ((size_t) d->nstates + 1 + h.list_total) * 4 + 16 + 512;
         if (scan_lds > 64 * 1024 || cap_lds > 64 * 1024) {
