@@ -253,26 +253,15 @@ scan_geometry(sre_hip_scanner_t *sc, size_t nstreams)
     uint64_t total = 0;
     for (size_t i = 0; i < nstreams; i++) total += sc->h_lens[i];
     uint64_t seg = sc->seg_override;
-    uint32_t tile = SRE_SCAN_TILE_DEFAULT;
-    {
-        const char *e = getenv("SRE_HIP_SCAN_TILE");      /* experiment knob: 64 / 128 / 256 */
-        if (e && (atoi(e) == 64 || atoi(e) == 128)) tile = (uint32_t) atoi(e);
-    }
     {
         const char *e = getenv("SRE_HIP_SEG_BYTES");        /* experiment knob */
         if (seg == 0 && e && atoi(e) > 0 && atoi(e) % 256 == 0) seg = (uint64_t) atoi(e);
     }
-    if (seg != 0 && seg % tile != 0) tile = 64;
-    /* the wider tile must still fit the LDS budget the tables were admitted under */
-    if (tile != SRE_SCAN_TILE_DEFAULT && sre_scan_lds_bytes(&sc->tab->h, tile) + 8704 > 64 * 1024) {
-        tile = SRE_SCAN_TILE_DEFAULT;
-    }
-    sc->geom.tile = tile;
     if (seg == 0) {
         /* as few rounds of resident workgroups as keep a segment <= ~16 KiB:
          * longer segments mean fewer summaries to verify, shorter ones keep
          * every CU busy; measured flat between 5.5 and 16 KiB on MI355X */
-        if (sc->blocks_per_cu == 0) sc->blocks_per_cu = sre_scan_blocks_per_cu(&sc->tab->h, tile);
+        if (sc->blocks_per_cu == 0) sc->blocks_per_cu = sre_scan_blocks_per_cu(&sc->tab->h);
         const uint64_t resident = 256ull * (uint64_t) sc->blocks_per_cu * SRE_SCAN_BLOCK;
         uint64_t       rounds = (total + resident * 16384 - 1) / (resident * 16384);
         if (rounds < 1) rounds = 1;

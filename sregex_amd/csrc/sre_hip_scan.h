@@ -29,8 +29,10 @@
 
 #define SRE_SCAN_MAX_STATES   64u     /* LDS budget: 64 KiB of fast table */
 #define SRE_SCAN_BLOCK        256u    /* lanes = segments per workgroup */
-#define SRE_SCAN_TILE_DEFAULT 64u     /* bytes per lane per LDS round (measured best of 64/128/256) */
-#define SRE_SCAN_SEG_ALIGN    256u    /* segments are a multiple of every tile size */
+#define SRE_SCAN_LDS_LIMIT    (128u * 1024u)  /* dynamic LDS a scan workgroup may ask for (160 KiB per CU) */
+#define SRE_SCAN_ROUND        64u     /* bytes a lane consumes per LDS round */
+#define SRE_SCAN_LINE         128u    /* staging granule: whole lines, half a wave per stage; also the warm-up */
+#define SRE_SCAN_SEG_ALIGN    256u    /* segments are a multiple of the line size */
 
 /* full transition record (global memory; slow path and lineage kernels) */
 typedef struct {
@@ -130,7 +132,6 @@ typedef struct {
     uint32_t nstreams;
     uint32_t seg_bytes;
     uint64_t nsegs;
-    uint32_t tile;                  /* 64 or 128 bytes per lane per LDS round */
     uint32_t init_variant;          /* SRE_DFA_INIT_* of the search that starts at offset 0 */
 } sre_scan_geom_t;
 
@@ -145,8 +146,8 @@ hipError_t sre_launch_read_pattern(const void *d_src, uint64_t n, uint32_t seg_b
     uint32_t tile, uint32_t lds_bytes, uint32_t *d_sink, hipStream_t stream);
 
 /* dynamic LDS one scan workgroup needs (fast table + class map + tile) */
-size_t sre_scan_lds_bytes(const sre_scan_tables_t *h_tab, uint32_t tile);
-int sre_scan_blocks_per_cu(const sre_scan_tables_t *h_tab, uint32_t tile);
+size_t sre_scan_lds_bytes(const sre_scan_tables_t *h_tab);
+int sre_scan_blocks_per_cu(const sre_scan_tables_t *h_tab);
 
 /* control pass over segments [lo[s], nseg_s) of every stream; lo == NULL: all.
  * carry[s] (with lo) = exact entry of segment lo[s] taken from summaries[lo[s]-1]. */

@@ -382,23 +382,31 @@ struct __attribute__((aligned(16))) RowDesc {
 typedef uint32_t sre_u32x4 __attribute__((ext_vector_type(4)));
 typedef sre_u32x4 __attribute__((aligned(1))) sre_u32x4_unaligned;
 
-/* stage one round (TILE bytes of each of the 256 rows): the 16-byte pieces this
- * lane fetches; pieces outside a row's valid range read as zeros (their lanes
- * take the exact path there).  The loads are GLOBAL loads (address space 1) on
- * purpose: a flat load also counts on lgkmcnt, so every wait for an LDS lookup
- * in the consumer would wait for the prefetch as well. */
-template <int TILE>
+/*
+ * Staging works on whole 128-byte lines although a lane consumes 64 bytes per
+ * round: stage s brings ONE line for each row of half a wave — rows 0..31 of the
+ * wave at even stages, rows 32..63 at odd stages — as 4 x 16-byte pieces per
+ * lane, 8 adjacent lanes per line.  Every line is requested exactly once and in
+ * one piece (two 64-byte requests for the same line one round apart each go to
+ * HBM when the L2 has dropped the line in between), and the staging registers
+ * stay at 64 bytes per lane.  The upper half-wave therefore runs one round
+ * behind the lower one.  Pieces outside a row's valid range read as zeros
+ * (their lanes take the exact path there).  The loads are GLOBAL loads
+ * (address space 1) on purpose: a flat load also counts on lgkmcnt, so every
+ * wait for an LDS lookup in the consumer would wait for the prefetch as well.
+ */
 __device__ inline void
-tile_fetch(uint4 (&regs)[TILE / 16], const RowDesc *rows, uint32_t tid, uint32_t r)
+tile_fetch(uint4 (&regs)[4], const RowDesc *rows, uint32_t tid, uint32_t stage)
 {
-    /* wave-private staging: the 64 lanes of a wave fetch the 64 rows of that
-     * same wave, so no workgroup barrier is needed between rounds */
-    const uint32_t wbase = tid & ~63u, lane = tid & 63u;
+    /* wave-private staging: the 64 lanes of a wave fetch rows of that same
+     * wave, so no workgroup barrier is needed between rounds */
+    const uint32_t wbase = (tid & ~63u) + (stage & 1u) * 32u, lane = tid & 63u;
+    const int32_t  line_off = (int32_t) ((stage >> 1) * SRE_SCAN_LINE);
 #pragma unroll
-    for (uint32_t i = 0; i < TILE / 16; i++) {
+    for (uint32_t i = 0; i < 4; i++) {
         const uint32_t piece = i * 64 + lane;
-        const uint32_t row = wbase + piece / (TILE / 16), col = piece % (TILE / 16);
-        const int32_t  off = (int32_t) (r * TILE + col * 16);
+        const uint32_t row = wbase + piece / 8, col = piece % 8;
+        const int32_t  off = line_off + (int32_t) (col * 16);
         const uint4    d = *reinterpret_cast<const uint4 *>(&rows[row]);
         sre_u32x4      v = {0, 0, 0, 0};
         if ((off >= (int32_t) d.z) & (off <= (int32_t) d.w)) {
@@ -411,34 +419,38 @@ tile_fetch(uint4 (&regs)[TILE / 16], const RowDesc *rows, uint32_t tid, uint32_t
     }
 }
 
-/* Stage one round into LDS.  The raw bytes are classified and packed HERE, by
- * the lane that fetched them (16 independent class lookups per piece), so the
- * tile holds ready-made fast-table indices — 8 / BITS input bytes per index
- * byte — and the consuming lane's dependent chain is table lookups only.  A row
- * is TILE * BITS / 8 bytes; rows are contiguous, which makes the consumer's
- * wide read conflict-free without padding (rows longer than 16 bytes keep a
- * 16-byte pad). */
-template <int TILE, int BITS>
+/* Stage one line per row of half a wave into LDS.  The raw bytes are classified
+ * and packed HERE, by the lane that fetched them (16 independent class lookups
+ * per piece), so the tile holds ready-made fast-table indices and the consuming
+ * lane's dependent chain is table lookups only.  A tile row holds the two
+ * 64-byte halves of the row's current line back to back plus a 16-byte pad,
+ * which makes the consumer's 16-byte reads bank-conflict free. */
+template <int BITS>
 __device__ inline void
-tile_store(const uint4 (&regs)[TILE / 16], uint8_t *tile, const uint16_t (*clsx)[256], uint32_t tid)
+tile_store(const uint4 (&regs)[4], uint8_t *tile, const uint16_t (*clsx)[256], uint32_t tid, uint32_t stage)
 {
     constexpr int      STRIDE = 8 / BITS;                       /* input bytes per index */
-    constexpr uint32_t ROWRAW = (BITS == 8) ? TILE : TILE * BITS / 4;
-    constexpr uint32_t ROWB = ROWRAW > 16 ? ROWRAW + 16 : ROWRAW;
-    const uint32_t wbase = tid & ~63u, lane = tid & 63u;
+    constexpr bool     WIDE = (BITS <= 2);                      /* 16-bit pre-scaled indices */
+    constexpr uint32_t HALFB = SRE_SCAN_ROUND / STRIDE * (WIDE ? 2 : 1);
+    constexpr uint32_t ROWB = 2 * HALFB + 16;
+    constexpr uint32_t PIECEB = HALFB / 4;                      /* index bytes per 16 input bytes */
+    const uint32_t wbase = (tid & ~63u) + (stage & 1u) * 32u, lane = tid & 63u;
 #pragma unroll
-    for (uint32_t i = 0; i < TILE / 16; i++) {
+    for (uint32_t i = 0; i < 4; i++) {
         const uint32_t piece = i * 64 + lane;
-        const uint32_t row = wbase + piece / (TILE / 16), col = piece % (TILE / 16);
+        const uint32_t row = wbase + piece / 8, col = piece % 8;
         const uint32_t words[4] = {regs[i].x, regs[i].y, regs[i].z, regs[i].w};
+        uint8_t       *dst = tile + row * ROWB + col * PIECEB;
         if (BITS == 8) {
-            *reinterpret_cast<uint4 *>(tile + row * ROWB + col * 16) = regs[i];
+            *reinterpret_cast<uint4 *>(dst) = regs[i];
         } else {
-            /* one index per STRIDE input bytes, as a 16-bit word already scaled
-             * to a byte offset into a fast-table row: table u holds the class
-             * shifted to its place, so an index is the OR of its lookups */
-            constexpr int NIDX = 16 / STRIDE;                   /* indices per piece: 2 * BITS */
-            uint32_t      out[NIDX / 2];
+            /* one index per STRIDE input bytes: table u holds the class shifted
+             * to its place, so an index is the OR of its lookups.  With few
+             * classes the index is stored as a 16-bit word already scaled to a
+             * byte offset into a fast-table row, otherwise as a byte. */
+            constexpr int NIDX = 16 / STRIDE;                   /* indices per piece */
+            constexpr int PERW = WIDE ? 2 : 4;                  /* indices per 32-bit word */
+            uint32_t      out[NIDX / PERW];
 #pragma unroll
             for (int k = 0; k < NIDX; k++) {
                 uint32_t v = 0;
@@ -448,31 +460,32 @@ tile_store(const uint4 (&regs)[TILE / 16], uint8_t *tile, const uint16_t (*clsx)
                     const uint32_t c = (words[b >> 2] >> ((b & 3) * 8)) & 0xffu;
                     v |= (uint32_t) clsx[u][c];
                 }
-                if (k & 1) out[k >> 1] |= v << 16; else out[k >> 1] = v;
+                if (k % PERW) out[k / PERW] |= v << ((k % PERW) * (32 / PERW)); else out[k / PERW] = v;
             }
-            uint8_t *dst = tile + row * ROWB + col * (2 * NIDX);
-            if (BITS == 1) *reinterpret_cast<uint32_t *>(dst) = out[0];
-            else if (BITS == 2) *reinterpret_cast<uint2 *>(dst) = make_uint2(out[0], out[1 % (NIDX / 2)]);
-            else *reinterpret_cast<uint4 *>(dst) = make_uint4(out[0], out[1 % (NIDX / 2)], out[2 % (NIDX / 2)], out[3 % (NIDX / 2)]);
+            if (PIECEB == 4) *reinterpret_cast<uint32_t *>(dst) = out[0];
+            else *reinterpret_cast<uint2 *>(dst) = make_uint2(out[0], out[1 % (NIDX / PERW)]);
         }
     }
 }
 
 /*
  * BITS = class bits per input byte: one fast-table lookup advances 8 / BITS
- * bytes (BITS == 8: the index is the byte itself).  TILE = bytes per lane per
- * LDS round.  Round 0 is the speculative warm-up: the TILE bytes in front of
- * the segment, walked with the same fast loop, nothing recorded.
+ * bytes (BITS == 8: the index is the byte itself).  A lane consumes
+ * SRE_SCAN_ROUND (64) bytes per round.  Rounds 0 and 1 are the speculative
+ * warm-up: the 128 bytes (one line) in front of the segment, walked with the
+ * same fast loop, nothing recorded.
  */
-template <int MODE, int BITS, int TILE>
-__global__ __launch_bounds__(SRE_SCAN_BLOCK) void
+template <int MODE, int BITS>
+__global__ __launch_bounds__(SRE_SCAN_BLOCK, MODE == SRE_HIP_PIKE_COUNT ? 3 : 4) void
 sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
            sre_seg_summary_t *__restrict__ sum, const int64_t *__restrict__ lo)
 {
+    constexpr int      TILE = SRE_SCAN_ROUND;
+    constexpr int      WARM = SRE_SCAN_LINE;         /* warm-up bytes in front of a segment */
     constexpr int      STRIDE = 8 / BITS;
-    constexpr bool     WIDE = (BITS != 8);           /* 16-bit pre-scaled indices (see tile_store) */
-    constexpr uint32_t ROWRAW = WIDE ? TILE * BITS / 4 : TILE;
-    constexpr uint32_t ROWB = ROWRAW > 16 ? ROWRAW + 16 : ROWRAW;
+    constexpr bool     WIDE = (BITS <= 2);           /* 16-bit pre-scaled indices (see tile_store) */
+    constexpr uint32_t ROWRAW = TILE / STRIDE * (WIDE ? 2 : 1);  /* index bytes per round */
+    constexpr uint32_t ROWB = 2 * ROWRAW + 16;       /* see tile_store */
     constexpr int      GIDX = 16 / STRIDE;           /* indices per 16 input bytes */
     typedef const __attribute__((address_space(3))) uint32_t *lds_u32_t;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -515,7 +528,7 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
     clsl[tid] = tabp->cls[tid];
     if (BITS != 8) {
 #pragma unroll
-        for (int u = 0; u < 8 / BITS; u++) clsx[u][tid] = (uint16_t) ((uint32_t) tabp->cls[tid] << (BITS * u + 2));
+        for (int u = 0; u < 8 / BITS; u++) clsx[u][tid] = (uint16_t) ((uint32_t) tabp->cls[tid] << (BITS * u + (WIDE ? 2 : 0)));
     }
     __syncthreads();
     const sre_scan_tables_t &T = Ts;
@@ -593,7 +606,7 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
                 w.ev_kind = T.trans[(size_t) c.pe_state * (T.ncls + 1) + c.pe_sym].kind;
             }
         } else {
-            /* speculative: assume the state reached by a warm-up over the TILE
+            /* speculative: assume the state reached by a warm-up over the WARM
              * bytes in front of the segment.  In a fix-up round the warm-up
              * starts from the state the verified prefix ended in (it tends to
              * recur), otherwise from the initial state. */
@@ -607,10 +620,11 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
             w.st = seed;
         }
         s_in = w.st;
-        /* row = [seg_a - TILE, seg_b): the warm-up round, then the segment */
-        mine.addr = (uint64_t) reinterpret_cast<uintptr_t>(w.data) + (uint64_t) (seg_a - TILE);
-        mine.lo = warm ? 0 : TILE;
-        mine.hi16 = (int32_t) (TILE + (seg_b - seg_a)) - 16;
+        /* row = [seg_a - WARM, seg_b): the warm-up rounds, then the segment */
+        mine.addr = (uint64_t) reinterpret_cast<uintptr_t>(w.data) + (uint64_t) (seg_a - WARM);
+        /* the warm-up of a stream's second segment may be cut short by the stream start */
+        mine.lo = warm ? (seg_a >= WARM ? 0 : (int32_t) (WARM - seg_a)) : WARM;
+        mine.hi16 = (int32_t) (WARM + (seg_b - seg_a)) - 16;
     }
     rows[tid] = mine;
 
@@ -621,25 +635,30 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
     uint32_t fc_s0 = 0;
     bool     fc_pending = false;
 
-    const uint32_t nrounds = 1 + G.seg_bytes / TILE;
-    uint4          regs[TILE / 16];
+    /* rounds per lane; the upper half of every wave runs one round behind the
+     * lower half (see tile_fetch), hence one more iteration than rounds */
+    const uint32_t nrounds = WARM / TILE + G.seg_bytes / TILE;
+    const uint32_t lag = (tid >> 5) & 1u;
+    uint4          regs[4];
     __syncthreads();                        /* row tables are complete */
-    tile_fetch<TILE>(regs, rows, tid, 0);
-    for (uint32_t r = 0; r < nrounds; r++) {
+    tile_fetch(regs, rows, tid, 0);
+    for (uint32_t s = 0; s <= nrounds; s++) {
         /* LDS operations of one wave execute in order; the fences only stop the
          * compiler from moving tile reads across the stores */
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        tile_store<TILE, BITS>(regs, tile, clsx, tid);
+        tile_store<BITS>(regs, tile, clsx, tid, s);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        /* next round's HBM loads fly while this round is consumed from LDS */
-        if (r + 1 < nrounds) tile_fetch<TILE>(regs, rows, tid, r + 1);
+        /* the next stage's HBM loads fly while this round is consumed from LDS */
+        if (s < nrounds) tile_fetch(regs, rows, tid, s + 1);
 
-        const bool warm_round = (r == 0);
+        if (s < lag || s - lag >= nrounds) continue;
+        const uint32_t r = s - lag;                     /* this lane's round */
+        const bool     warm_round = (r < WARM / TILE);
         if (!active || w.finished || (warm_round && !warm)) continue;
-        const int64_t base = seg_a + ((int64_t) r - 1) * TILE;
-        if (base >= seg_b) continue;
+        const int64_t base = seg_a - WARM + (int64_t) r * TILE;
+        if (base >= seg_b || base < 0) continue;
         w.anchor_pos = warm_round ? -1 : base;
         w.anchor_state = w.st;
 
@@ -648,7 +667,7 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
         constexpr int ROWW = (ROWRAW + 3) / 4;                  /* dwords of indices per round */
         uint32_t      roww[ROWW < 4 ? 4 : ROWW];
         {
-            const uint8_t *src = tile + tid * ROWB;
+            const uint8_t *src = tile + tid * ROWB + (r & 1u) * ROWRAW;
             if (ROWW >= 4) {
 #pragma unroll
                 for (int x = 0; x < ROWW / 4; x++) {
@@ -680,7 +699,7 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
                 | (MODE == SRE_HIP_PIKE_COUNT ? (SRE_FAST_CNT_MASK << SRE_FAST_CNT_SHIFT) : 0u)) << 16;
             if (!(acc & EVENTS)) {
                 w.st = ((t & 0xffffu) - fast_lds) / SRE_FAST_ROW_BYTES;
-                if (warm_round) {
+                if (r + 1 == WARM / TILE) {
                     s_in = w.st;
                     w.cur_sp = -1;
                     if (w.st == 0) w.finished = true;
@@ -734,8 +753,8 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
                 w.st = ((t & 0xffffu) - fast_lds) / SRE_FAST_ROW_BYTES;
             }
         }
-        if (warm_round) {
-            /* what this lane assumes about its entry */
+        if (r + 1 == WARM / TILE) {
+            /* end of the warm-up: what this lane assumes about its entry */
             s_in = w.st;
             w.cur_sp = -1;                  /* search starts seen in the warm-up are not verified */
             if (w.st == 0) w.finished = true;
@@ -1350,50 +1369,46 @@ sre_k_captures(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
 typedef void (*sre_scan_kernel_t)(const sre_scan_tables_t *, sre_scan_geom_t, sre_seg_summary_t *,
                                   const int64_t *);
 
-template <int MODE, int TILE>
+template <int MODE>
 static sre_scan_kernel_t
 scan_kernel_bits(uint32_t bits)
 {
     switch (bits) {
-    case 1: return sre_k_scan<MODE, 1, TILE>;
-    case 2: return sre_k_scan<MODE, 2, TILE>;
-    case 4: return sre_k_scan<MODE, 4, TILE>;
-    default: return sre_k_scan<MODE, 8, TILE>;
+    case 1: return sre_k_scan<MODE, 1>;
+    case 2: return sre_k_scan<MODE, 2>;
+    case 4: return sre_k_scan<MODE, 4>;
+    default: return sre_k_scan<MODE, 8>;
     }
 }
 
-/* the variant that runs for these tables: [mode][class bits][tile] */
+/* the variant that runs for these tables: [mode][class bits] */
 static sre_scan_kernel_t
-scan_kernel(const sre_scan_tables_t *h_tab, uint32_t tile)
+scan_kernel(const sre_scan_tables_t *h_tab)
 {
-    if (h_tab->mode == SRE_HIP_PIKE_COUNT) {
-        return tile == 128 ? scan_kernel_bits<SRE_HIP_PIKE_COUNT, 128>(h_tab->class_bits)
-                           : scan_kernel_bits<SRE_HIP_PIKE_COUNT, 64>(h_tab->class_bits);
-    }
-    return tile == 128 ? scan_kernel_bits<1, 128>(h_tab->class_bits)
-                       : scan_kernel_bits<1, 64>(h_tab->class_bits);
+    return h_tab->mode == SRE_HIP_PIKE_COUNT ? scan_kernel_bits<SRE_HIP_PIKE_COUNT>(h_tab->class_bits)
+                                             : scan_kernel_bits<1>(h_tab->class_bits);
 }
 
 extern "C" size_t
-sre_scan_lds_bytes(const sre_scan_tables_t *h_tab, uint32_t tile)
+sre_scan_lds_bytes(const sre_scan_tables_t *h_tab)
 {
     const size_t tr = (size_t) h_tab->nstates * (h_tab->ncls + 1) * sizeof(sre_dev_trans_t);
-    /* index tile row: raw bytes (8 class bits) or 16-bit scaled indices */
-    size_t rowb = h_tab->class_bits == 8 ? (size_t) tile : (size_t) tile * h_tab->class_bits / 4;
-    if (rowb > 16) rowb += 16;
+    /* index tile row: the two halves of a line as raw bytes (8 class bits) or
+     * 16-bit scaled indices, plus the pad */
+    const size_t half = (size_t) SRE_SCAN_ROUND * h_tab->class_bits / 8 * (h_tab->class_bits <= 2 ? 2 : 1);
     return (size_t) h_tab->fast_bytes + 256 + tr + ((h_tab->nstates + 15u) & ~15u) + 16
-           + (size_t) SRE_SCAN_BLOCK * rowb;
+           + (size_t) SRE_SCAN_BLOCK * (2 * half + 16);
 }
 
 /* workgroups of the scan kernel one CU can hold (registers and LDS), for the
  * geometry heuristic */
 extern "C" int
-sre_scan_blocks_per_cu(const sre_scan_tables_t *h_tab, uint32_t tile)
+sre_scan_blocks_per_cu(const sre_scan_tables_t *h_tab)
 {
     int          n = 0;
-    const size_t shmem = sre_scan_lds_bytes(h_tab, tile);
+    const size_t shmem = sre_scan_lds_bytes(h_tab);
     hipError_t   e;
-    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, scan_kernel(h_tab, tile), SRE_SCAN_BLOCK, shmem);
+    e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, scan_kernel(h_tab), SRE_SCAN_BLOCK, shmem);
     if (e != hipSuccess || n < 1) n = 1;
     if (n > 8) n = 8;
     return n;
@@ -1405,8 +1420,20 @@ sre_launch_scan(const sre_scan_tables_t *d_tab, sre_scan_tables_t h_tab, sre_sca
 {
     if (geom.nsegs == 0) return hipSuccess;
     const uint32_t grid = (uint32_t) ((geom.nsegs + SRE_SCAN_BLOCK - 1) / SRE_SCAN_BLOCK);
-    const size_t   shmem = sre_scan_lds_bytes(&h_tab, geom.tile);
-    hipLaunchKernelGGL(scan_kernel(&h_tab, geom.tile), dim3(grid), dim3(SRE_SCAN_BLOCK), shmem, stream,
+    const size_t   shmem = sre_scan_lds_bytes(&h_tab);
+    if (shmem > 48 * 1024) {
+        /* more than the default dynamic LDS limit: opt in (once per variant) */
+        static bool raised[2][9];
+        bool       &done = raised[h_tab.mode == SRE_HIP_PIKE_COUNT][h_tab.class_bits & 8 ? 8 : h_tab.class_bits];
+        if (!done) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(scan_kernel(&h_tab)),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               SRE_SCAN_LDS_LIMIT);
+            if (e != hipSuccess) return e;
+            done = true;
+        }
+    }
+    hipLaunchKernelGGL(scan_kernel(&h_tab), dim3(grid), dim3(SRE_SCAN_BLOCK), shmem, stream,
                        d_tab, geom, d_sum, d_lo);
     return hipGetLastError();
 }

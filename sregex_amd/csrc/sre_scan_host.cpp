@@ -151,13 +151,16 @@ sre_scan_tables_build(const sre_program_t *prog, const sre_dfa_t *d, int mode, c
     h.list_total = (uint32_t) d->list_pcs.size();
 
     {
-        /* both LDS-resident kernels must fit the 64 KiB a launch may ask for
-         * without opting in; otherwise the exact VM engine takes the program */
+        /* the scan kernel addresses its fast table (first in dynamic LDS, behind
+         * at most 8.5 KiB of static LDS) with 16-bit LDS addresses and may ask
+         * for SRE_SCAN_LDS_LIMIT in all; the capture walker stays within the
+         * default 64 KiB.  Otherwise the exact VM engine takes the program. */
         const size_t tr = ((size_t) d->nstates * nsym + 3) * sizeof(sre_dev_trans_t);
-        const size_t scan_lds = sre_scan_lds_bytes(&h, SRE_SCAN_TILE_DEFAULT) + 4096 + 4096 + 512;   /* + static: rows, class tables, header */
+        const size_t scan_lds = sre_scan_lds_bytes(&h);
+        const size_t fast_end = (size_t) h.fast_bytes + 4096 + 4096 + 512;
         const size_t cap_lds = (size_t) h.fast_bytes + 256 + tr + (size_t) h.lin_total * 9
                                + ((size_t) d->nstates + 1 + h.list_total) * 4 + 16 + 512;
-        if (scan_lds > 64 * 1024 || cap_lds > 64 * 1024) {
+        if (scan_lds > SRE_SCAN_LDS_LIMIT || fast_end > 64 * 1024 || cap_lds > 64 * 1024) {
             *why = "automaton tables exceed the LDS budget of the scanner";
             delete t;
             return NULL;
