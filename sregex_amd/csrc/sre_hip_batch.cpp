@@ -54,23 +54,28 @@ struct sre_hip_scanner_s {
     int                       fixup_rounds;     /* of the last scan (diagnostics) */
     hipEvent_t                ev0, ev1;         /* around the dominant scan kernel */
     int                       ev_valid;
+    /* results of a call travel to pinned host memory as part of the enqueued
+     * work; results() waits for this event only, so a caller can queue the
+     * next buffer (on another scanner) before collecting */
+    sre_int_t                *h_records;
+    hipEvent_t                ev_done;
+    /* d_ptrs / d_lens / d_seg_first live in ONE device block (h_* in one pinned
+     * block) and d_records / d_status in another, laid out per call, so that a
+     * call costs one small copy in and one out */
+    uint64_t                 *d_in, *h_in;
+    unsigned char            *d_out, *h_out;
 };
 
 static void
 scanner_release(void *data)
 {
     sre_hip_scanner_t *sc = static_cast<sre_hip_scanner_t *>(data);
-    if (sc->d_ptrs) (void) hipFree(sc->d_ptrs);
-    if (sc->d_lens) (void) hipFree(sc->d_lens);
-    if (sc->d_records) (void) hipFree(sc->d_records);
+    if (sc->d_in) (void) hipFree(sc->d_in);
+    if (sc->h_in) (void) hipHostFree(sc->h_in);
+    if (sc->d_out) (void) hipFree(sc->d_out);
+    if (sc->h_out) (void) hipHostFree(sc->h_out);
     if (sc->d_ctx) (void) hipFree(sc->d_ctx);
-    if (sc->h_lens) (void) hipHostFree(sc->h_lens);
-    if (sc->h_ptrs) (void) hipHostFree(sc->h_ptrs);
-    if (sc->d_seg_first) (void) hipFree(sc->d_seg_first);
-    if (sc->h_seg_first) (void) hipHostFree(sc->h_seg_first);
     if (sc->d_sum) (void) hipFree(sc->d_sum);
-    if (sc->d_status) (void) hipFree(sc->d_status);
-    if (sc->h_status) (void) hipHostFree(sc->h_status);
     if (sc->d_acc) (void) hipFree(sc->d_acc);
     if (sc->d_lo) (void) hipFree(sc->d_lo);
     if (sc->h_lo) (void) hipHostFree(sc->h_lo);
@@ -79,6 +84,7 @@ scanner_release(void *data)
     if (sc->d_blocks) (void) hipFree(sc->d_blocks);
     if (sc->ev0) (void) hipEventDestroy(sc->ev0);
     if (sc->ev1) (void) hipEventDestroy(sc->ev1);
+    if (sc->ev_done) (void) hipEventDestroy(sc->ev_done);
     sre_scan_tables_release(sc->tab);
     sre_dfa_free(sc->dfa);
     free(sc);
@@ -189,47 +195,52 @@ sre_hip_scanner_last_segment_bytes(sre_hip_scanner_t *sc)
     return sc->engine == SRE_HIP_ENGINE_SCAN ? sc->geom.seg_bytes : 0;
 }
 
+static size_t
+record_bytes(const sre_hip_scanner_t *sc, size_t n)
+{
+    return n * (2 + (size_t) sc->ovec_slots) * sizeof(int64_t);
+}
+
 static int
 scanner_reserve(sre_hip_scanner_t *sc, size_t n)
 {
     if (n > sc->cap_streams) {
-        if (sc->d_ptrs) (void) hipFree(sc->d_ptrs);
-        if (sc->d_lens) (void) hipFree(sc->d_lens);
-        if (sc->d_records) (void) hipFree(sc->d_records);
-        if (sc->h_lens) (void) hipHostFree(sc->h_lens);
-        if (sc->h_ptrs) (void) hipHostFree(sc->h_ptrs);
-        if (sc->d_seg_first) (void) hipFree(sc->d_seg_first);
-        if (sc->h_seg_first) (void) hipHostFree(sc->h_seg_first);
-        if (sc->d_status) (void) hipFree(sc->d_status);
-        if (sc->h_status) (void) hipHostFree(sc->h_status);
+        if (sc->d_in) (void) hipFree(sc->d_in);
+        if (sc->h_in) (void) hipHostFree(sc->h_in);
+        if (sc->d_out) (void) hipFree(sc->d_out);
+        if (sc->h_out) (void) hipHostFree(sc->h_out);
         if (sc->d_acc) (void) hipFree(sc->d_acc);
-        sc->d_acc = NULL;
         if (sc->d_lo) (void) hipFree(sc->d_lo);
         if (sc->h_lo) (void) hipHostFree(sc->h_lo);
-        sc->d_ptrs = NULL;
-        sc->d_lens = NULL;
-        sc->d_records = NULL;
-        sc->h_lens = NULL;
-        sc->h_ptrs = NULL;
-        sc->d_seg_first = sc->h_seg_first = NULL;
-        sc->d_status = sc->h_status = NULL;
+        sc->d_in = sc->h_in = NULL;
+        sc->d_out = sc->h_out = NULL;
+        sc->d_acc = NULL;
         sc->d_lo = sc->h_lo = NULL;
         sc->cap_streams = 0;
-        SRE_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&sc->d_ptrs), n * sizeof(void *)));
-        SRE_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&sc->d_lens), n * sizeof(uint64_t)));
-        SRE_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&sc->d_records),
-                              n * (2 + (size_t) sc->ovec_slots) * sizeof(int64_t)));
-        SRE_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&sc->h_lens), n * sizeof(uint64_t), 0));
-        SRE_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&sc->h_ptrs), n * sizeof(void *), 0));
-        SRE_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&sc->d_seg_first), (n + 1) * sizeof(uint64_t)));
-        SRE_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&sc->h_seg_first), (n + 1) * sizeof(uint64_t), 0));
-        SRE_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&sc->d_status), n * sizeof(sre_stream_status_t)));
-        SRE_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&sc->h_status), n * sizeof(sre_stream_status_t), 0));
+        const size_t in_bytes = (3 * n + 1) * sizeof(uint64_t);
+        const size_t out_bytes = record_bytes(sc, n) + n * sizeof(sre_stream_status_t);
+        SRE_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&sc->d_in), in_bytes));
+        SRE_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&sc->h_in), in_bytes, 0));
+        SRE_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&sc->d_out), out_bytes));
+        SRE_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&sc->h_out), out_bytes, 0));
         SRE_HIP_TRY(hipMalloc(&sc->d_acc, sre_scan_verify_acc_bytes((uint32_t) n)));
+        SRE_HIP_TRY(sre_scan_verify_acc_init(sc->d_acc, (uint32_t) n, NULL));
+        SRE_HIP_TRY(hipStreamSynchronize(NULL));
         SRE_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&sc->d_lo), n * sizeof(int64_t)));
         SRE_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&sc->h_lo), n * sizeof(int64_t), 0));
         sc->cap_streams = n;
     }
+    /* this call's layout: [ptrs n][lens n][seg_first n + 1] and [records n][status n] */
+    sc->h_ptrs = reinterpret_cast<const void **>(sc->h_in);
+    sc->h_lens = sc->h_in + n;
+    sc->h_seg_first = sc->h_in + 2 * n;
+    sc->d_ptrs = reinterpret_cast<const void **>(sc->d_in);
+    sc->d_lens = sc->d_in + n;
+    sc->d_seg_first = sc->d_in + 2 * n;
+    sc->d_records = reinterpret_cast<sre_int_t *>(sc->d_out);
+    sc->h_records = reinterpret_cast<sre_int_t *>(sc->h_out);
+    sc->d_status = reinterpret_cast<sre_stream_status_t *>(sc->d_out + record_bytes(sc, n));
+    sc->h_status = reinterpret_cast<sre_stream_status_t *>(sc->h_out + record_bytes(sc, n));
     if (sc->engine == SRE_HIP_ENGINE_VM && n * sc->ctx_stride > sc->ctx_cap) {
         if (sc->d_ctx) (void) hipFree(sc->d_ctx);
         sc->d_ctx = NULL;
@@ -325,11 +336,9 @@ sre_hip_scan_enqueue(sre_hip_scanner_t *sc, const void *const *d_streams, const 
         sc->h_ptrs[i] = d_streams[i];
         sc->h_lens[i] = lens[i];
     }
-    SRE_HIP_TRY(hipMemcpyAsync(sc->d_ptrs, sc->h_ptrs, nstreams * sizeof(void *),
-                               hipMemcpyHostToDevice, stream));
-    SRE_HIP_TRY(hipMemcpyAsync(sc->d_lens, sc->h_lens, nstreams * sizeof(uint64_t),
-                               hipMemcpyHostToDevice, stream));
     if (sc->engine == SRE_HIP_ENGINE_VM) {
+        SRE_HIP_TRY(hipMemcpyAsync(sc->d_in, sc->h_in, 2 * nstreams * sizeof(uint64_t),
+                                   hipMemcpyHostToDevice, stream));
         /* zero-filled state == fresh context */
         SRE_HIP_TRY(hipMemsetAsync(sc->d_ctx, 0, nstreams * sc->ctx_stride, stream));
         SRE_HIP_TRY(sre_launch_vm_scan(sc->dp->d_blob, sc->mode, sc->d_ptrs, sc->d_lens,
@@ -337,7 +346,7 @@ sre_hip_scan_enqueue(sre_hip_scanner_t *sc, const void *const *d_streams, const 
                                        sc->d_records, sc->ovec_slots, stream));
     } else {
         if (scan_geometry(sc, nstreams) != 0) return -1;
-        SRE_HIP_TRY(hipMemcpyAsync(sc->d_seg_first, sc->h_seg_first, (nstreams + 1) * sizeof(uint64_t),
+        SRE_HIP_TRY(hipMemcpyAsync(sc->d_in, sc->h_in, (3 * nstreams + 1) * sizeof(uint64_t),
                                    hipMemcpyHostToDevice, stream));
         /* speculative pass, chain check, captures — all queued; results() only
          * has to look at the status words */
@@ -354,6 +363,13 @@ sre_hip_scan_enqueue(sre_hip_scanner_t *sc, const void *const *d_streams, const 
                                         sc->d_scratch, sc->d_records, sc->ovec_slots,
                                         NULL, NULL, 0, stream));
     }
+    /* records (and the scanner's status words behind them) in one copy */
+    SRE_HIP_TRY(hipMemcpyAsync(sc->h_out, sc->d_out,
+                               record_bytes(sc, nstreams)
+                                   + (sc->engine == SRE_HIP_ENGINE_SCAN ? nstreams * sizeof(sre_stream_status_t) : 0),
+                               hipMemcpyDeviceToHost, stream));
+    if (sc->ev_done == NULL) SRE_HIP_TRY(hipEventCreateWithFlags(&sc->ev_done, hipEventDisableTiming));
+    SRE_HIP_TRY(hipEventRecord(sc->ev_done, stream));
     sc->last_n = nstreams;
     sc->last_stream = stream;
     return 0;
@@ -368,13 +384,20 @@ sre_hip_scan_results(sre_hip_scanner_t *sc, sre_int_t *results)
     const size_t n = sc->last_n;
     hipStream_t  stream = sc->last_stream;
 
+    const size_t bytes = n * (2 + (size_t) sc->ovec_slots) * sizeof(int64_t);
+    bool         settled = true;        /* the copies queued by enqueue() are the answer */
+
+    /* everything enqueue() queued for this call, result copies included */
+    SRE_HIP_TRY(hipEventSynchronize(sc->ev_done));
     if (sc->engine == SRE_HIP_ENGINE_SCAN) {
         /* segments behind a broken state chain are re-run from the exact carried
          * state until every stream's verified prefix reaches its end */
-        for (;;) {
-            SRE_HIP_TRY(hipMemcpyAsync(sc->h_status, sc->d_status, n * sizeof(sre_stream_status_t),
-                                       hipMemcpyDeviceToHost, stream));
-            SRE_HIP_TRY(hipStreamSynchronize(stream));
+        for (bool first = true;; first = false) {
+            if (!first) {
+                SRE_HIP_TRY(hipMemcpyAsync(sc->h_status, sc->d_status, n * sizeof(sre_stream_status_t),
+                                           hipMemcpyDeviceToHost, stream));
+                SRE_HIP_TRY(hipStreamSynchronize(stream));
+            }
             size_t pending = 0;
             for (size_t i = 0; i < n; i++) {
                 if (sc->h_status[i].done) {
@@ -385,6 +408,7 @@ sre_hip_scan_results(sre_hip_scanner_t *sc, sre_int_t *results)
                 }
             }
             if (pending == 0) break;
+            settled = false;
             if (++sc->fixup_rounds > 1000000) {
                 fprintf(stderr, "[sregex-hip] scanner fix-up did not converge\n");
                 return -1;
@@ -414,6 +438,7 @@ sre_hip_scan_results(sre_hip_scanner_t *sc, sre_int_t *results)
                     sc->maps_cap = sc->geom.nsegs;
                 }
                 sc->lineage_passes++;
+                settled = false;
                 SRE_HIP_TRY(sre_launch_lineage(sc->tab->d_tab, sc->tab->h, sc->geom, sc->d_sum,
                                                sc->d_status, sc->d_maps, sc->d_blocks, stream));
                 SRE_HIP_TRY(sre_launch_captures(sc->tab->d_tab, sc->tab->h, sc->geom, sc->d_sum,
@@ -423,11 +448,11 @@ sre_hip_scan_results(sre_hip_scanner_t *sc, sre_int_t *results)
             }
         }
     }
-    {
-        size_t bytes = n * (2 + (size_t) sc->ovec_slots) * sizeof(int64_t);
-        SRE_HIP_TRY(hipMemcpyAsync(results, sc->d_records, bytes, hipMemcpyDeviceToHost, stream));
+    if (!settled) {
+        SRE_HIP_TRY(hipMemcpyAsync(sc->h_records, sc->d_records, bytes, hipMemcpyDeviceToHost, stream));
         SRE_HIP_TRY(hipStreamSynchronize(stream));
     }
+    memcpy(results, sc->h_records, bytes);
     return 0;
 hip_failed:
     return -1;

@@ -154,6 +154,7 @@ int sre_scan_blocks_per_cu(const sre_scan_tables_t *h_tab);
 hipError_t sre_launch_scan(const sre_scan_tables_t *d_tab, sre_scan_tables_t h_tab,
     sre_scan_geom_t geom, sre_seg_summary_t *d_sum, const int64_t *d_lo, hipStream_t stream);
 size_t sre_scan_verify_acc_bytes(uint32_t nstreams);
+hipError_t sre_scan_verify_acc_init(void *d_acc, uint32_t nstreams, hipStream_t stream);
 hipError_t sre_launch_verify(sre_scan_tables_t h_tab, sre_scan_geom_t geom,
     const sre_seg_summary_t *d_sum, void *d_acc, sre_stream_status_t *d_status,
     hipStream_t stream);

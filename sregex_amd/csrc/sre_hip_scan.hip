@@ -880,17 +880,21 @@ sre_k_verify_b(sre_scan_geom_t G, const sre_seg_summary_t *__restrict__ sum, Ver
 
 __global__ void
 sre_k_verify_c(sre_scan_tables_t T, sre_scan_geom_t G, const sre_seg_summary_t *__restrict__ sum,
-               const VerifyAcc *__restrict__ acc, sre_stream_status_t *__restrict__ status)
+               VerifyAcc *__restrict__ accs, sre_stream_status_t *__restrict__ status)
 {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= G.nstreams) return;
+    /* take this stream's accumulator and leave it reset for the next pass */
+    const VerifyAcc acc = accs[s];
+    accs[s].bad = accs[s].end = ~0ull;
+    accs[s].count = accs[s].evseg = accs[s].spseg = 0;
     const uint64_t first = G.seg_first[s], nseg = G.seg_first[s + 1] - first;
-    uint64_t       bad = acc[s].bad, end = acc[s].end;
+    uint64_t       bad = acc.bad, end = acc.end;
     if (bad > nseg) bad = nseg;
     if (end > nseg) end = nseg;
     const bool     done = (end < bad) || (bad >= nseg);
     const uint64_t limit = end < bad ? end + 1 : bad;
-    const uint64_t evseg = acc[s].evseg;
+    const uint64_t evseg = acc.evseg;
 
     sre_stream_status_t st;
     st.first_bad = (int64_t) bad;
@@ -899,7 +903,7 @@ sre_k_verify_c(sre_scan_tables_t T, sre_scan_geom_t G, const sre_seg_summary_t *
     st.error = 0;
     st.need_maps = 0;
     st.pad = 0;
-    st.count = (int64_t) acc[s].count;
+    st.count = (int64_t) acc.count;
     st.rc = RC_DECLINED;
     st.ev_pos = st.ev_sp = -1;
     st.ev_state = st.ev_sym = 0;
@@ -923,7 +927,7 @@ sre_k_verify_c(sre_scan_tables_t T, sre_scan_geom_t G, const sre_seg_summary_t *
              * known before it.  (A start known at or after the match's own
              * segment belongs to a later search.) */
             int64_t        sp = 0;
-            const uint64_t spseg = acc[s].spseg;
+            const uint64_t spseg = acc.spseg;
             if (T.mode != SRE_HIP_PIKE_COUNT || spseg == 0) {
                 sp = 0;                     /* one search per stream, from its start */
             } else if (spseg < evseg) {
@@ -1444,19 +1448,25 @@ sre_scan_verify_acc_bytes(uint32_t nstreams)
     return (size_t) nstreams * sizeof(VerifyAcc);
 }
 
+/* reset state of the accumulators: bad/end at ~0, the counters at 0 */
+extern "C" hipError_t
+sre_scan_verify_acc_init(void *d_acc, uint32_t nstreams, hipStream_t stream)
+{
+    hipError_t e = hipMemset2DAsync(d_acc, sizeof(VerifyAcc), 0xff, 2 * sizeof(unsigned long long),
+                                    nstreams, stream);
+    if (e != hipSuccess) return e;
+    return hipMemset2DAsync(static_cast<char *>(d_acc) + 2 * sizeof(unsigned long long),
+                            sizeof(VerifyAcc), 0, 3 * sizeof(unsigned long long), nstreams, stream);
+}
+
 extern "C" hipError_t
 sre_launch_verify(sre_scan_tables_t h_tab, sre_scan_geom_t geom, const sre_seg_summary_t *d_sum,
                   void *d_acc, sre_stream_status_t *d_status, hipStream_t stream)
 {
     if (geom.nstreams == 0) return hipSuccess;
+    /* the accumulators are in their reset state: sre_scan_verify_acc_init at
+     * allocation, sre_k_verify_c after every pass */
     VerifyAcc *acc = static_cast<VerifyAcc *>(d_acc);
-    /* bad/end start at ~0, the counters at 0: two strided memsets */
-    hipError_t e = hipMemset2DAsync(acc, sizeof(VerifyAcc), 0xff, 2 * sizeof(unsigned long long),
-                                    geom.nstreams, stream);
-    if (e != hipSuccess) return e;
-    e = hipMemset2DAsync(reinterpret_cast<char *>(acc) + 2 * sizeof(unsigned long long),
-                         sizeof(VerifyAcc), 0, 3 * sizeof(unsigned long long), geom.nstreams, stream);
-    if (e != hipSuccess) return e;
     const uint32_t gseg = (uint32_t) ((geom.nsegs + 255) / 256);
     hipLaunchKernelGGL(sre_k_verify_a, dim3(gseg), dim3(256), 0, stream, geom, d_sum, acc);
     hipLaunchKernelGGL(sre_k_verify_b, dim3(gseg), dim3(256), 0, stream, geom, d_sum, acc);
