@@ -7,8 +7,9 @@ Workload (BASELINE.json):
   N == 1  configs[1]: ONE 4 GiB stream  "abccc" x k . "aaabbccb"  (bench/gen-data.pl:9
           scaled), pattern /[a-z]+@[a-z]+\\.[a-z]+/, Pike semantics (first match +
           captures), input resident in HBM (generated on device).
-  N  > 1  configs[4] shape: 64*N independent 64 MiB streams of the same pattern,
-          stream i on rank i mod N (64 streams = 4 GiB per GPU, weak scaling),
+  N  > 1  configs[4] shape: 128*N independent 64 MiB streams of the same pattern
+          (N = 8: the 1024 streams of configs[4]), stream i on rank i mod N
+          (128 streams = 8 GiB per GPU, weak scaling),
           tails alternate matching (" a@abc.cc ") / non-matching ("aaabbccb");
           the only collective is one RCCL all-reduce of the per-rank match counts.
 A step = one complete scan of the rank's resident input through the public
@@ -88,7 +89,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--bytes", type=int, default=4 * GIB, help="bytes per GPU (default 4 GiB)")
+    ap.add_argument("--bytes", type=int, default=0,
+                    help="bytes per GPU (default: 4 GiB single stream at N=1, 8 GiB = 128 x 64 MiB streams at N>1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--config", default="cfg2", choices=["cfg1", "cfg2", "cfg2m", "cfg3", "cfg4"],
                     help="N=1 workload: cfg2 = BASELINE configs[1] (default, the headline); cfg2m = "
@@ -122,6 +124,8 @@ def main():
 
     # ---- resident input -------------------------------------------------
     pats, mode = [PATTERN], S.HIP_PIKE_FIRST
+    if args.bytes <= 0:
+        args.bytes = 4 * GIB if (world == 1 and not args.many_streams) else 8 * GIB
     if world == 1 and not args.many_streams:
         tail = b"aaabbccb"
         name = "configs[1]: /[a-z]+@[a-z]+\\.[a-z]+/ Pike first-match + captures"
@@ -225,7 +229,8 @@ def main():
                        "matches": matches, "engine": "scan", "lineage_passes": sc.last_lineage_passes},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "sre_k_scan<%d>" % (2 if mode == S.HIP_PIKE_COUNT else 1), "kernel_ms": kms,
+                         "kernel": "sre_k_scan<%d, %d>" % (2 if mode == S.HIP_PIKE_COUNT else 1, sc.class_bits),
+                         "kernel_ms": kms,
                          "algorithmic_bytes_per_launch": total},
         }
         prof = os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")
@@ -234,7 +239,7 @@ def main():
             # HBM bytes per launch from the separate rocprofv3 --pmc passes of this
             # same command (profiles/README.md): 2 x FETCH_SIZE (gfx950 correction,
             # MI355X_MICROARCH.md HBM section) + WRITE_SIZE, KB -> bytes
-            pm = {(r["counter"], "sre_k_scan<1, 2, 64>" in r["kernel"]): r["mean_value_KB"]
+            pm = {(r["counter"], "sre_k_scan<1, 2>" in r["kernel"]): r["mean_value_KB"]
                   for r in json.load(open(prof))}
             if ("FETCH_SIZE", True) in pm:
                 line["roofline"]["traffic"] = (2 * pm[("FETCH_SIZE", True)] + pm[("WRITE_SIZE", True)]) * 1024
@@ -249,6 +254,18 @@ def main():
             ev1.record(stream)
             torch.cuda.synchronize()
             line["roofline"]["measured_read_ceiling"] = lens[0] * 5 / (ev0.elapsed_time(ev1) * 1e-3) / 1e9
+            # ... and of the scanner's own staging pattern with no automaton work
+            # (one row per lane, whole 128-byte lines, one stage ahead)
+            seg = sc.last_segment_bytes
+            if seg % 128 == 0 and lens[0] >= seg:
+                lib.sre_hip_read_pattern(ptrs[0], lens[0], seg, 128, 16384, hstream)
+                ev0.record(stream)
+                for _ in range(5):
+                    lib.sre_hip_read_pattern(ptrs[0], lens[0], seg, 128, 16384, hstream)
+                ev1.record(stream)
+                torch.cuda.synchronize()
+                line["roofline"]["measured_staging_ceiling"] = \
+                    (lens[0] // seg * seg) * 5 / (ev0.elapsed_time(ev1) * 1e-3) / 1e9
             if not args.no_cpu_baseline:
                 line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))

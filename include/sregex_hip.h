@@ -74,6 +74,11 @@ SRE_API int sre_hip_scanner_last_fixups(sre_hip_scanner_t *sc);
  * reconstruct the captures of a match spanning many segments */
 SRE_API int sre_hip_scanner_last_lineage_passes(sre_hip_scanner_t *sc);
 
+/* class bits per input byte of the scanner's fast table (1, 2, 4 or 8: one table
+ * lookup advances 8 / bits bytes); 0 for the VM engine.  Names the kernel
+ * variant (sre_k_scan<mode, bits>) in profiles. */
+SRE_API int sre_hip_scanner_class_bits(sre_hip_scanner_t *sc);
+
 /* measurement: duration (ms) of the segment-scan kernel of the last enqueued
  * scan, from hipEvents recorded on the caller's stream around that launch;
  * -1 when the exact VM engine ran.  Waits for the kernel. */

@@ -60,6 +60,7 @@ API = {
     "sre_hip_scanner_set_segment_bytes": (ctypes.c_int, [_vp, _sz]),
     "sre_hip_scanner_last_fixups": (ctypes.c_int, [_vp]),
     "sre_hip_scanner_last_lineage_passes": (ctypes.c_int, [_vp]),
+    "sre_hip_scanner_class_bits": (ctypes.c_int, [_vp]),
     "sre_hip_scanner_last_kernel_ms": (ctypes.c_double, [_vp]),
     "sre_hip_scanner_last_segment_bytes": (_sz, [_vp]),
     "sre_hip_scan_enqueue": (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_sz), _sz, _vp]),
@@ -282,6 +283,10 @@ class Scanner:
     @property
     def last_lineage_passes(self):
         return self.lib.sre_hip_scanner_last_lineage_passes(self.h)
+
+    @property
+    def class_bits(self):
+        return self.lib.sre_hip_scanner_class_bits(self.h)
 
     @property
     def last_kernel_ms(self):

@@ -174,6 +174,12 @@ sre_hip_scanner_last_fixups(sre_hip_scanner_t *sc)
 }
 
 extern "C" SRE_API int
+sre_hip_scanner_class_bits(sre_hip_scanner_t *sc)
+{
+    return sc->engine == SRE_HIP_ENGINE_SCAN ? (int) sc->tab->h.class_bits : 0;
+}
+
+extern "C" SRE_API int
 sre_hip_scanner_last_lineage_passes(sre_hip_scanner_t *sc)
 {
     return sc->lineage_passes;

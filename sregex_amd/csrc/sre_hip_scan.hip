@@ -337,38 +337,43 @@ __device__ void slow_run(Walk &w, int64_t p, int64_t p_to, bool warm, uint32_t w
     }
 }
 
-/* COUNT: matches completed inside one pure-fast 16-byte group were only counted;
- * recover the last one and the start of the search now in flight. */
-__device__ void resolve_fast_group(Walk &w, int64_t gpos, uint32_t s0, int64_t sp0, bool is_last)
+/* COUNT: matches completed inside a pure-fast span (a 16-byte group or a whole
+ * round, entered in state s0 with the search in flight started at sp0) were
+ * only counted; recover the last one and the start of the search in flight
+ * after the span.  With at least one match in the span the latter does not
+ * depend on sp0.  Deliberately a real call, by value: it runs a few times per
+ * segment and must not add to the scan loop's register pressure. */
+struct SpanResult {
+    int64_t  sp;                /* start of the search in flight after the span */
+    int64_t  last_pos, last_sp; /* last completed match: its final byte (-1 none), its search start */
+    uint32_t last_state, last_sym;
+};
+
+__device__ __attribute__((noinline)) SpanResult
+resolve_fast_span(const sre_scan_tables_t *Tp, const uint8_t *data, int64_t gpos, uint32_t len,
+                  uint32_t s0, int64_t sp0)
 {
-    const sre_scan_tables_t &T = *w.T;
-    uint32_t st = s0;
-    int64_t  sp = sp0, last_pos = -1, last_sp = -1;
-    uint32_t last_state = 0, last_sym = 0;
-    for (int b = 0; b < 16; b++) {
-        const uint32_t         sym = T.cls[w.data[gpos + b]];
+    const sre_scan_tables_t &T = *Tp;
+    SpanResult r;
+    uint32_t   st = s0;
+    r.sp = sp0;
+    r.last_pos = r.last_sp = -1;
+    r.last_state = r.last_sym = 0;
+    for (uint32_t b = 0; b < len; b++) {
+        const uint32_t         sym = T.cls[data[gpos + b]];
         const sre_dev_trans_t &tr = T.trans[(size_t) st * (T.ncls + 1) + sym];
         if (tr.kind && tr.next == 0) {
-            last_pos = gpos + b;
-            last_state = st;
-            last_sym = sym;
-            last_sp = sp;
-            sp = gpos + b + 1;
+            r.last_pos = gpos + b;
+            r.last_state = st;
+            r.last_sym = sym;
+            r.last_sp = r.sp;
+            r.sp = gpos + b + 1;
             st = T.init[2];
         } else {
             st = tr.next;
         }
     }
-    if (is_last && last_pos >= 0) {
-        w.lm_valid = true;
-        w.lm_pos = last_pos;
-        w.lm_state = last_state;
-        w.lm_sym = last_sym;
-        w.lm_sp = last_sp;
-        w.lm_apos = -1;
-        w.lm_astate = 0;
-    }
-    w.cur_sp = sp;
+    return r;
 }
 
 /* one row of a workgroup's staging: where the lane's segment (with its warm-up
@@ -509,16 +514,23 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
         Ts.trans = reinterpret_cast<const sre_dev_trans_t *>(trl);
         Ts.state_flags = sfl;
     }
-    /* In LDS an entry is [flags : 16][LDS byte address of the next state's row : 16]
-     * (the launch keeps all LDS below 64 KiB): a lookup address is then one add
-     * of two 16-bit fields, which the hardware selects in the add itself. */
+    /* In LDS an entry is [matches completed : 8][flags : 8][LDS byte address of the
+     * next state's row : 16] (the fast table lies below 64 KiB): a lookup address
+     * is then one add of two 16-bit fields and the match count one add of a byte
+     * field, both selected by the add instruction itself. */
+    constexpr uint32_t LDS_SLOW = 1u << 16;
+    constexpr uint32_t LDS_CNT_SHIFT = 24;
     const uint32_t fast_lds = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) uint8_t *) lds;
     for (uint32_t i = tid; i < tabp->fast_bytes / 16; i += SRE_SCAN_BLOCK) {
         uint4 e = reinterpret_cast<const uint4 *>(tabp->fast)[i];
-        e.x = ((e.x & 0xffu) << 16) | (fast_lds + (e.x & ~(SRE_FAST_ROW_BYTES - 1)));
-        e.y = ((e.y & 0xffu) << 16) | (fast_lds + (e.y & ~(SRE_FAST_ROW_BYTES - 1)));
-        e.z = ((e.z & 0xffu) << 16) | (fast_lds + (e.z & ~(SRE_FAST_ROW_BYTES - 1)));
-        e.w = ((e.w & 0xffu) << 16) | (fast_lds + (e.w & ~(SRE_FAST_ROW_BYTES - 1)));
+        auto to_lds = [fast_lds](uint32_t g) -> uint32_t {
+            return (fast_lds + (g & ~(SRE_FAST_ROW_BYTES - 1))) | ((g & SRE_FAST_SLOW) ? LDS_SLOW : 0u)
+                   | (((g >> SRE_FAST_CNT_SHIFT) & SRE_FAST_CNT_MASK) << LDS_CNT_SHIFT);
+        };
+        e.x = to_lds(e.x);
+        e.y = to_lds(e.y);
+        e.z = to_lds(e.z);
+        e.w = to_lds(e.w);
         reinterpret_cast<uint4 *>(fast)[i] = e;
     }
     for (uint32_t i = tid; i < tr_bytes / 8; i += SRE_SCAN_BLOCK) {
@@ -631,12 +643,46 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
     /* pure-fast COUNT bookkeeping: the last 16-byte group that completed matches
      * without leaving the fast loop, while it still holds the segment's last
      * completed match */
-    int64_t  fc_gpos = -1, fc_sp0 = -1;
-    uint32_t fc_s0 = 0;
-    bool     fc_pending = false;
+    int64_t  fcA_pos = -1, fcB_pos = -1, fc_sp0 = -1;
+    uint32_t fcA_len = 0, fcA_s0 = 0, fcB_len = 0, fcB_s0 = 0;
+    bool     sp_dirty = false;
+    /* a pure-fast span [pos, pos + len), entered in state s0, completed cnt matches */
+    auto note_span = [&](int64_t pos, uint32_t len, uint32_t s0, uint32_t cnt, bool warm_round) {
+        w.has_ev = false;                       /* superseded */
+        if (warm_round) return;
+        if (sp_dirty) {
+            fcA_pos = fcB_pos;
+            fcA_len = fcB_len;
+            fcA_s0 = fcB_s0;
+        } else {
+            fc_sp0 = w.cur_sp;                  /* exact right now */
+            fcA_pos = -1;
+        }
+        fcB_pos = pos;
+        fcB_len = len;
+        fcB_s0 = s0;
+        sp_dirty = true;
+        w.count += cnt;
+    };
+    /* make w.cur_sp exact again and record the last completed match (lm_*) */
+    auto settle = [&]() {
+        if (MODE != SRE_HIP_PIKE_COUNT || !sp_dirty) return;
+        int64_t sp0 = fc_sp0;
+        if (fcA_pos >= 0) sp0 = resolve_fast_span(&T, w.data, fcA_pos, fcA_len, fcA_s0, -1).sp;
+        const SpanResult r = resolve_fast_span(&T, w.data, fcB_pos, fcB_len, fcB_s0, sp0);
+        if (r.last_pos >= 0) {
+            w.lm_valid = true;
+            w.lm_pos = r.last_pos;
+            w.lm_state = r.last_state;
+            w.lm_sym = r.last_sym;
+            w.lm_sp = r.last_sp;
+            w.lm_apos = -1;
+            w.lm_astate = 0;
+        }
+        w.cur_sp = r.sp;
+        sp_dirty = false;
+    };
 
-    /* rounds per lane; the upper half of every wave runs one round behind the
-     * lower half (see tile_fetch), hence one more iteration than rounds */
     const uint32_t nrounds = WARM / TILE + G.seg_bytes / TILE;
     const uint32_t lag = (tid >> 5) & 1u;
     uint4          regs[4];
@@ -689,15 +735,17 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
         /* the common round: every byte in range, no transition needs the exact
          * path, (COUNT) no match completes — one straight chain of lookups */
         if (base + TILE <= seg_b) {
-            uint32_t t = fast_lds + w.st * SRE_FAST_ROW_BYTES, acc = 0;
+            uint32_t t = fast_lds + w.st * SRE_FAST_ROW_BYTES, acc = 0, cnt = 0;
 #pragma unroll
             for (int j = 0; j < TILE * BITS / 8; j++) {
                 t = *(lds_u32_t) (uintptr_t) ((t & 0xffffu) + sidx(j));
                 acc |= t;
+                if (MODE == SRE_HIP_PIKE_COUNT) cnt += t >> LDS_CNT_SHIFT;
             }
-            constexpr uint32_t EVENTS = (SRE_FAST_SLOW
-                | (MODE == SRE_HIP_PIKE_COUNT ? (SRE_FAST_CNT_MASK << SRE_FAST_CNT_SHIFT) : 0u)) << 16;
-            if (!(acc & EVENTS)) {
+            if (!(acc & LDS_SLOW)) {
+                /* matches completed in the round, each followed by a restart at
+                 * the next byte, are only counted here (see note_span) */
+                if (MODE == SRE_HIP_PIKE_COUNT && cnt) note_span(base, TILE, w.st, cnt, warm_round);
                 w.st = ((t & 0xffffu) - fast_lds) / SRE_FAST_ROW_BYTES;
                 if (r + 1 == WARM / TILE) {
                     s_in = w.st;
@@ -707,49 +755,38 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
                 continue;
             }
         }
-#pragma unroll
+        /* otherwise group by group (16 bytes); a real loop, the indices of a
+         * group re-read from the tile: this is the uncommon path and must not
+         * weigh on the registers of the common one */
+#pragma unroll 1
         for (uint32_t q = 0; q < TILE / 16; q++) {
             const int64_t gp = base + q * 16;
             if (gp >= seg_b || w.finished) break;
-            if (gp + 16 > seg_b) {
-                /* ragged tail of the stream: exact path */
-                const int64_t before = w.count;
-                slow_run<MODE>(w, gp, seg_b, false, 0);
-                if (w.count != before) fc_pending = false;
-                break;
-            }
-            /* this group's ready-made indices: GIDX of them starting at q * GIDX */
-            uint32_t t = fast_lds + w.st * SRE_FAST_ROW_BYTES, acc = 0, cnt = 0, lastb = 0;
+            const int64_t g_end = gp + 16 <= seg_b ? gp + 16 : seg_b;   /* ragged tail of the stream */
+            bool          exact = (g_end != gp + 16);
+            uint32_t      t = fast_lds + w.st * SRE_FAST_ROW_BYTES, cnt = 0;
+            if (!exact) {
+                constexpr int GW = GIDX * (WIDE ? 2 : 1) / 4;           /* dwords of indices per group */
+                uint32_t      gw[GW];
+                const uint32_t *gsrc = reinterpret_cast<const uint32_t *>(tile + tid * ROWB + (r & 1u) * ROWRAW) + q * GW;
 #pragma unroll
-            for (int j = 0; j < GIDX; j++) {
-                t = *(lds_u32_t) (uintptr_t) ((t & 0xffffu) + sidx((int) q * GIDX + j));
-                acc |= t;
-                if (MODE == SRE_HIP_PIKE_COUNT) {
-                    const uint32_t c1 = (t >> (16 + SRE_FAST_CNT_SHIFT)) & SRE_FAST_CNT_MASK;
-                    cnt += c1;
-                    lastb = c1 ? (uint32_t) (j * STRIDE) + ((t >> (16 + SRE_FAST_LAST_SHIFT)) & 7u) : lastb;
+                for (int x = 0; x < GW; x++) gw[x] = gsrc[x];
+                uint32_t acc = 0;
+#pragma unroll
+                for (int j = 0; j < GIDX; j++) {
+                    const uint32_t ix = WIDE ? (gw[j >> 1] >> ((j & 1) * 16)) & 0xffffu
+                                             : ((gw[j >> 2] >> ((j & 3) * 8)) & 0xffu) << 2;
+                    t = *(lds_u32_t) (uintptr_t) ((t & 0xffffu) + ix);
+                    acc |= t;
+                    if (MODE == SRE_HIP_PIKE_COUNT) cnt += t >> LDS_CNT_SHIFT;
                 }
+                exact = (acc & LDS_SLOW) != 0;
             }
-            if (acc & (SRE_FAST_SLOW << 16)) {
-                const int64_t before = w.count;
-                slow_run<MODE>(w, gp, gp + 16, warm_round, seed);
-                if (w.count != before) fc_pending = false;
+            if (exact) {
+                settle();
+                slow_run<MODE>(w, gp, g_end, warm_round, seed);
             } else {
-                if (MODE == SRE_HIP_PIKE_COUNT && cnt) {
-                    /* matches completed inside this group, each followed by a
-                     * restart at the next byte */
-                    w.has_ev = false;               /* superseded */
-                    if (!warm_round) {
-                        /* remember the group: its last completing transition is
-                         * recovered at the end if it stays the segment's last */
-                        fc_gpos = gp;
-                        fc_s0 = w.st;
-                        fc_sp0 = w.cur_sp;
-                        fc_pending = true;
-                        w.count += cnt;
-                        w.cur_sp = gp + lastb + 1;
-                    }
-                }
+                if (MODE == SRE_HIP_PIKE_COUNT && cnt) note_span(gp, 16, w.st, cnt, warm_round);
                 w.st = ((t & 0xffffu) - fast_lds) / SRE_FAST_ROW_BYTES;
             }
         }
@@ -765,17 +802,12 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
 
     /* the lane that owns the end of the stream performs the EOF step(s) */
     if (last_seg && !w.finished) {
-        const int64_t before = w.count;
+        settle();
         w.anchor_pos = -1;
         slow_run<MODE>(w, w.n, w.n + 1, false, 0);
-        if (w.count != before) fc_pending = false;
     }
-    /* the segment's last completed match sits in a pure-fast group: recover it */
-    if (MODE == SRE_HIP_PIKE_COUNT && fc_pending) {
-        const int64_t sp_now = w.cur_sp;
-        resolve_fast_group(w, fc_gpos, fc_s0, fc_sp0, true);
-        w.cur_sp = sp_now;
-    }
+    /* the segment's last completed match may sit in a pure-fast span: recover it */
+    settle();
 
     sre_seg_summary_t out;
     out.s_in = w.unresolved ? 0xffffffffu : s_in;
