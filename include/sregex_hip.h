@@ -106,6 +106,13 @@ SRE_API size_t sre_hip_scanner_result_slots(sre_hip_scanner_t *sc);
  * (a hipStream_t, NULL = default stream).  `d_streams[i]` is a DEVICE pointer
  * to `lens[i]` bytes; both arrays are HOST arrays.  Asynchronous: returns
  * after the kernels are queued.  0 on success, -1 on failure.
+ *
+ * The copy of the result records to pinned host memory is part of the queued
+ * work and sre_hip_scan_results() waits for an event behind it, not for the
+ * whole stream: a caller that alternates two scanners (enqueue on one, then
+ * collect from the other) keeps the GPU busy without a gap between scans.
+ * One call per scanner may be in flight; the streams must stay unchanged until
+ * sre_hip_scan_results() has returned.
  */
 SRE_API int sre_hip_scan_enqueue(sre_hip_scanner_t *sc,
     const void *const *d_streams, const size_t *lens, size_t nstreams,
