@@ -27,7 +27,7 @@
 #define SRE_FAST_LAST_SHIFT 5u
 #define SRE_FAST_ROW_BYTES  1024u
 
-#define SRE_SCAN_MAX_STATES   64u     /* LDS budget: 64 KiB of fast table */
+#define SRE_SCAN_MAX_STATES   55u     /* the fast table (1 KiB per state) must end below 64 KiB of LDS */
 #define SRE_SCAN_BLOCK        256u    /* lanes = segments per workgroup */
 #define SRE_SCAN_LDS_LIMIT    (128u * 1024u)  /* dynamic LDS a scan workgroup may ask for (160 KiB per CU) */
 #define SRE_SCAN_ROUND        64u     /* bytes a lane consumes per LDS round */
