@@ -3,10 +3,19 @@
  * the reference VM's step on capture-free thread lists.
  *
  * Mirrors (capture-free): byte loop sre_vm_pike.c:314-567, closure
- * sre_vm_pike.c:756-942.  Look-ahead assertions are not admitted here, so the
- * assertion splice (:506-526) never occurs; \A and ^ are resolved at add time
- * from the byte just consumed (:839-864) and are therefore functions of the
- * input symbol.
+ * sre_vm_pike.c:756-942.  \A and ^ are resolved at add time from the byte just
+ * consumed (:839-864) and are therefore functions of the input symbol.
+ *
+ * Look-ahead assertions ($ \z \b \B) wait in the list and are decided by the
+ * NEXT symbol (:450-504).  One that holds is replaced, within the same step, by
+ * the closure of its continuation at the SAME position, de-duplicated against
+ * the generation that built the current list and spliced in at the head of the
+ * list (:506-526).  For a list holding such threads the state key therefore
+ * also carries (i) what the byte in front of the position was (word character /
+ * newline / buffer start: the threads' seen_word, and ^ \A inside a splice) and
+ * (ii) the set of instructions that generation visited.  SAVEs executed by a
+ * splice carry the position BEFORE the byte ("early" masks); everything else
+ * about a spliced thread is folded into the thread of the list it came from.
  *
  * The leading-byte skip (sre_vm_pike.c:256-309) is part of the observable
  * behaviour (its initial-state test ignores the last thread, :266-273, so it
@@ -18,24 +27,32 @@
 #include "sre_dfa.h"
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
+#include <deque>
 #include <map>
 
 namespace {
+
+enum { PREV_WORD = 1, PREV_NL = 2, PREV_START = 4 };
 
 struct Builder {
     const sre_program_t *prog;
     sre_dfa_t           *d;
     std::vector<uint32_t> tags;
-    uint32_t             gen = 0;
-    std::map<std::vector<uint32_t>, uint32_t> ids;     /* key: pcs..., matched|sss<<1|variant<<2 */
+    uint32_t             gen = 0, gen_alloc = 0;
+    std::map<std::vector<uint32_t>, uint32_t> ids;     /* key: pcs..., flags [, prev, visited pcs...] */
     std::vector<std::vector<uint32_t>> lists;          /* per state */
     std::vector<uint8_t>               sss, variant;   /* per state */
+    std::vector<uint8_t>               prevk;          /* per state: PREV_* of the byte in front */
+    std::vector<std::vector<uint32_t>> visited;        /* per state: instructions tagged by the generation
+                                                          that built the list (kept if it holds a look-ahead) */
     bool                 visited_start = false;        /* pc 0 reached by the last closure(s) */
+    std::vector<uint32_t> vis_now;                     /* instructions tagged while building the new list */
 
     /* result of one closure / step */
     std::vector<uint32_t> nl;          /* new list pcs */
     std::vector<uint8_t>  npar;
-    std::vector<uint64_t> nsav;
+    std::vector<uint64_t> nsav, nearly;
 
     bool consumes(const sre_insn_t &in, unsigned c) const
     {
@@ -48,13 +65,30 @@ struct Builder {
         }
     }
 
+    bool is_lookahead(uint32_t pc) const
+    {
+        const sre_insn_t &in = prog->insns[pc];
+        return in.opcode == SRE_OP_ASSERT && (in.ch & SRE_ASSERT_LOOKAHEAD);
+    }
+
+    bool holds_lookahead(const std::vector<uint32_t> &pcs) const
+    {
+        for (uint32_t pc : pcs) {
+            if (is_lookahead(pc)) return true;
+        }
+        return false;
+    }
+
     /*
-     * Capture-free closure (sre_vm_pike.c:756-942).  Appends to nl/npar/nsav.
-     * Returns true when MATCH was reached with from_loop set (SRE_DONE);
-     * *done_saves / *done_regex then describe the match.
+     * Capture-free closure (sre_vm_pike.c:756-942) under generation `gen`.
+     * Appends to out_pc/out_par/out_sav.  Returns true when MATCH was reached
+     * with from_loop set (SRE_DONE); *done_saves / *done_regex then describe
+     * the match.  `track`: remember what gets tagged (vis_now).
      */
     bool closure(uint32_t pc0, bool a_ok, bool caret_ok, bool from_loop, uint8_t parent,
-                 uint64_t *done_saves, uint32_t *done_regex)
+                 std::vector<uint32_t> &out_pc, std::vector<uint8_t> &out_par,
+                 std::vector<uint64_t> &out_sav, uint64_t *done_saves, uint32_t *done_regex,
+                 bool track)
     {
         struct Rec { uint32_t pc; uint64_t mask; };
         std::vector<Rec> stack;
@@ -74,6 +108,7 @@ struct Builder {
                     break;
                 }
                 tags[pc] = gen;
+                if (track) vis_now.push_back(pc);
                 if (pc == 0) visited_start = true;                          /* :799-802 */
                 if (in.opcode == SRE_OP_JMP) {
                     pc = in.x;
@@ -89,8 +124,8 @@ struct Builder {
                     pc++;
                     continue;
                 }
-                if (in.opcode == SRE_OP_ASSERT) {
-                    bool ok = in.ch == SRE_ASSERT_BIG_A ? a_ok : caret_ok;
+                if (in.opcode == SRE_OP_ASSERT && !(in.ch & SRE_ASSERT_LOOKAHEAD)) {
+                    bool ok = in.ch == SRE_ASSERT_BIG_A ? a_ok : caret_ok;   /* :839-864 */
                     if (!ok) break;
                     pc++;
                     continue;
@@ -100,9 +135,10 @@ struct Builder {
                     *done_regex = in.arg;
                     return true;
                 }
-                nl.push_back(pc);
-                npar.push_back(parent);
-                nsav.push_back(mask);
+                /* consuming instruction, look-ahead assertion (:866-884) or MATCH */
+                out_pc.push_back(pc);
+                out_par.push_back(parent);
+                out_sav.push_back(mask);
                 break;
             }
             if (stack.empty()) return false;
@@ -114,7 +150,8 @@ struct Builder {
 
     /* seen_start: 0 clear, 1 set (consumed by the next check), 2 set by a skip
      * re-seed that is still travelling to its target byte (see step) */
-    uint32_t intern(const std::vector<uint32_t> &pcs, bool matched, int seen_start, int var)
+    uint32_t intern(const std::vector<uint32_t> &pcs, bool matched, int seen_start, int var,
+                    unsigned prev)
     {
         if (pcs.empty()) return SRE_DFA_DEAD;
         if (prog->nleading == 0) {       /* the skip does not exist: flags are inert */
@@ -124,6 +161,17 @@ struct Builder {
         if (!d->has_caret) var = 0;      /* all three initial lists coincide */
         std::vector<uint32_t> key(pcs);
         key.push_back((matched ? 1u : 0u) | ((uint32_t) seen_start << 1) | ((uint32_t) var << 3));
+        std::vector<uint32_t> vis;
+        if (holds_lookahead(pcs)) {
+            /* what a splice out of this list will see (:506-526) */
+            vis = vis_now;
+            std::sort(vis.begin(), vis.end());
+            vis.erase(std::unique(vis.begin(), vis.end()), vis.end());
+            key.push_back(0x80000000u | prev);
+            key.insert(key.end(), vis.begin(), vis.end());
+        } else {
+            prev = 0;
+        }
         auto it = ids.find(key);
         if (it != ids.end()) return it->second;
         uint32_t id = (uint32_t) lists.size();
@@ -132,6 +180,8 @@ struct Builder {
         d->matched.push_back(matched ? 1 : 0);
         sss.push_back((uint8_t) seen_start);
         variant.push_back((uint8_t) var);
+        prevk.push_back((uint8_t) prev);
+        visited.push_back(vis);
         return id;
     }
 
@@ -161,10 +211,6 @@ sre_dfa_build(const sre_program_t *prog, uint32_t max_states, const char **why)
     if (why == NULL) why = &dummy;
     *why = NULL;
 
-    if (prog->lookahead_asserts) {
-        *why = "program has look-ahead assertions ($ \\z \\b \\B)";
-        return NULL;
-    }
     if (prog->nslots > 64) {
         *why = "more than 64 capture slots";
         return NULL;
@@ -177,12 +223,18 @@ sre_dfa_build(const sre_program_t *prog, uint32_t max_states, const char **why)
     b.tags.assign(prog->len + 1, 0);
     d->nslots = prog->nslots;
     d->has_caret = 0;
+    d->has_lookahead = prog->lookahead_asserts ? 1 : 0;
 
     /* ---- byte classes: bytes no consuming instruction can tell apart ---- */
     {
         std::map<std::vector<uint8_t>, uint32_t> sigs;
+        bool has_dollar = false, has_b = false;
         for (uint32_t pc = 0; pc < prog->len; pc++) {
-            if (prog->insns[pc].opcode == SRE_OP_ASSERT) d->has_caret = 1;
+            const sre_insn_t &in = prog->insns[pc];
+            if (in.opcode != SRE_OP_ASSERT) continue;
+            if (in.ch & (SRE_ASSERT_BIG_A | SRE_ASSERT_CARET)) d->has_caret = 1;
+            if (in.ch & SRE_ASSERT_DOLLAR) has_dollar = true;
+            if (in.ch & (SRE_ASSERT_SMALL_B | SRE_ASSERT_BIG_B)) has_b = true;
         }
         for (unsigned c = 0; c < 256; c++) {
             std::vector<uint8_t> sig;
@@ -192,7 +244,8 @@ sre_dfa_build(const sre_program_t *prog, uint32_t max_states, const char **why)
                     sig.push_back(b.consumes(in, c) ? 1 : 0);
                 }
             }
-            if (d->has_caret) sig.push_back(c == '\n');
+            if (d->has_caret || has_dollar) sig.push_back(c == '\n');
+            if (has_b) sig.push_back(sre_isword(c) ? 1 : 0);
             auto it = sigs.find(sig);
             if (it == sigs.end()) it = sigs.emplace(sig, (uint32_t) sigs.size()).first;
             d->cls_map[c] = (uint8_t) it->second;
@@ -212,19 +265,25 @@ sre_dfa_build(const sre_program_t *prog, uint32_t max_states, const char **why)
     d->matched.push_back(0);
     b.sss.push_back(0);
     b.variant.push_back(0);
+    b.prevk.push_back(0);
+    b.visited.push_back(std::vector<uint32_t>());
     std::vector<std::vector<uint32_t>> init_lists(SRE_DFA_NINIT);
     std::vector<std::vector<uint8_t>>  lin_par_of_init(SRE_DFA_NINIT);
     std::vector<std::vector<uint64_t>> lin_sav_of_init(SRE_DFA_NINIT);
     for (int v = 0; v < SRE_DFA_NINIT; v++) {
         uint64_t ds;
         uint32_t dr;
-        b.gen++;
+        b.gen = ++b.gen_alloc;
         b.nl.clear();
         b.npar.clear();
         b.nsav.clear();
+        b.vis_now.clear();
         b.closure(0, v == SRE_DFA_INIT_START, v != SRE_DFA_INIT_RESTART, false,
-                  SRE_DFA_NO_PARENT, &ds, &dr);
-        d->init[v] = b.intern(b.nl, false, 1, v);
+                  SRE_DFA_NO_PARENT, b.nl, b.npar, b.nsav, &ds, &dr, true);
+        /* in front of the position: the buffer start (look-ahead programs are
+         * only ever started on a fresh context, see sre_dfa.h) */
+        d->init[v] = b.intern(b.nl, false, 1, v,
+                              v == SRE_DFA_INIT_START ? PREV_START : v == SRE_DFA_INIT_RESTART_NL ? PREV_NL : 0);
         lin_par_of_init[v] = b.npar;
         lin_sav_of_init[v] = b.nsav;
         init_lists[v] = b.nl;
@@ -248,11 +307,21 @@ sre_dfa_build(const sre_program_t *prog, uint32_t max_states, const char **why)
             const bool eof = (sym == d->ncls);
             const int  c = eof ? -1 : rep[sym];
 
-            b.gen++;
+            /* generation of the current list (what a splice de-duplicates
+             * against), then the one the new list is built under */
+            const uint32_t g_list = ++b.gen_alloc;
+            for (uint32_t pc : b.visited[s]) b.tags[pc] = g_list;
+            const uint32_t g_new = ++b.gen_alloc;
+            b.gen = g_new;
             b.nl.clear();
             b.npar.clear();
             b.nsav.clear();
+            b.nearly.clear();
+            b.vis_now.clear();
             b.visited_start = false;
+            const unsigned prev_here = b.prevk[s];
+            const unsigned prev_next = eof ? 0u : ((sre_isword((unsigned) c) ? PREV_WORD : 0u)
+                                                   | (c == '\n' ? PREV_NL : 0u));
 
             /* :256-309.  In the reference one check can jump sp over many
              * bytes, re-seed at the target and run that byte's step in the SAME
@@ -281,36 +350,77 @@ sre_dfa_build(const sre_program_t *prog, uint32_t max_states, const char **why)
                 /* re-seed one byte further with a fresh capture (:286-302) */
                 uint64_t ds;
                 uint32_t dr;
-                b.closure(0, false, c == '\n', false, SRE_DFA_NO_PARENT, &ds, &dr);
+                b.closure(0, false, c == '\n', false, SRE_DFA_NO_PARENT, b.nl, b.npar, b.nsav, &ds, &dr, true);
+                b.nearly.assign(b.nl.size(), 0);
                 t.skipped = 1;
-                t.next = b.intern(b.nl, was_matched, 2, var);
+                t.next = b.intern(b.nl, was_matched, 2, var, prev_next);
             } else {
-                for (size_t idx = 0; idx < L.size(); idx++) {
-                    const sre_insn_t &in = prog->insns[L[idx]];
+                /* the list as a work queue: a look-ahead assertion that holds
+                 * puts the closure of its continuation in front (:506-526) */
+                struct Item { uint32_t pc; uint8_t src; uint64_t early; };
+                std::deque<Item> work;
+                for (size_t idx = 0; idx < L.size(); idx++) work.push_back(Item{L[idx], (uint8_t) idx, 0});
+                while (!work.empty()) {
+                    const Item it = work.front();
+                    work.pop_front();
+                    const sre_insn_t &in = prog->insns[it.pc];
                     if (in.opcode == SRE_OP_MATCH) {                  /* :530-553 */
                         t.ev_kind = SRE_DFA_EV_POP;
-                        t.ev_src = (uint8_t) idx;
+                        t.ev_src = it.src;
                         t.ev_regex = (uint16_t) in.arg;
+                        t.ev_early = it.early;
                         break;
                     }
+                    if (in.opcode == SRE_OP_ASSERT) {                 /* :450-504 */
+                        bool hold = false;
+                        const bool word_here = !eof && sre_isword((unsigned) c);
+                        switch (in.ch) {
+                        case SRE_ASSERT_SMALL_Z: hold = eof; break;
+                        case SRE_ASSERT_DOLLAR:  hold = eof || c == '\n'; break;
+                        case SRE_ASSERT_SMALL_B: hold = ((prev_here & PREV_WORD) != 0) != word_here; break;
+                        case SRE_ASSERT_BIG_B:   hold = ((prev_here & PREV_WORD) != 0) == word_here; break;
+                        default: break;
+                        }
+                        if (!hold) continue;
+                        std::vector<uint32_t> sp_pc;
+                        std::vector<uint8_t>  sp_par;
+                        std::vector<uint64_t> sp_sav;
+                        uint64_t ds = 0;
+                        uint32_t dr = 0;
+                        b.gen = g_list;                               /* ctx->tag-- */
+                        b.closure(it.pc + 1, (prev_here & PREV_START) != 0,
+                                  (prev_here & (PREV_START | PREV_NL)) != 0, false, it.src,
+                                  sp_pc, sp_par, sp_sav, &ds, &dr, false);
+                        b.gen = g_new;                                /* ctx->tag++ */
+                        for (size_t k = sp_pc.size(); k-- > 0;) {
+                            work.push_front(Item{sp_pc[k], it.src, it.early | sp_sav[k]});
+                        }
+                        continue;
+                    }
                     if (eof || !b.consumes(in, (unsigned) c)) continue;
-                    uint64_t ds = 0;
-                    uint32_t dr = 0;
-                    if (b.closure(L[idx] + 1, false, c == '\n', true, (uint8_t) idx, &ds, &dr)) {
+                    uint64_t     ds = 0;
+                    uint32_t     dr = 0;
+                    const size_t before = b.nl.size();
+                    const bool   done = b.closure(it.pc + 1, false, c == '\n', true, it.src,
+                                                  b.nl, b.npar, b.nsav, &ds, &dr, true);
+                    for (size_t k = before; k < b.nl.size(); k++) b.nearly.push_back(it.early & ~b.nsav[k]);
+                    if (done) {
                         t.ev_kind = SRE_DFA_EV_DONE;                  /* :356-358, 535-553 */
-                        t.ev_src = (uint8_t) idx;
+                        t.ev_src = it.src;
                         t.ev_regex = (uint16_t) dr;
                         t.ev_saves = ds;
+                        t.ev_early = it.early & ~ds;
                         break;
                     }
                 }
                 t.next = b.intern(b.nl, was_matched || t.ev_kind != SRE_DFA_EV_NONE,
-                                  (base_flag || b.visited_start) ? 1 : 0, var);
+                                  (base_flag || b.visited_start) ? 1 : 0, var, prev_next);
             }
             t.lin_off = (uint32_t) d->lin_parent.size();
             t.lin_n = (uint16_t) b.nl.size();
             d->lin_parent.insert(d->lin_parent.end(), b.npar.begin(), b.npar.end());
             d->lin_saves.insert(d->lin_saves.end(), b.nsav.begin(), b.nsav.end());
+            d->lin_early.insert(d->lin_early.end(), b.nearly.begin(), b.nearly.end());
             d->trans.push_back(t);
         }
     }
@@ -336,6 +446,7 @@ sre_dfa_build(const sre_program_t *prog, uint32_t max_states, const char **why)
         t.lin_n = (uint16_t) lin_par_of_init[v].size();
         d->lin_parent.insert(d->lin_parent.end(), lin_par_of_init[v].begin(), lin_par_of_init[v].end());
         d->lin_saves.insert(d->lin_saves.end(), lin_sav_of_init[v].begin(), lin_sav_of_init[v].end());
+        d->lin_early.insert(d->lin_early.end(), lin_sav_of_init[v].size(), 0);
         d->trans.push_back(t);
     }
     return d;

@@ -11,8 +11,9 @@
  * same MATCH cut-off — on capture-free thread lists and memoises the results:
  * a deterministic automaton whose states ARE the reference's thread lists.
  * It is built eagerly at scanner creation (a compile step, independent of any
- * input), with a state cap; programs over the cap or containing look-ahead
- * assertions ($ \z \b \B) are declined and run on the exact VM kernel instead.
+ * input), with a state cap; programs over the cap are declined and run on the
+ * exact VM kernel instead.  Look-ahead assertions ($ \z \b \B) are decided by
+ * the next symbol inside the step (sre_dfa.cpp).
  *
  * Each transition additionally records, per surviving thread, which thread of
  * the previous list it descends from and which SAVE slots its closure path
@@ -50,6 +51,7 @@ struct sre_dfa_trans_t {
     uint8_t  ev_src;        /* index (old list) of the thread that reached MATCH */
     uint16_t ev_regex;
     uint64_t ev_saves;      /* DONE: slots saved on the way to MATCH (value pos + 1) */
+    uint64_t ev_early;      /* slots saved by a look-ahead splice in front of the event (value pos) */
     uint32_t lin_off;       /* into lin_parent / lin_saves: one entry per NEW thread */
     uint16_t lin_n;
     uint8_t  skipped;       /* leading-byte skip: list re-seeded, no thread stepped */
@@ -63,9 +65,14 @@ struct sre_dfa_s {
     uint32_t max_threads;           /* longest thread list of any state */
     uint32_t nslots;
     int      has_caret;             /* program contains ^ or \A */
+    int      has_lookahead;         /* program contains $ \z \b \B: valid from a FRESH context only
+                                       (init[SRE_DFA_INIT_START]); a re-armed search would need the
+                                       context's seen_word, which no initial list models */
     std::vector<sre_dfa_trans_t> trans;      /* [nstates][ncls + 1] */
     std::vector<uint8_t>         lin_parent; /* old-list index or SRE_DFA_NO_PARENT */
     std::vector<uint64_t>        lin_saves;  /* slots saved on the closure path (value pos + 1) */
+    std::vector<uint64_t>        lin_early;  /* slots saved by a look-ahead splice before the byte was
+                                                consumed (value pos), not saved again afterwards */
     std::vector<uint8_t>         matched;    /* [nstates] a match is pending in this state */
     std::vector<uint8_t>         seen_start; /* [nstates] 0/1, 2 = reached by a leading-byte skip */
     std::vector<uint16_t>        nthreads;   /* [nstates] list length */
@@ -82,8 +89,7 @@ typedef struct sre_dfa_s sre_dfa_t;
 #endif
 
 /* Build the automaton, or return NULL when the program is not admitted
- * (look-ahead assertions, more than `max_states` states, too many capture
- * slots).  `why` (optional) receives a static reason string. */
+ * (more than `max_states` states, too many capture slots).  `why` (optional) receives a static reason string. */
 sre_dfa_t *sre_dfa_build(const sre_program_t *prog, uint32_t max_states, const char **why);
 void sre_dfa_free(sre_dfa_t *dfa);
 

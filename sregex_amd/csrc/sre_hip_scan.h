@@ -44,7 +44,8 @@ typedef struct {
     uint16_t lin_n;
     uint8_t  skipped;
     uint8_t  pad;
-    uint64_t saves;         /* DONE: slots written on the way to MATCH */
+    uint64_t saves;         /* DONE: slots written on the way to MATCH (value pos + 1) */
+    uint64_t early;         /* slots written by a look-ahead splice in front of the event (value pos) */
 } sre_dev_trans_t;
 
 typedef struct {
@@ -59,6 +60,8 @@ typedef struct {
     const sre_dev_trans_t *trans;       /* [nstates][ncls + 1], then 3 pseudo rows for the initial closures */
     const uint8_t         *lin_parent;
     const uint64_t        *lin_saves;
+    const uint64_t        *lin_early;   /* NULL unless the program has look-ahead assertions: slots a
+                                           splice wrote before the byte was consumed (value pos) */
     const uint8_t         *lin_flags;   /* per new thread: bit0 its closure path saved a slot,
                                            bit1 it is the ".*?" ANY thread (pc 1) */
     uint32_t               lin_total, list_total;  /* entries of lin_* / list_pcs */

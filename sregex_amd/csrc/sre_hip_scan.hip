@@ -1334,7 +1334,16 @@ sre_k_captures(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
         }
         unresolved &= ~m;
     }
+    if (te.early & unresolved) {
+        /* SAVEs of a look-ahead splice in front of the event: the position itself */
+        const uint64_t m = te.early & unresolved;
+        for (uint32_t q = 0; q < T.nslots; q++) {
+            if ((m >> q) & 1) vec[q] = st.ev_pos;
+        }
+        unresolved &= ~m;
+    }
 
+    const uint64_t *const lin_early = tabp->lin_early;      /* global memory; rare */
     const uint64_t first = G.seg_first[s];
     const int64_t  seg = (int64_t) G.seg_bytes;
     const int64_t  k_sp = tr.sp / seg;
@@ -1386,6 +1395,14 @@ sre_k_captures(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
             if ((m >> q) & 1) vec[q] = val;
         }
         unresolved &= ~m;
+        if (lin_early != nullptr) {
+            /* written by a look-ahead splice before the byte was consumed */
+            const uint64_t m2 = lin_early[t->lin_off + j] & unresolved;
+            for (uint32_t q = 0; q < T.nslots; q++) {
+                if ((m2 >> q) & 1) vec[q] = val - 1;
+            }
+            unresolved &= ~m2;
+        }
         if (p == tr.sp) break;
         j = T.lin_parent[t->lin_off + j];
         if (j == 0xffu) break;              /* re-seeded by the leading-byte skip */

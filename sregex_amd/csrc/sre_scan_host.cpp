@@ -55,6 +55,10 @@ sre_scan_tables_build(const sre_program_t *prog, const sre_dfa_t *d, int mode, c
         *why = "COUNT with ^ or \\A needs the per-context newline flag";
         return NULL;
     }
+    if (mode == SRE_HIP_PIKE_COUNT && d->has_lookahead) {
+        *why = "COUNT with $ \\z \\b \\B needs the per-context word flag";
+        return NULL;
+    }
 
     const uint32_t nsym = d->ncls + 1;
     sre_scan_device_tables_t *t = new sre_scan_device_tables_t();
@@ -130,6 +134,7 @@ sre_scan_tables_build(const sre_program_t *prog, const sre_dfa_t *d, int mode, c
         b.lin_n = a.lin_n;
         b.skipped = a.skipped;
         b.saves = a.ev_saves;
+        b.early = a.ev_early;
     }
     std::vector<uint8_t> cls(d->cls_map, d->cls_map + 256);
     std::vector<uint8_t> flags(d->nstates);
@@ -142,7 +147,7 @@ sre_scan_tables_build(const sre_program_t *prog, const sre_dfa_t *d, int mode, c
     for (size_t i = 0; i < d->trans.size(); i++) {
         const sre_dfa_trans_t &a = d->trans[i];
         for (uint32_t j = 0; j < a.lin_n; j++) {
-            uint8_t f = d->lin_saves[a.lin_off + j] ? 1 : 0;
+            uint8_t f = (d->lin_saves[a.lin_off + j] | d->lin_early[a.lin_off + j]) ? 1 : 0;
             if (a.next != SRE_DFA_DEAD && d->list_pcs[d->list_off[a.next] + j] == 1) f |= 2;
             lin_flags[a.lin_off + j] = f;
         }
@@ -174,6 +179,7 @@ sre_scan_tables_build(const sre_program_t *prog, const sre_dfa_t *d, int mode, c
         || (e = upload(trans, &h.trans, t->owned)) != hipSuccess
         || (e = upload(d->lin_parent, &h.lin_parent, t->owned)) != hipSuccess
         || (e = upload(d->lin_saves, &h.lin_saves, t->owned)) != hipSuccess
+        || (d->has_lookahead && (e = upload(d->lin_early, &h.lin_early, t->owned)) != hipSuccess)
         || (e = upload(lin_flags, &h.lin_flags, t->owned)) != hipSuccess
         || (e = upload(flags, &h.state_flags, t->owned)) != hipSuccess
         || (e = upload(d->list_off, &h.list_off, t->owned)) != hipSuccess

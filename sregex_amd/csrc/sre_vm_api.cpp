@@ -177,6 +177,9 @@ pike_scan_route(sre_vm_pike_ctx_t *ctx, sre_char *input, size_t len, sre_int_t *
         }
     }
     if (ctx->scanner == NULL) return 0;
+    /* look-ahead assertions: the automaton models a FRESH context only (a
+     * re-armed search needs seen_word, sre_vm_pike.c:472-473, 594) */
+    if (ctx->prog->lookahead_asserts && (ctx->empty_capture || ctx->processed_bytes != 0)) return 0;
 
     size_t skip = 0;
     int    variant;

@@ -5,7 +5,7 @@
  * buffer and reconstructs captures from the lineage tables exactly the way the
  * device kernels do (forward state trace, backward parent walk).  It lets the
  * CPU test-suite check the automaton and the capture reconstruction against
- * the oracle on every assertion-free reference block without a GPU.  It is
+ * the oracle on every admitted reference block without a GPU.  It is
  * compiled by tests/test_dfa_model.py into tests/_build/ and is not part of,
  * nor linked into, the product library.
  */
@@ -73,6 +73,13 @@ void captures(const sre_dfa_t *d, const uint8_t *data, int64_t sp, int variant, 
             }
         }
     }
+    /* SAVEs of a look-ahead splice in front of the event: the position itself */
+    for (uint32_t k = 0; k < nslots; k++) {
+        if (((te.ev_early & unresolved) >> k) & 1) {
+            vec[k] = r.ev_pos;
+            unresolved &= ~(1ull << k);
+        }
+    }
     /* thread j lives in the list of state trace[p - sp] at position p */
     for (int64_t p = r.ev_pos; unresolved; p--) {
         uint32_t s_here = trace[(size_t) (p - sp)];
@@ -90,6 +97,11 @@ void captures(const sre_dfa_t *d, const uint8_t *data, int64_t sp, int variant, 
         uint64_t m = d->lin_saves[t->lin_off + j] & unresolved;
         for (uint32_t k = 0; k < nslots; k++) {
             if ((m >> k) & 1) vec[k] = val;
+        }
+        unresolved &= ~m;
+        m = d->lin_early[t->lin_off + j] & unresolved;      /* saved by a splice before the byte */
+        for (uint32_t k = 0; k < nslots; k++) {
+            if ((m >> k) & 1) vec[k] = val - 1;
         }
         unresolved &= ~m;
         if (p == sp) break;
@@ -112,6 +124,7 @@ void dfa_sim_free(void *d) { sre_dfa_free(static_cast<sre_dfa_t *>(d)); }
 uint32_t dfa_sim_nstates(void *d) { return static_cast<sre_dfa_t *>(d)->nstates; }
 uint32_t dfa_sim_ncls(void *d) { return static_cast<sre_dfa_t *>(d)->ncls; }
 uint32_t dfa_sim_max_threads(void *d) { return static_cast<sre_dfa_t *>(d)->max_threads; }
+int dfa_sim_has_lookahead(void *d) { return static_cast<sre_dfa_t *>(d)->has_lookahead; }
 
 /*
  * The find-all iteration (or a single exec when max_matches == 1) on ONE
