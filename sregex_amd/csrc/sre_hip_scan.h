@@ -43,7 +43,7 @@ typedef struct {
     uint32_t lin_off;       /* per new thread: parent / saves */
     uint16_t lin_n;
     uint8_t  skipped;
-    uint8_t  pad;
+    uint8_t  pad;           /* 1: the lineage map at lin_off is idempotent (sre_scan_host.cpp) */
     uint64_t saves;         /* DONE: slots written on the way to MATCH (value pos + 1) */
     uint64_t early;         /* slots written by a look-ahead splice in front of the event (value pos) */
 } sre_dev_trans_t;

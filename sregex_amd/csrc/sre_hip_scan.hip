@@ -1169,8 +1169,15 @@ sre_k_lineage_maps(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G
 
     uint64_t anc = 0xfedcba9876543210ull;       /* identity */
     uint32_t saved = 0, stop = 0;
+    uint32_t last_off = 0xffffffffu;            /* lineage vector applied by the previous byte */
     auto step = [&](uint32_t c) {
         const sre_dev_trans_t &tr = trl[cur * nsym + clsl[c]];
+        if (tr.pad && tr.lin_off == last_off) {
+            /* the same idempotent map again (a list looping in place): no change */
+            cur = tr.next;
+            return;
+        }
+        last_off = tr.lin_off;
         uint64_t nanc = 0;
         uint32_t nsaved = 0, nstop = 0;
         for (uint32_t j = 0; j < tr.lin_n; j++) {
@@ -1356,7 +1363,7 @@ sre_k_captures(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
             /* at a segment start: jump over the segments (blocks) in front of it
              * in which this lineage neither saved nor restarted */
             int64_t k2 = p / seg - 1;
-            while (k2 > k_sp) {
+            while (k2 >= k_sp) {        /* the search's own (partial) segment has a map too */
                 const uint64_t g2 = first + (uint64_t) k2;
                 if (g2 % SRE_LINEAGE_BLOCK == SRE_LINEAGE_BLOCK - 1
                     && k2 - (int64_t) SRE_LINEAGE_BLOCK > k_sp)
@@ -1373,7 +1380,7 @@ sre_k_captures(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
                 j = (uint32_t) ((m.anc >> (4 * j)) & 15ull);
                 k2--;
             }
-            p = (k2 + 1) * seg;
+            p = k2 < k_sp ? tr.sp : (k2 + 1) * seg;
         }
         if (!can_jump && --budget < 0 && T.max_threads <= 16) {
             status[s].need_maps = 1;         /* come back with the ancestor maps */

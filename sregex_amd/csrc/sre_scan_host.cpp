@@ -9,6 +9,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <map>
 #include <vector>
 
 template <typename T>
@@ -142,17 +143,66 @@ sre_scan_tables_build(const sre_program_t *prog, const sre_dfa_t *d, int mode, c
         flags[s] = (uint8_t) ((d->matched[s] ? 1 : 0) | (d->seen_start[s] << 1));
     }
     std::vector<uint32_t> ncaps(prog->multi_ncaps, prog->multi_ncaps + prog->nregexes);
-    /* per new thread of every transition: did its closure path save, is it the ANY thread */
-    std::vector<uint8_t> lin_flags(d->lin_parent.size(), 0);
-    for (size_t i = 0; i < d->trans.size(); i++) {
-        const sre_dfa_trans_t &a = d->trans[i];
-        for (uint32_t j = 0; j < a.lin_n; j++) {
-            uint8_t f = (d->lin_saves[a.lin_off + j] | d->lin_early[a.lin_off + j]) ? 1 : 0;
-            if (a.next != SRE_DFA_DEAD && d->list_pcs[d->list_off[a.next] + j] == 1) f |= 2;
-            lin_flags[a.lin_off + j] = f;
+    /* Lineage vectors, stored once per distinct content.  Per new thread of a
+     * transition: parent index, SAVE masks, and flag bits (bit0 its closure path
+     * saved a slot, bit1 it is the ".*?" ANY thread).  Equal lin_off therefore
+     * means equal lineage function, which sre_k_lineage_maps uses to skip runs
+     * of an idempotent one (a thread list looping in place: x+ over a long run
+     * of x). */
+    std::vector<uint8_t>  lin_parent, lin_flags;
+    std::vector<uint64_t> lin_saves, lin_early;
+    {
+        std::map<std::vector<uint64_t>, uint32_t> canon;
+        for (size_t i = 0; i < d->trans.size(); i++) {
+            const sre_dfa_trans_t &a = d->trans[i];
+            std::vector<uint64_t>  key;
+            std::vector<uint8_t>   fl(a.lin_n);
+            key.push_back(a.lin_n);
+            for (uint32_t j = 0; j < a.lin_n; j++) {
+                uint8_t f = (d->lin_saves[a.lin_off + j] | d->lin_early[a.lin_off + j]) ? 1 : 0;
+                if (a.next != SRE_DFA_DEAD && d->list_pcs[d->list_off[a.next] + j] == 1) f |= 2;
+                fl[j] = f;
+                key.push_back(d->lin_parent[a.lin_off + j] | ((uint64_t) f << 8));
+                key.push_back(d->lin_saves[a.lin_off + j]);
+                key.push_back(d->lin_early[a.lin_off + j]);
+            }
+            auto it = canon.find(key);
+            if (it == canon.end()) {
+                it = canon.emplace(key, (uint32_t) lin_parent.size()).first;
+                for (uint32_t j = 0; j < a.lin_n; j++) {
+                    lin_parent.push_back(d->lin_parent[a.lin_off + j]);
+                    lin_saves.push_back(d->lin_saves[a.lin_off + j]);
+                    lin_early.push_back(d->lin_early[a.lin_off + j]);
+                    lin_flags.push_back(fl[j]);
+                }
+            }
+            trans[i].lin_off = it->second;
+
+            /* idempotent: applying the map twice == once, for every input.  As
+             * (source, saved-constant, stop-constant) per entry; a source of
+             * NONE forces stop, and then the ancestor nibble is never used. */
+            const uint32_t off = it->second;
+            bool           idem = a.lin_n > 0 && a.lin_n <= 16;
+            for (uint32_t j = 0; idem && j < a.lin_n; j++) {
+                const uint32_t p1 = lin_parent[off + j];
+                const bool     c1 = (lin_flags[off + j] & 1) != 0, c2 = (lin_flags[off + j] & 2) != 0;
+                if (p1 == SRE_DFA_NO_PARENT) continue;          /* constant either way */
+                if (p1 >= a.lin_n) {
+                    idem = false;                               /* refers to a thread the new list lacks */
+                    break;
+                }
+                const uint32_t p2 = lin_parent[off + p1];
+                const bool     d1 = (lin_flags[off + p1] & 1) != 0, d2 = (lin_flags[off + p1] & 2) != 0;
+                /* twice: source p2 (through p1), constants c | d */
+                const bool stop_twice = c2 || d2 || p2 == SRE_DFA_NO_PARENT;
+                if (stop_twice != c2) idem = false;             /* once: stop = stop_in[p1] | c2 — differs unless forced equal */
+                if (!stop_twice && p2 != p1) idem = false;
+                if ((c1 || d1) != c1) idem = false;
+            }
+            trans[i].pad = idem ? 1 : 0;
         }
     }
-    h.lin_total = (uint32_t) d->lin_parent.size();
+    h.lin_total = (uint32_t) lin_parent.size();
     h.list_total = (uint32_t) d->list_pcs.size();
 
     {
@@ -177,9 +227,9 @@ sre_scan_tables_build(const sre_program_t *prog, const sre_dfa_t *d, int mode, c
         || (e = upload(fast_plain, &h.fast_plain, t->owned)) != hipSuccess
         || (e = upload(cls, &h.cls, t->owned)) != hipSuccess
         || (e = upload(trans, &h.trans, t->owned)) != hipSuccess
-        || (e = upload(d->lin_parent, &h.lin_parent, t->owned)) != hipSuccess
-        || (e = upload(d->lin_saves, &h.lin_saves, t->owned)) != hipSuccess
-        || (d->has_lookahead && (e = upload(d->lin_early, &h.lin_early, t->owned)) != hipSuccess)
+        || (e = upload(lin_parent, &h.lin_parent, t->owned)) != hipSuccess
+        || (e = upload(lin_saves, &h.lin_saves, t->owned)) != hipSuccess
+        || (d->has_lookahead && (e = upload(lin_early, &h.lin_early, t->owned)) != hipSuccess)
         || (e = upload(lin_flags, &h.lin_flags, t->owned)) != hipSuccess
         || (e = upload(flags, &h.state_flags, t->owned)) != hipSuccess
         || (e = upload(d->list_off, &h.list_off, t->owned)) != hipSuccess
