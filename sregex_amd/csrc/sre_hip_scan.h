@@ -109,7 +109,7 @@ typedef struct {
 } sre_seg_lineage_t;
 
 #define SRE_LINEAGE_BLOCK  256u     /* segments composed into one block map */
-#define SRE_WALK_BUDGET    2048     /* positions of plain backward walk before asking for the maps */
+#define SRE_WALK_BUDGET    256      /* positions of plain backward walk (~2 us each) before asking for the maps */
 
 /* per-stream outcome of verify + reduce */
 typedef struct {

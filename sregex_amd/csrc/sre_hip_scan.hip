@@ -1214,33 +1214,41 @@ sre_k_lineage_maps(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G
     maps[g] = out;
 }
 
-/* compose SRE_LINEAGE_BLOCK consecutive segment maps (global segment ids) */
-__global__ void
+/* compose SRE_LINEAGE_BLOCK consecutive segment maps (global segment ids):
+ * 16 adjacent lanes per block of segments, one per thread index */
+__global__ __launch_bounds__(256) void
 sre_k_lineage_blocks(uint64_t nsegs, const sre_seg_lineage_t *__restrict__ maps,
                      sre_seg_lineage_t *__restrict__ blocks)
 {
-    const uint64_t b = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t t = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t b = t / 16;
+    const uint32_t j = (uint32_t) (t % 16);
     const uint64_t g0 = b * SRE_LINEAGE_BLOCK;
-    if (g0 + SRE_LINEAGE_BLOCK > nsegs) return;
-    uint64_t anc = 0;
-    uint32_t blocked = 0;
-    for (uint32_t j = 0; j < 16; j++) {
-        uint32_t cur = j;
-        bool     bad = false;
+    const bool     live = g0 + SRE_LINEAGE_BLOCK <= nsegs;
+    uint32_t       cur = j;
+    bool           bad = false;
+    if (live) {
         for (int64_t g = (int64_t) (g0 + SRE_LINEAGE_BLOCK) - 1; g >= (int64_t) g0 && !bad; g--) {
             const sre_seg_lineage_t &m = maps[g];
             if (((m.saved | m.stop) >> cur) & 1u) bad = true;
             else cur = (uint32_t) ((m.anc >> (4 * cur)) & 15ull);
         }
-        if (bad) blocked |= 1u << j;
-        anc |= (uint64_t) cur << (4 * j);
     }
-    sre_seg_lineage_t out;
-    out.anc = anc;
-    out.saved = (uint16_t) blocked;
-    out.stop = 0;
-    out.pad = 0;
-    blocks[b] = out;
+    /* gather the 16 results of a block of segments in its first lane */
+    uint64_t anc = (uint64_t) cur << (4 * j);
+    uint32_t blocked = bad ? 1u << j : 0u;
+    for (int d = 8; d >= 1; d >>= 1) {
+        anc |= __shfl_down(anc, d, 16);
+        blocked |= __shfl_down(blocked, d, 16);
+    }
+    if (live && j == 0) {
+        sre_seg_lineage_t out;
+        out.anc = anc;
+        out.saved = (uint16_t) blocked;
+        out.stop = 0;
+        out.pad = 0;
+        blocks[b] = out;
+    }
 }
 
 __global__ __launch_bounds__(64) void
@@ -1562,7 +1570,7 @@ sre_launch_lineage(const sre_scan_tables_t *d_tab, sre_scan_tables_t h_tab, sre_
                        d_status, d_maps);
     const uint64_t nblocks = geom.nsegs / SRE_LINEAGE_BLOCK;
     if (nblocks) {
-        hipLaunchKernelGGL(sre_k_lineage_blocks, dim3((uint32_t) ((nblocks + 63) / 64)), dim3(64), 0,
+        hipLaunchKernelGGL(sre_k_lineage_blocks, dim3((uint32_t) ((nblocks * 16 + 255) / 256)), dim3(256), 0,
                            stream, geom.nsegs, d_maps, d_blocks);
     }
     return hipGetLastError();
