@@ -1197,12 +1197,27 @@ sre_k_lineage_maps(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G
     };
     int64_t q = lo;
     if ((reinterpret_cast<uintptr_t>(data) & 15) == 0) {
-        for (; q < hi && (q & 15); q++) step(data[q]);
-        for (; q + 16 <= hi; q += 16) {
-            const uint4    v = *reinterpret_cast<const uint4 *>(data + q);
-            const uint32_t words[4] = {v.x, v.y, v.z, v.w};
+        for (; q < hi && (q & 63); q++) step(data[q]);
+        /* 64 bytes per turn, the next 64 already in flight */
+        uint4 nx[4];
+        if (q + 64 <= hi) {
 #pragma unroll
-            for (int b = 0; b < 16; b++) step((words[b >> 2] >> ((b & 3) * 8)) & 0xffu);
+            for (int x = 0; x < 4; x++) nx[x] = *reinterpret_cast<const uint4 *>(data + q + 16 * x);
+        }
+        for (; q + 64 <= hi; q += 64) {
+            uint4 v[4];
+#pragma unroll
+            for (int x = 0; x < 4; x++) v[x] = nx[x];
+            if (q + 128 <= hi) {
+#pragma unroll
+                for (int x = 0; x < 4; x++) nx[x] = *reinterpret_cast<const uint4 *>(data + q + 64 + 16 * x);
+            }
+#pragma unroll
+            for (int x = 0; x < 4; x++) {
+                const uint32_t words[4] = {v[x].x, v[x].y, v[x].z, v[x].w};
+#pragma unroll
+                for (int b = 0; b < 16; b++) step((words[b >> 2] >> ((b & 3) * 8)) & 0xffu);
+            }
         }
     }
     for (; q < hi; q++) step(data[q]);
