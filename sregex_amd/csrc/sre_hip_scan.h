@@ -34,10 +34,13 @@
 #define SRE_SCAN_LINE         128u    /* staging granule: whole lines, half a wave per stage; also the warm-up */
 #define SRE_SCAN_SEG_ALIGN    256u    /* segments are a multiple of the line size */
 
+/* device-only event kind: a DONE (match end = pos + 1) whose match is empty */
+#define SRE_DEV_EV_DONE_EMPTY 3
+
 /* full transition record (global memory; slow path and lineage kernels) */
 typedef struct {
     uint32_t next;
-    uint8_t  kind;          /* SRE_DFA_EV_* */
+    uint8_t  kind;          /* SRE_DFA_EV_*, or SRE_DEV_EV_DONE_EMPTY */
     uint8_t  src;           /* matching thread's index in the old list */
     uint16_t regex;
     uint32_t lin_off;       /* per new thread: parent / saves */

@@ -186,6 +186,17 @@ stream_of(const sre_scan_geom_t &G, uint64_t g)
     return a;
 }
 
+/* Initial list of a search that starts at sp > 0 on a re-armed context: ^ holds
+ * iff the byte in front of it is a newline — for a search after a non-empty
+ * match that byte is the match's last one (seen_newline, sre_vm_pike.c:586-601),
+ * after an empty match it is the byte the caller skipped (:179-196).  (Without
+ * ^ in the program the three initial lists coincide.) */
+__device__ inline uint32_t
+restart_variant(const uint8_t *data, int64_t sp)
+{
+    return data[sp - 1] == '\n' ? 1u : 2u;
+}
+
 /* the search a lane is currently following */
 struct Walk {
     const sre_scan_tables_t *T;
@@ -317,8 +328,9 @@ __device__ void slow_run(Walk &w, int64_t p, int64_t p_to, bool warm, uint32_t w
         {
             /* next exec: from the match end; one byte further after an empty
              * match (sre_vm_pike.c:179-196, 624-628) */
-            const bool    empty = (w.ev_kind == EV_POP);
-            const int64_t e = empty ? w.ev_pos : w.ev_pos + 1;
+            const bool    pop = (w.ev_kind == EV_POP);
+            const bool    empty = pop || w.ev_kind == SRE_DEV_EV_DONE_EMPTY;
+            const int64_t e = pop ? w.ev_pos : w.ev_pos + 1;
             w.complete_match();
             if (empty) {
                 if (e >= w.n) {
@@ -330,7 +342,7 @@ __device__ void slow_run(Walk &w, int64_t p, int64_t p_to, bool warm, uint32_t w
             } else {
                 w.cur_sp = e;
             }
-            w.st = T.init[2];
+            w.st = T.init[restart_variant(w.data, w.cur_sp)];
             p = w.cur_sp;
             w.anchor_pos = -1;      /* the round's entry state belonged to the previous search */
         }
@@ -368,7 +380,7 @@ resolve_fast_span(const sre_scan_tables_t *Tp, const uint8_t *data, int64_t gpos
             r.last_sym = sym;
             r.last_sp = r.sp;
             r.sp = gpos + b + 1;
-            st = T.init[2];
+            st = T.init[restart_variant(data, r.sp)];
         } else {
             st = tr.next;
         }
@@ -1164,7 +1176,7 @@ sre_k_lineage_maps(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G
     if (k == st.ev_seg && st.ev_pos < hi) hi = st.ev_pos;      /* list at the event position */
     if (sp >= lo) {
         lo = sp;
-        cur = T.init[sp == 0 ? G.init_variant : 2];
+        cur = T.init[sp == 0 ? G.init_variant : restart_variant(data, sp)];
     }
 
     uint64_t anc = 0xfedcba9876543210ull;       /* identity */
@@ -1342,7 +1354,8 @@ sre_k_captures(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
     tr.n = (int64_t) G.lens[s];
     tr.sp = st.ev_sp;
     tr.seg_bytes = G.seg_bytes;
-    tr.init_state = T.init[st.ev_sp == 0 ? G.init_variant : 2];
+    const uint32_t variant = st.ev_sp == 0 ? G.init_variant : restart_variant(tr.data, st.ev_sp);
+    tr.init_state = T.init[variant];
     tr.apos = (st.ev_apos >= st.ev_sp) ? st.ev_apos : -1;
     tr.astate = st.ev_astate;
     tr.ck = scratch + (size_t) s * (G.seg_bytes + 16);
@@ -1357,7 +1370,7 @@ sre_k_captures(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
 
     const sre_dev_trans_t &te = T.trans[(size_t) st.ev_state * nsym + st.ev_sym];
     uint32_t               j = te.src;
-    if (te.kind == EV_DONE) {
+    if (te.kind == EV_DONE || te.kind == SRE_DEV_EV_DONE_EMPTY) {
         const uint64_t m = te.saves & unresolved;
         for (uint32_t q = 0; q < T.nslots; q++) {
             if ((m >> q) & 1) vec[q] = st.ev_pos + 1;
@@ -1414,7 +1427,7 @@ sre_k_captures(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
         const sre_dev_trans_t *t;
         int64_t                val;
         if (p == tr.sp) {
-            t = &T.trans[(size_t) T.nstates * nsym + (tr.sp == 0 ? G.init_variant : 2)];   /* initial closure */
+            t = &T.trans[(size_t) T.nstates * nsym + variant];   /* initial closure */
             val = tr.sp;
         } else {
             t = &T.trans[(size_t) tr.state_before(p - 1) * nsym + T.cls[tr.data[p - 1]]];

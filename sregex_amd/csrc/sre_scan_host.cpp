@@ -52,8 +52,10 @@ sre_scan_tables_build(const sre_program_t *prog, const sre_dfa_t *d, int mode, c
         *why = "thread lists longer than 254";
         return NULL;
     }
-    if (mode == SRE_HIP_PIKE_COUNT && d->has_caret) {
-        *why = "COUNT with ^ or \\A needs the per-context newline flag";
+    if (mode == SRE_HIP_PIKE_COUNT && d->has_caret && prog->nregexes > 1) {
+        /* the newline flag of a re-armed context comes from slot 1, i.e. from
+         * regex 0's group 0 whatever regex matched (sre_vm_pike.c:586-601) */
+        *why = "COUNT with ^ or \\A over several regexes needs the per-context newline flag";
         return NULL;
     }
     if (mode == SRE_HIP_PIKE_COUNT && d->has_lookahead) {
@@ -82,6 +84,18 @@ sre_scan_tables_build(const sre_program_t *prog, const sre_dfa_t *d, int mode, c
     const uint32_t stride = 8 / bits;
     h.stride = stride;
     h.class_bits = bits;
+    /* is class k the newline?  (classes separate it whenever ^ is in the program) */
+    std::vector<uint8_t> rep_is_nl(d->ncls + 1, 0);
+    if (d->has_caret) rep_is_nl[d->cls_map[(unsigned char) '\n']] = 1;
+    /* a DONE whose closure also saved the matched regex's group-0 start: the
+     * match is empty (start == end == pos + 1) although a byte was consumed —
+     * the ".*?" thread stepping into a nullable regex behind an assertion */
+    auto done_is_empty = [&](const sre_dfa_trans_t &tr) -> bool {
+        if (tr.ev_kind != SRE_DFA_EV_DONE) return false;
+        uint32_t slot0 = 0;
+        for (uint32_t i = 0; i < tr.ev_regex; i++) slot0 += 2 * (prog->multi_ncaps[i] + 1);
+        return ((tr.ev_saves >> slot0) & 1) != 0;
+    };
     auto build_fast = [&](int fmode) {
     std::vector<uint32_t> fast((size_t) d->nstates * 256);
     for (uint32_t s = 0; s < d->nstates; s++) {
@@ -96,11 +110,12 @@ sre_scan_tables_build(const sre_program_t *prog, const sre_dfa_t *d, int mode, c
                 }
                 const sre_dfa_trans_t &tr = d->t(st, k);
                 if (fmode == SRE_HIP_PIKE_COUNT && tr.ev_kind == SRE_DFA_EV_DONE
-                    && tr.next == SRE_DFA_DEAD)
+                    && tr.next == SRE_DFA_DEAD && !done_is_empty(tr))
                 {
                     /* a non-empty match completes and nothing outlives it: the
                      * next search starts at the next byte (sre_vm_pike.c:624-628) */
-                    st = d->init[SRE_DFA_INIT_RESTART];
+                    /* the byte in front of that search is the one just consumed */
+                    st = d->init[rep_is_nl[k] ? SRE_DFA_INIT_RESTART_NL : SRE_DFA_INIT_RESTART];
                     cnt++;
                     last = sub;
                 } else if (tr.ev_kind != SRE_DFA_EV_NONE || tr.next == SRE_DFA_DEAD) {
@@ -128,7 +143,7 @@ sre_scan_tables_build(const sre_program_t *prog, const sre_dfa_t *d, int mode, c
         sre_dev_trans_t       &b = trans[i];
         memset(&b, 0, sizeof(b));
         b.next = a.next;
-        b.kind = a.ev_kind;
+        b.kind = done_is_empty(a) ? SRE_DEV_EV_DONE_EMPTY : a.ev_kind;
         b.src = a.ev_src;
         b.regex = a.ev_regex;
         b.lin_off = a.lin_off;

@@ -192,6 +192,8 @@ def test_scanner_segments_vs_oracle(gpu, seg):
         [rb"a?a?a?aaa"], [rb"(a+)(b+)?"], [rb"(?:a.*b|a)"], [rb"x*"], [rb"(a|ab)(c|bcd)(d*)"],
         [b"a", b"ab", b"c", b"a(bc)", b"e(f)", b"gh", b"A", b"b", b"BLAH", rb"\s+", b"abcd", b"bc"],
         [rb"(a*)*b"], [rb"a.c"], [rb"\Aab|\n^b"], [rb"(x+x+)+y"], [rb"[ab]c?"], [rb"(a|b)*?c"],
+        # ^ in find-all counting: the initial list of every re-armed search depends on the byte in front
+        [rb"^a|^c|c"], [rb"^b+"], [rb"^x*"], [rb"(^|a)b"],
         # look-ahead assertions, decided inside the automaton step (FIRST / Thompson only)
         [rb"(\w+)\b(.)"], [rb"c$"], [rb"^(.*)$"], [rb"(a+)\b(?:\s|$)"], [rb"(\B.)*?\b(x)"], [rb"(b)\z"],
         [rb"a$", rb"\bb"], [rb"(?:$|a)(b|\b)"],
