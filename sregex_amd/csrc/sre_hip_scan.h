@@ -20,11 +20,11 @@
  *   bits 1..4    COUNT mode: matches completed inside this step, each followed
  *                by a restart at the next byte (the entry points at the state
  *                reached after the last restart)
- *   bits 5..7    COUNT mode: sub-step index of the last such completion */
+ * (global-memory format; sre_k_scan re-packs an entry for LDS as
+ *  [count : 8][flags : 8][LDS address of the next row : 16]) */
 #define SRE_FAST_SLOW       1u
 #define SRE_FAST_CNT_SHIFT  1u
 #define SRE_FAST_CNT_MASK   0xfu
-#define SRE_FAST_LAST_SHIFT 5u
 #define SRE_FAST_ROW_BYTES  1024u
 
 #define SRE_SCAN_MAX_STATES   55u     /* the fast table (1 KiB per state) must end below 64 KiB of LDS */

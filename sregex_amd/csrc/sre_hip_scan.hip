@@ -3,15 +3,17 @@
  * two utility kernels of the measurement harness.
  *
  * Data layout.  A stream is cut into fixed segments; ONE LANE walks ONE
- * SEGMENT, so a wavefront advances 64 independent segments per step and every
- * input byte is examined by exactly one lane (plus a 256-byte speculative
- * warm-up per segment).  A workgroup of 256 lanes stages its 256 segments
- * through LDS in 64-byte rows: the global loads are 16 B per lane with four
- * consecutive lanes covering one 64-byte row piece (coalesced, each 128-byte
- * line is fetched once), the rows are padded to 80 bytes so that the per-lane
- * ds_read_b128 of "my row" is bank-conflict free.  The automaton's fast table
- * (one 32-bit word per state x byte, <= 64 KiB) lives in LDS next to the tile;
- * the per-byte work of a lane is one dependent LDS lookup.
+ * SEGMENT, 64 bytes per round, so a wavefront advances 64 independent segments
+ * per step and every input byte is examined by exactly one lane (plus a
+ * 128-byte speculative warm-up per segment).  A workgroup of 256 lanes stages
+ * its 256 segments through LDS in whole 128-byte lines: one line per row for
+ * half a wave per stage, 4 x 16-byte global loads per lane with eight adjacent
+ * lanes per line, one stage ahead of its use (tile_fetch).  The fetching lane
+ * classifies the bytes and stores ready-made fast-table indices (tile_store);
+ * rows are padded so that the per-lane ds_read_b128 of "my row" is
+ * bank-conflict free.  The automaton's fast table (one 32-bit word per state x
+ * index, below 64 KiB) lives in LDS next to the tile; the per-step work of a
+ * lane is one add and one dependent LDS lookup per 8 / BITS input bytes.
  *
  * Exactness.  A lane does not know the true automaton state at the start of
  * its segment; it assumes the state reached after a short warm-up and records

@@ -100,7 +100,7 @@ sre_scan_tables_build(const sre_program_t *prog, const sre_dfa_t *d, int mode, c
     std::vector<uint32_t> fast((size_t) d->nstates * 256);
     for (uint32_t s = 0; s < d->nstates; s++) {
         for (unsigned idx = 0; idx < 256; idx++) {
-            uint32_t st = s, flags = 0, cnt = 0, last = 0;
+            uint32_t st = s, flags = 0, cnt = 0;
             for (uint32_t sub = 0; sub < stride && !(flags & SRE_FAST_SLOW); sub++) {
                 /* sub-step `sub` consumes input byte `sub` of the group */
                 const uint32_t k = bits == 8 ? d->cls_map[idx] : ((idx >> (sub * bits)) & ((1u << bits) - 1));
@@ -117,7 +117,6 @@ sre_scan_tables_build(const sre_program_t *prog, const sre_dfa_t *d, int mode, c
                     /* the byte in front of that search is the one just consumed */
                     st = d->init[rep_is_nl[k] ? SRE_DFA_INIT_RESTART_NL : SRE_DFA_INIT_RESTART];
                     cnt++;
-                    last = sub;
                 } else if (tr.ev_kind != SRE_DFA_EV_NONE || tr.next == SRE_DFA_DEAD) {
                     flags |= SRE_FAST_SLOW;
                 } else {
@@ -126,10 +125,10 @@ sre_scan_tables_build(const sre_program_t *prog, const sre_dfa_t *d, int mode, c
             }
             if (flags & SRE_FAST_SLOW) {
                 st = s;
-                cnt = last = 0;
+                cnt = 0;
             }
             fast[(size_t) s * 256 + idx] = st * SRE_FAST_ROW_BYTES | flags
-                                           | (cnt << SRE_FAST_CNT_SHIFT) | (last << SRE_FAST_LAST_SHIFT);
+                                           | (cnt << SRE_FAST_CNT_SHIFT);
         }
     }
     return fast;
