@@ -268,3 +268,30 @@ def findall(engine, prog, ncaps, data, limit=1 << 30):
         off = p.ovector[1]
     p.close()
     return out
+
+
+# ------------------------------------------------------------------ random patterns
+
+def random_regex(rng, depth=0):
+    """A random pattern over a small alphabet, from the constructs the reference
+    parser accepts: literals, classes, '.', groups, alternation, greedy and lazy
+    quantifiers, counted repeats, and every assertion."""
+    atoms = [b"a", b"b", b"c", b"x", b".", b"[ab]", b"[^a]", b"\\w", b"\\s", b"\\n", b"[a-c]"]
+    asserts = [b"^", b"$", b"\\b", b"\\B", b"\\A", b"\\z"]
+    n = rng.randrange(1, 5 if depth == 0 else 4)
+    seq = []
+    for _ in range(n):
+        r = rng.random()
+        if r < 0.12:
+            piece = rng.choice(asserts)
+        elif r < 0.30 and depth < 2:
+            inner = random_regex(rng, depth + 1)
+            if rng.random() < 0.5:
+                inner += b"|" + random_regex(rng, depth + 1)
+            piece = (b"(" if rng.random() < 0.7 else b"(?:") + inner + b")"
+        else:
+            piece = rng.choice(atoms)
+        if piece not in asserts and rng.random() < 0.45:
+            piece += rng.choice([b"*", b"+", b"?", b"*?", b"+?", b"??", b"{2}", b"{1,3}", b"{0,2}?"])
+        seq.append(piece)
+    return b"".join(seq)

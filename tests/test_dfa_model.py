@@ -177,6 +177,42 @@ def test_model_lookahead_assertions_vs_oracle(sim):
             sim.dfa_sim_free(d)
 
 
+def test_model_random_patterns_vs_oracle(sim):
+    """Differential test of the automaton + lineage walk: random patterns (all
+    constructs, all assertions) x random subjects against the oracle."""
+    ora = harness.OracleEngine()
+    rng = random.Random(424242)
+    alphabet = b"abcx \n_."
+    built = 0
+    for _ in range(400):
+        nre = 1 if rng.random() < 0.8 else rng.randrange(2, 4)
+        pats = [harness.random_regex(rng) for _ in range(nre)]
+        with S.Pool() as pool:
+            re = S.parse(pool, pats)
+            prog = S.compile(pool, re)
+            d, why = _build(sim, prog)
+            if not d:
+                continue
+            built += 1
+            look = sim.dfa_sim_has_lookahead(d)
+            for _ in range(8):
+                data = bytes(rng.choice(alphabet) for _ in range(rng.choice([0, 1, 2, 5, 17, 40, 90])))
+                want = harness.findall(ora, prog, re.ncaps, data, 1 if look else 1 << 30)
+                if look:
+                    want = [] if want[0][0] < 0 else want[:1]
+                    got = _findall(sim, d, prog, re.ncaps, data, 1)
+                else:
+                    if want[-1] != [S.SRE_ERROR]:
+                        want = want[:-1]
+                    got = _findall(sim, d, prog, re.ncaps, data)
+                assert got == want, (pats, data)
+                t = ora.thompson(prog)
+                assert sim.dfa_sim_thompson(d, data, len(data)) == t.exec(data, True), (pats, data)
+                t.close()
+            sim.dfa_sim_free(d)
+    assert built > 300, built
+
+
 def test_builder_declines_what_it_cannot_model(sim):
     with S.Pool() as pool:
         d, why = _build(sim, S.compile(pool, S.parse(pool, [rb"[ab]*a[ab]{12}"])), 256)

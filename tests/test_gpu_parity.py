@@ -360,3 +360,57 @@ def test_full_size_streams_closed_form_properties(gpu):
             assert rec == expect(L), (pats, tail, rec, expect(L))
             assert sc.last_fixups == 0
     buf.free()
+
+
+# ------------------------------------------------------------ randomised differential
+
+@pytest.mark.parametrize("seg", [64, 0])
+def test_scanner_random_patterns_vs_oracle(gpu, seg):
+    """Differential test: random patterns x random subjects, every mode the
+    scanner admits, against the oracle (tiny segments force speculation)."""
+    import random
+    ora = harness.OracleEngine()
+    rng = random.Random(20261004 + seg)
+    alphabet = b"abcx \n_."
+    tested = admitted = 0
+    for _ in range(600):
+        nre = 1 if rng.random() < 0.8 else rng.randrange(2, 4)
+        pats = [harness.random_regex(rng) for _ in range(nre)]
+        with S.Pool() as pool:
+            try:
+                re = S.parse(pool, pats)
+            except Exception:
+                continue
+            prog = S.compile(pool, re)
+            scs = {}
+            for mode in (S.HIP_THOMPSON, S.HIP_PIKE_FIRST, S.HIP_PIKE_COUNT):
+                try:
+                    sc = S.Scanner(pool, prog, mode, S.ENGINE_SCAN)
+                except RuntimeError:
+                    continue
+                if seg:
+                    sc.set_segment_bytes(seg)
+                scs[mode] = sc
+            tested += 1
+            if not scs:
+                continue
+            admitted += 1
+            datas = [bytes(rng.choice(alphabet) for _ in range(rng.choice([0, 1, 7, 64, 65, 130, 400])))
+                     for _ in range(6)]
+            bufs = [S.DeviceBuffer.from_bytes(d) for d in datas]
+            ptrs, lens = [b.ptr for b in bufs], [len(d) for d in datas]
+            got = {m: sc.scan(ptrs, lens) for m, sc in scs.items()}
+            for i, d in enumerate(datas):
+                first, cnt = _expect(ora, prog, re.ncaps, d)
+                if S.HIP_PIKE_FIRST in got:
+                    assert got[S.HIP_PIKE_FIRST][i] == first, (pats, seg, d)
+                if S.HIP_THOMPSON in got:
+                    t = ora.thompson(prog)
+                    want = t.exec(d, True)
+                    t.close()
+                    assert got[S.HIP_THOMPSON][i][0] == want, (pats, seg, d)
+                if S.HIP_PIKE_COUNT in got:
+                    assert got[S.HIP_PIKE_COUNT][i] == cnt, (pats, seg, d)
+            for b in bufs:
+                b.free()
+    assert admitted > 400, (tested, admitted)
