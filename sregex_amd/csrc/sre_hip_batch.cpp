@@ -454,6 +454,17 @@ sre_hip_scan_results(sre_hip_scanner_t *sc, sre_int_t *results)
             }
         }
     }
+    if (sc->engine == SRE_HIP_ENGINE_SCAN && getenv("SRE_HIP_DEBUG_STATUS")) {
+        /* diagnostics: what the chain check decided per stream */
+        for (size_t i = 0; i < n && i < 8; i++) {
+            const sre_stream_status_t &t = sc->h_status[i];
+            fprintf(stderr, "[sregex-hip] stream %zu: rc %lld count %lld ev_pos %lld ev_sp %lld ev_state %u ev_sym %u "
+                            "ev_apos %lld ev_astate %u ev_seg %lld limit %lld need_maps %d seg %u\n",
+                    i, (long long) t.rc, (long long) t.count, (long long) t.ev_pos, (long long) t.ev_sp,
+                    t.ev_state, t.ev_sym, (long long) t.ev_apos, t.ev_astate, (long long) t.ev_seg,
+                    (long long) t.limit, t.need_maps, sc->geom.seg_bytes);
+        }
+    }
     if (!settled) {
         SRE_HIP_TRY(hipMemcpyAsync(sc->h_records, sc->d_records, bytes, hipMemcpyDeviceToHost, stream));
         SRE_HIP_TRY(hipStreamSynchronize(stream));

@@ -123,7 +123,9 @@ typedef struct {
     int64_t  ev_pos, ev_sp;
     uint32_t ev_state, ev_sym;
     int64_t  ev_apos;       /* anchor: a known state shortly before the event, -1 none */
-    uint32_t ev_astate, pad0;
+    uint32_t ev_astate;
+    uint32_t valid_from;    /* set by sre_k_captures: first segment whose recorded entry state belongs
+                               to the event's search (see Tracer::entry_state) */
     int64_t  ev_seg;        /* segment holding the event */
     int32_t  done;          /* 1: result final, 0: needs a fix-up round from first_bad */
     int32_t  error;         /* COUNT: the iteration ended with SRE_ERROR */

@@ -955,7 +955,7 @@ sre_k_verify_c(sre_scan_tables_t T, sre_scan_geom_t G, const sre_seg_summary_t *
     st.ev_state = st.ev_sym = 0;
     st.ev_apos = -1;
     st.ev_astate = 0;
-    st.pad0 = 0;
+    st.valid_from = 0;
     st.ev_seg = -1;
     if (done && evseg > 0) {
         const sre_seg_summary_t &c = sum[first + evseg - 1];
@@ -995,6 +995,20 @@ sre_k_verify_c(sre_scan_tables_t T, sre_scan_geom_t G, const sre_seg_summary_t *
 
 /* =================================================================== captures */
 
+/* First segment whose recorded entry state belongs to the search that started
+ * at sp and holds the final event (Tracer::entry_state): the one behind the
+ * segment whose lane (re)started that search, i.e. the first lane from sp's
+ * segment on that ends with cur_sp == sp.  One search per stream (FIRST /
+ * Thompson): the lane of sp's segment itself. */
+__device__ inline int64_t
+first_valid_segment(const sre_seg_summary_t *sum, int64_t sp, int64_t seg_bytes, int64_t ev_seg)
+{
+    for (int64_t k = sp / seg_bytes; k <= ev_seg; k++) {
+        if (sum[k].cur_sp == sp) return k + 1;
+    }
+    return ev_seg + 1;          /* nothing recorded can be taken: replay from sp */
+}
+
 /*
  * One lane per stream.  The winning thread's capture vector is rebuilt by
  * walking its lineage backwards from the match event (sre_dfa.h).  The state
@@ -1017,6 +1031,8 @@ struct Tracer {
     uint16_t                *trace;     /* states before each position of the loaded 64-byte block */
     int64_t                  seg_lo, seg_hi;    /* loaded segment: [seg_lo, seg_hi], -1 none */
     int64_t                  blk_lo, blk_hi;
+    int64_t                  valid_from;        /* see entry_state */
+    uint32_t                 seg_entry;         /* state before seg_lo */
 
     __device__ inline uint32_t step(uint32_t st, int64_t q) const
     {
@@ -1049,6 +1065,26 @@ struct Tracer {
         return so / SRE_FAST_ROW_BYTES;
     }
 
+    /*
+     * State of THIS search (the one that started at sp) before the first byte
+     * of segment kq > sp's segment.  The entry state a scan lane recorded
+     * (s_in) is the state in scan order; it belongs to this search only from
+     * the segment behind the one in which the search was started in scan order:
+     * in COUNT mode the previous match may have been completed segments later
+     * than it ended (its list lived on), and the lane that completed it then
+     * walked back to sp — the entry states of the segments in between belong
+     * to the older search.  `valid_from` (first_valid_segment above) is the
+     * first segment whose s_in can be taken; in front of it the state is
+     * replayed from sp.
+     */
+    __device__ uint32_t entry_state(int64_t kq) const
+    {
+        if (kq >= valid_from) return sum[kq].s_in;
+        uint32_t cur = init_state;
+        for (int64_t q = sp; q < kq * (int64_t) seg_bytes; q++) cur = step(cur, q);
+        return cur;
+    }
+
     /* checkpoint segment kq up to (and including the block of) position upto */
     __device__ void load_segment(int64_t kq, int64_t upto)
     {
@@ -1060,10 +1096,11 @@ struct Tracer {
             lo = sp;
             cur = init_state;
         } else {
-            cur = sum[kq].s_in;
+            cur = entry_state(kq);
         }
         seg_lo = lo;
         seg_hi = hi;
+        seg_entry = cur;
         /* ck[i] = state before position c0 + 64 * i, c0 = lo rounded up to 64 */
         const int64_t c0 = (lo + 63) & ~(int64_t) 63;
         int64_t       q = lo;
@@ -1110,7 +1147,7 @@ struct Tracer {
             if (lo < c0) {
                 /* in front of the first checkpoint: replay from the segment entry */
                 lo = seg_lo;
-                cur = (seg_lo == sp) ? init_state : sum[seg_lo / seg_bytes].s_in;
+                cur = seg_entry;
                 hi = c0 < seg_hi ? c0 : seg_hi;
             } else {
                 cur = ck[(lo - c0) / 64];
@@ -1179,6 +1216,10 @@ sre_k_lineage_maps(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G
     if (sp >= lo) {
         lo = sp;
         cur = T.init[sp == 0 ? G.init_variant : restart_variant(data, sp)];
+    } else if (k < (int64_t) st.valid_from) {
+        /* the recorded entry state belongs to an older search (Tracer::entry_state) */
+        cur = T.init[sp == 0 ? G.init_variant : restart_variant(data, sp)];
+        for (int64_t x = sp; x < lo; x++) cur = trl[cur * nsym + clsl[data[x]]].next;
     }
 
     uint64_t anc = 0xfedcba9876543210ull;       /* identity */
@@ -1365,6 +1406,9 @@ sre_k_captures(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
     tr.seg_lo = tr.seg_hi = -1;
     tr.blk_lo = 1;
     tr.blk_hi = 0;
+    tr.seg_entry = 0;
+    tr.valid_from = first_valid_segment(tr.sum, tr.sp, (int64_t) G.seg_bytes, st.ev_seg);
+    status[s].valid_from = (uint32_t) tr.valid_from;
 
     int64_t  vec[64];
     uint64_t unresolved = T.nslots >= 64 ? ~0ull : ((1ull << T.nslots) - 1);
@@ -1425,6 +1469,10 @@ sre_k_captures(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
             return;
         }
         const uint32_t s_here = (p == st.ev_pos) ? st.ev_state : tr.state_before(p);
+#ifdef SRE_DEBUG_WALK
+        printf("walk p %lld s_here %u j %u pc %u unresolved %llx\n", (long long) p, s_here, j,
+               T.list_pcs[T.list_off[s_here] + j], (unsigned long long) unresolved);
+#endif
         if (T.list_pcs[T.list_off[s_here] + j] == 1) break;      /* the ".*?" ANY thread */
         const sre_dev_trans_t *t;
         int64_t                val;

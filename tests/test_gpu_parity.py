@@ -403,14 +403,14 @@ def test_scanner_random_patterns_vs_oracle(gpu, seg):
             for i, d in enumerate(datas):
                 first, cnt = _expect(ora, prog, re.ncaps, d)
                 if S.HIP_PIKE_FIRST in got:
-                    assert got[S.HIP_PIKE_FIRST][i] == first, (pats, seg, d)
+                    assert got[S.HIP_PIKE_FIRST][i] == first, (pats, seg, d.hex())
                 if S.HIP_THOMPSON in got:
                     t = ora.thompson(prog)
                     want = t.exec(d, True)
                     t.close()
-                    assert got[S.HIP_THOMPSON][i][0] == want, (pats, seg, d)
+                    assert got[S.HIP_THOMPSON][i][0] == want, (pats, seg, d.hex())
                 if S.HIP_PIKE_COUNT in got:
-                    assert got[S.HIP_PIKE_COUNT][i] == cnt, (pats, seg, d)
+                    assert got[S.HIP_PIKE_COUNT][i] == cnt, (pats, seg, d.hex())
             for b in bufs:
                 b.free()
     assert admitted > 400, (tested, admitted)
