@@ -101,6 +101,12 @@ typedef struct {
 #define SRE_SUM_LASTEV    4u
 #define SRE_SUM_ERROR     8u   /* COUNT: ... and the iteration ended with SRE_ERROR */
 
+/* COUNT: an empty match ended on the segment's last byte boundary, so the
+ * caller's one-byte skip (sre_vm_pike.c:179-196) falls on the first byte of the
+ * NEXT segment.  s_out carries this bit, which no assumed entry state has: the
+ * chain check fails there and the next lane is re-run with the exact carry. */
+#define SRE_STATE_SKIP    0x40000000u
+
 /* lineage of one segment (sre_k_lineage_maps): for the thread at index j of the
  * list at the segment's END, which thread of the list at its START it descends
  * from — valid to jump over the segment only if neither flag bit j is set */

@@ -221,6 +221,9 @@ struct Walk {
     int64_t  count;
     int64_t  term_pos;
     bool     finished, error, unresolved;
+    bool     skip_next;                 /* COUNT: the next position to be processed is the byte the
+                                           caller skips after an empty match; it lies beyond the span
+                                           that was being processed when the match completed */
 
     __device__ void complete_match()
     {
@@ -249,6 +252,10 @@ __device__ void slow_run(Walk &w, int64_t p, int64_t p_to, bool warm, uint32_t w
     const sre_scan_tables_t &T = *w.T;
     const uint32_t           nsym = T.ncls + 1;
 
+    if (w.skip_next) {
+        w.skip_next = false;
+        p++;                        /* w.st is already the list of the search that starts behind it */
+    }
     while (p < p_to && !w.finished) {
         if (p == w.n && ((T.state_flags[w.st] >> 1) & 3) == 2) {
             /* the leading-byte skip ran to the end of input: the reference
@@ -346,6 +353,9 @@ __device__ void slow_run(Walk &w, int64_t p, int64_t p_to, bool warm, uint32_t w
             }
             w.st = T.init[restart_variant(w.data, w.cur_sp)];
             p = w.cur_sp;
+            /* an empty match that ended with a consumed byte can put the skipped
+             * byte just outside this span */
+            if (p > p_to && p_to <= w.n) w.skip_next = true;
             w.anchor_pos = -1;      /* the round's entry state belonged to the previous search */
         }
     }
@@ -596,6 +606,7 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
     w.count = 0;
     w.term_pos = -1;
     w.finished = w.error = w.unresolved = false;
+    w.skip_next = false;
 
     int64_t  seg_a = 0, seg_b = 0;
     uint32_t s_in = 0, seed = 0;
@@ -619,7 +630,8 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
         } else if (lo != nullptr && (int64_t) k == lo[sidx]) {
             /* exact carry from the verified predecessor */
             const sre_seg_summary_t &c = sum[g - 1];
-            w.st = c.s_out;
+            w.st = c.s_out & ~SRE_STATE_SKIP;
+            w.skip_next = (c.s_out & SRE_STATE_SKIP) != 0;
             w.cur_sp = c.cur_sp;
             if (c.flags & SRE_SUM_PENDING) {
                 w.has_ev = true;
@@ -639,13 +651,13 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
             warm = true;
             seed = T.init[0];
             if (lo != nullptr && lo[sidx] > 0) {
-                const uint32_t cs = sum[G.seg_first[sidx] + lo[sidx] - 1].s_out;
+                const uint32_t cs = sum[G.seg_first[sidx] + lo[sidx] - 1].s_out & ~SRE_STATE_SKIP;
                 /* COUNT cannot resolve a pending match it has not seen */
                 if (cs != 0 && !(MODE == SRE_HIP_PIKE_COUNT && (T.state_flags[cs] & 1))) seed = cs;
             }
             w.st = seed;
         }
-        s_in = w.st;
+        s_in = w.st | (w.skip_next ? SRE_STATE_SKIP : 0u);      /* what the chain check compares */
         /* row = [seg_a - WARM, seg_b): the warm-up rounds, then the segment */
         mine.addr = (uint64_t) reinterpret_cast<uintptr_t>(w.data) + (uint64_t) (seg_a - WARM);
         /* the warm-up of a stream's second segment may be cut short by the stream start */
@@ -748,7 +760,7 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
         };
         /* the common round: every byte in range, no transition needs the exact
          * path, (COUNT) no match completes — one straight chain of lookups */
-        if (base + TILE <= seg_b) {
+        if (base + TILE <= seg_b && !(MODE == SRE_HIP_PIKE_COUNT && w.skip_next)) {
             uint32_t t = fast_lds + w.st * SRE_FAST_ROW_BYTES, acc = 0, cnt = 0;
 #pragma unroll
             for (int j = 0; j < TILE * BITS / 8; j++) {
@@ -777,7 +789,7 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
             const int64_t gp = base + q * 16;
             if (gp >= seg_b || w.finished) break;
             const int64_t g_end = gp + 16 <= seg_b ? gp + 16 : seg_b;   /* ragged tail of the stream */
-            bool          exact = (g_end != gp + 16);
+            bool          exact = (g_end != gp + 16) || (MODE == SRE_HIP_PIKE_COUNT && w.skip_next);
             uint32_t      t = fast_lds + w.st * SRE_FAST_ROW_BYTES, cnt = 0;
             if (!exact) {
                 constexpr int GW = GIDX * (WIDE ? 2 : 1) / 4;           /* dwords of indices per group */
@@ -825,7 +837,7 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
 
     sre_seg_summary_t out;
     out.s_in = w.unresolved ? 0xffffffffu : s_in;
-    out.s_out = w.st;
+    out.s_out = w.st | (w.skip_next ? SRE_STATE_SKIP : 0u);
     out.flags = 0;
     out.pad = 0;
     out.count = w.count;
@@ -1079,7 +1091,7 @@ struct Tracer {
      */
     __device__ uint32_t entry_state(int64_t kq) const
     {
-        if (kq >= valid_from) return sum[kq].s_in;
+        if (kq >= valid_from) return sum[kq].s_in & ~SRE_STATE_SKIP;
         uint32_t cur = init_state;
         for (int64_t q = sp; q < kq * (int64_t) seg_bytes; q++) cur = step(cur, q);
         return cur;
@@ -1210,7 +1222,7 @@ sre_k_lineage_maps(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G
     const uint8_t *data = G.streams[s];
     const int64_t  n = (int64_t) G.lens[s];
     int64_t        lo = k * (int64_t) G.seg_bytes, hi = lo + G.seg_bytes;
-    uint32_t       cur = sum[g].s_in;
+    uint32_t       cur = sum[g].s_in & ~SRE_STATE_SKIP;
     if (hi > n) hi = n;
     if (k == st.ev_seg && st.ev_pos < hi) hi = st.ev_pos;      /* list at the event position */
     if (sp >= lo) {
