@@ -16,6 +16,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <vector>
 
 struct sre_hip_scanner_s {
     sre_program_t     *prog;
@@ -463,6 +464,18 @@ sre_hip_scan_results(sre_hip_scanner_t *sc, sre_int_t *results)
                     i, (long long) t.rc, (long long) t.count, (long long) t.ev_pos, (long long) t.ev_sp,
                     t.ev_state, t.ev_sym, (long long) t.ev_apos, t.ev_astate, (long long) t.ev_seg,
                     (long long) t.limit, t.need_maps, sc->geom.seg_bytes);
+        }
+        /* ... and what the lanes of the first segments recorded */
+        const size_t ns = sc->geom.nsegs < 16 ? (size_t) sc->geom.nsegs : 16;
+        std::vector<sre_seg_summary_t> hs(ns);
+        if (hipMemcpy(hs.data(), sc->d_sum, ns * sizeof(sre_seg_summary_t), hipMemcpyDeviceToHost) == hipSuccess) {
+            for (size_t k = 0; k < ns; k++) {
+                fprintf(stderr, "[sregex-hip]   seg %zu: s_in %x s_out %x flags %x count %lld cur_sp %lld term %lld "
+                                "pe_pos %lld lm_pos %lld lm_sp %lld\n",
+                        k, hs[k].s_in, hs[k].s_out, hs[k].flags, (long long) hs[k].count,
+                        (long long) hs[k].cur_sp, (long long) hs[k].term_pos, (long long) hs[k].pe_pos,
+                        (long long) hs[k].lm_pos, (long long) hs[k].lm_sp);
+            }
         }
     }
     if (!settled) {

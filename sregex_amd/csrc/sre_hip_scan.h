@@ -94,12 +94,18 @@ typedef struct {
     int64_t  term_pos;      /* position where the scan of this stream ended, -1 none */
     int64_t  count;         /* COUNT: searches completed with a match in this segment */
     int64_t  cur_sp;        /* start of the search in flight at the segment end, -1 unknown */
+    /* COUNT, SRE_SUM_IN_PENDING: the pending match the lane believed it ENTERED with (from its
+     * warm-up, or the exact carry).  Equal entry states do not imply equal pending events, so the
+     * chain check compares this with the predecessor's pe_* as well. */
+    int64_t  in_pe_pos;
+    uint32_t in_pe_state, in_pe_sym;
 } sre_seg_summary_t;
 
 #define SRE_SUM_PENDING   1u
 #define SRE_SUM_TERM      2u   /* the scan of this stream ended inside this segment */
 #define SRE_SUM_LASTEV    4u
 #define SRE_SUM_ERROR     8u   /* COUNT: ... and the iteration ended with SRE_ERROR */
+#define SRE_SUM_IN_PENDING 16u /* COUNT: the lane entered its segment holding a pending match (in_pe_*) */
 
 /* COUNT: an empty match ended on the segment's last byte boundary, so the
  * caller's one-byte skip (sre_vm_pike.c:179-196) falls on the first byte of the

@@ -610,6 +610,10 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
 
     int64_t  seg_a = 0, seg_b = 0;
     uint32_t s_in = 0, seed = 0;
+    /* COUNT: the pending match this lane enters its segment with (see sre_seg_summary_t) */
+    bool     in_pending = false;
+    int64_t  in_pe_pos = -1;
+    uint32_t in_pe_state = 0, in_pe_sym = 0;
     bool     last_seg = false, warm = false;
     RowDesc mine;
     mine.addr = 0;
@@ -642,6 +646,10 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
                 w.ev_apos = c.pe_apos;
                 w.ev_astate = c.pe_astate;
                 w.ev_kind = T.trans[(size_t) c.pe_state * (T.ncls + 1) + c.pe_sym].kind;
+                in_pending = true;
+                in_pe_pos = c.pe_pos;
+                in_pe_state = c.pe_state;
+                in_pe_sym = c.pe_sym;
             }
         } else {
             /* speculative: assume the state reached by a warm-up over the WARM
@@ -777,6 +785,10 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
                     s_in = w.st;
                     w.cur_sp = -1;
                     if (w.st == 0) w.finished = true;
+                    in_pending = w.has_ev;
+                    in_pe_pos = w.ev_pos;
+                    in_pe_state = w.ev_state;
+                    in_pe_sym = w.ev_sym;
                 }
                 continue;
             }
@@ -821,6 +833,10 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
             s_in = w.st;
             w.cur_sp = -1;                  /* search starts seen in the warm-up are not verified */
             if (w.st == 0) w.finished = true;
+            in_pending = w.has_ev;          /* ... nor is the pending match: the chain check compares it */
+            in_pe_pos = w.ev_pos;
+            in_pe_state = w.ev_state;
+            in_pe_sym = w.ev_sym;
         }
     }
 
@@ -847,6 +863,10 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
     if (w.error) out.flags |= SRE_SUM_ERROR;
     if (w.has_ev) out.flags |= SRE_SUM_PENDING;
     if (w.lm_valid) out.flags |= SRE_SUM_LASTEV;
+    if (MODE == SRE_HIP_PIKE_COUNT && in_pending) out.flags |= SRE_SUM_IN_PENDING;
+    out.in_pe_pos = in_pe_pos;
+    out.in_pe_state = in_pe_state;
+    out.in_pe_sym = in_pe_sym;
     out.pe_state = w.ev_state;
     out.pe_sym = w.ev_sym;
     out.pe_pos = w.ev_pos;
@@ -878,14 +898,28 @@ struct VerifyAcc {
 };
 
 __global__ __launch_bounds__(256) void
-sre_k_verify_a(sre_scan_geom_t G, const sre_seg_summary_t *__restrict__ sum, VerifyAcc *__restrict__ acc)
+sre_k_verify_a(sre_scan_geom_t G, const sre_seg_summary_t *__restrict__ sum, VerifyAcc *__restrict__ acc,
+               int mode)
 {
     const uint64_t g = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= G.nsegs) return;
     const uint32_t s = stream_of(G, g);
     const uint64_t k = g - G.seg_first[s];
     const uint32_t s_in = sum[g].s_in;
-    if ((k > 0 && s_in != sum[g - 1].s_out) || s_in == 0xffffffffu) atomicMin(&acc[s].bad, (unsigned long long) k);
+    bool           bad = s_in == 0xffffffffu;
+    if (k > 0) {
+        const sre_seg_summary_t &p = sum[g - 1], &c = sum[g];
+        if (s_in != p.s_out) bad = true;
+        if (mode == SRE_HIP_PIKE_COUNT) {
+            /* the same entry state can hold different pending matches */
+            const bool pp = (p.flags & SRE_SUM_PENDING) != 0, cp = (c.flags & SRE_SUM_IN_PENDING) != 0;
+            if (pp != cp) bad = true;
+            if (pp && cp && (p.pe_pos != c.in_pe_pos || p.pe_state != c.in_pe_state || p.pe_sym != c.in_pe_sym)) {
+                bad = true;
+            }
+        }
+    }
+    if (bad) atomicMin(&acc[s].bad, (unsigned long long) k);
     if (sum[g].flags & SRE_SUM_TERM) atomicMin(&acc[s].end, (unsigned long long) k);
 }
 
@@ -1622,7 +1656,7 @@ sre_launch_verify(sre_scan_tables_t h_tab, sre_scan_geom_t geom, const sre_seg_s
      * allocation, sre_k_verify_c after every pass */
     VerifyAcc *acc = static_cast<VerifyAcc *>(d_acc);
     const uint32_t gseg = (uint32_t) ((geom.nsegs + 255) / 256);
-    hipLaunchKernelGGL(sre_k_verify_a, dim3(gseg), dim3(256), 0, stream, geom, d_sum, acc);
+    hipLaunchKernelGGL(sre_k_verify_a, dim3(gseg), dim3(256), 0, stream, geom, d_sum, acc, (int) h_tab.mode);
     hipLaunchKernelGGL(sre_k_verify_b, dim3(gseg), dim3(256), 0, stream, geom, d_sum, acc);
     hipLaunchKernelGGL(sre_k_verify_c, dim3((geom.nstreams + 63) / 64), dim3(64), 0, stream, h_tab,
                        geom, d_sum, acc, d_status);
