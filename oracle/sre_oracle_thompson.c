@@ -30,6 +30,11 @@ struct sre_oracle_thompson_ctx_s {
     ttlist_t        lists[2];
     ttlist_t       *clist, *nlist;
     unsigned        first_buf;
+    unsigned        overflow;   /* test-harness guard, NOT reference behaviour: on programs whose
+                                   assertion splice cycles (a look-ahead assertion inside an empty
+                                   loop) the reference appends to its list without bound and writes
+                                   past the array (sre_vm_thompson.c:227-231 with :17-27 sizing);
+                                   here the exec stops with SRE_ERROR so that tests can skip the case */
 };
 
 SRE_API sre_oracle_thompson_ctx_t *
@@ -106,6 +111,10 @@ add_thread(sre_oracle_thompson_ctx_t *ctx, ttlist_t *l, uint32_t pc, const sre_c
         break;
     }
 
+    if (l->count > ctx->prog->len) {
+        ctx->overflow = 1;
+        return;
+    }
     t = &l->threads[l->count++];
     t->pc = pc;
     t->seen_word = seen_word;
@@ -132,7 +141,7 @@ sre_oracle_thompson_exec(sre_oracle_thompson_ctx_t *ctx, const sre_char *input,
 
         /* the list may grow while it is walked: a holding look-ahead assertion
          * appends its continuation to the END of the current list (:227-231) */
-        for (unsigned i = 0; i < clist->count; i++) {
+        for (unsigned i = 0; i < clist->count && !ctx->overflow; i++) {
             tthr_t           *t = &clist->threads[i];
             const sre_insn_t *in = &prog->insns[t->pc];
             unsigned          hold, w;
@@ -187,6 +196,7 @@ sre_oracle_thompson_exec(sre_oracle_thompson_ctx_t *ctx, const sre_char *input,
             }
         }
 
+        if (ctx->overflow) return SRE_ERROR;        /* harness guard, see the struct */
         tmp = clist;
         clist = nlist;
         nlist = tmp;

@@ -163,10 +163,13 @@ struct Builder {
         key.push_back((matched ? 1u : 0u) | ((uint32_t) seen_start << 1) | ((uint32_t) var << 3));
         std::vector<uint32_t> vis;
         if (holds_lookahead(pcs)) {
-            /* what a splice out of this list will see (:506-526) */
-            vis = vis_now;
-            std::sort(vis.begin(), vis.end());
-            vis.erase(std::unique(vis.begin(), vis.end()), vis.end());
+            /* what a splice out of this list will see (:506-526): the marks of
+             * the generation that built the list which are STILL in place — a
+             * splice later in the same step overwrites, with the older
+             * generation, the marks of instructions it walks through */
+            for (uint32_t pc = 0; pc < prog->len; pc++) {
+                if (tags[pc] == gen) vis.push_back(pc);
+            }
             key.push_back(0x80000000u | prev);
             key.insert(key.end(), vis.begin(), vis.end());
         } else {
@@ -360,7 +363,16 @@ sre_dfa_build(const sre_program_t *prog, uint32_t max_states, const char **why)
                 struct Item { uint32_t pc; uint8_t src; uint64_t early; };
                 std::deque<Item> work;
                 for (size_t idx = 0; idx < L.size(); idx++) work.push_back(Item{L[idx], (uint8_t) idx, 0});
+                /* A look-ahead assertion inside an empty loop can make the splice
+                 * re-mark and re-list in a cycle; the reference VM then duplicates
+                 * threads without bound (and crashes).  No automaton for that. */
+                size_t budget = 64 * ((size_t) prog->len + 16);
                 while (!work.empty()) {
+                    if (budget-- == 0) {
+                        *why = "assertion splice does not terminate (the reference VM diverges on this program)";
+                        delete d;
+                        return NULL;
+                    }
                     const Item it = work.front();
                     work.pop_front();
                     const sre_insn_t &in = prog->insns[it.pc];

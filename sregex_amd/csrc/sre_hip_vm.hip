@@ -103,7 +103,7 @@ struct PikeHdr {
     int32_t  head[2], tail[2];
     uint32_t used[2], count[2];
     uint32_t seen_start_state, initial_count;
-    uint32_t pad;
+    uint32_t overflow;            /* a thread list outgrew its nodes: see node_new */
 };
 
 struct Node {           /* followed by int64_t cap[nslots] */
@@ -176,9 +176,18 @@ struct Pike {
         h->count[l] = 0;
     }
 
-    /* append a thread carrying the working capture vector */
+    /* Append a thread carrying the working capture vector.  A list holds each
+     * list-able instruction at most once per generation — except on programs
+     * whose assertion splice re-marks and re-lists in a cycle (a look-ahead
+     * assertion inside an empty loop, e.g. (\n?|^$)+?): there the reference VM
+     * duplicates threads without bound and crashes (sre_vm_pike.c:506-526).
+     * Here the list stops growing and the exec ends with SRE_ERROR. */
     __device__ inline int32_t node_new(int l, uint32_t pc, uint32_t seen_word)
     {
+        if (h->used[l] > P.h->nthreads) {
+            h->overflow = 1;
+            return -1;
+        }
         int32_t  i = (int32_t) h->used[l]++;
         Node    *n = node(l, i);
         h->count[l]++;
@@ -293,6 +302,7 @@ struct Pike {
 
                 if (list_it) {
                     int32_t i = node_new(l, pc, seen_word);
+                    if (i < 0) break;               /* overflow: flagged, the exec will fail */
                     if (tail >= 0) {
                         node(l, tail)->next = i;
                     } else {
@@ -515,6 +525,7 @@ struct Pike {
                 /* every thread of lower priority is dropped (:547-553) */
                 has_matched = true;
             }
+            if (h->overflow) return RC_ERROR;
             /* step_done :569-580 */
             list_reset(cl);
             cl ^= 1;
@@ -576,6 +587,7 @@ constexpr uint32_t THOMPSON_MAGIC = 0x54484f4du;
 struct ThompsonHdr {
     uint32_t magic, tag, first_buf, cur;
     uint32_t count[2];
+    uint32_t overflow, pad;       /* see Pike::node_new */
 };
 
 struct Thompson {
@@ -632,6 +644,10 @@ struct Thompson {
                     if (in.ch == AS_SMALL_B || in.ch == AS_BIG_B) {
                         seen_word = (sp != 0 && is_word(this->in.at(sp - 1))) ? 1u : 0u;
                     }
+                }
+                if (h->count[l] > P.h->len) {
+                    h->overflow = 1;            /* see Pike::node_new */
+                    break;
                 }
                 list[l][h->count[l]++] = pc | (seen_word << 31);
                 break;
@@ -692,6 +708,7 @@ struct Thompson {
                 closure(nl, pc + 1, sp + 1);
             }
 
+            if (h->overflow) return RC_ERROR;
             h->count[cl] = 0;
             cl ^= 1;
             nl ^= 1;

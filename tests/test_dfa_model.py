@@ -181,7 +181,7 @@ def test_model_random_patterns_vs_oracle(sim):
     """Differential test of the automaton + lineage walk: random patterns (all
     constructs, all assertions) x random subjects against the oracle."""
     ora = harness.OracleEngine()
-    rng = random.Random(424242)
+    rng = random.Random(int(os.environ.get("SRE_FUZZ_SEED", "424242")))
     alphabet = b"abcx \n_."
     built = 0
     for _ in range(400):
@@ -207,8 +207,10 @@ def test_model_random_patterns_vs_oracle(sim):
                     got = _findall(sim, d, prog, re.ncaps, data)
                 assert got == want, (pats, data)
                 t = ora.thompson(prog)
-                assert sim.dfa_sim_thompson(d, data, len(data)) == t.exec(data, True), (pats, data)
+                th = t.exec(data, True)
                 t.close()
+                if th != S.SRE_ERROR:       # ERROR: the reference's Thompson list overflows here (oracle guard)
+                    assert sim.dfa_sim_thompson(d, data, len(data)) == th, (pats, data)
             sim.dfa_sim_free(d)
     assert built > 300, built
 

@@ -417,6 +417,8 @@ def test_scanner_random_patterns_vs_oracle(gpu, seg):
                 t.close()
                 for (eng, mode), recs in got.items():
                     want = first if mode == S.HIP_PIKE_FIRST else cnt if mode == S.HIP_PIKE_COUNT else None
+                    if want is None and th == S.SRE_ERROR:
+                        continue            # the reference's Thompson list overflows here (oracle guard)
                     ok = recs[i][0] == th if want is None else recs[i] == want
                     if not ok:
                         bad.append({"engine": eng, "mode": mode, "seg": seg, "re": [p.hex() for p in pats],
