@@ -30,6 +30,12 @@
 #include "sre_hip_common.h"
 #include "sre_hip_vm.h"
 
+/* Entries of a thread list.  Without look-ahead assertions a list holds every
+ * list-able instruction at most once; an assertion splice may list some again
+ * (the marks it de-duplicates against have been overwritten meanwhile), so
+ * there is generous room — and a hard stop, see Pike::node_new. */
+#define SRE_LIST_CAP(n) (8u * ((n) + 1u) + 32u)
+
 namespace {
 
 enum : uint8_t {
@@ -129,8 +135,8 @@ sre_pike_layout(uint32_t len, uint32_t nthreads, uint32_t nslots)
     L.node_bytes = (uint32_t) (sizeof(Node) + (size_t) nslots * 8);
     L.tags = off;       off += SRE_DEV_ALIGN((size_t) (len + 1) * 4);
     L.initial = off;    off += SRE_DEV_ALIGN((size_t) (nthreads + 1) * 4);
-    L.nodes[0] = off;   off += SRE_DEV_ALIGN((size_t) (nthreads + 1) * L.node_bytes);
-    L.nodes[1] = off;   off += SRE_DEV_ALIGN((size_t) (nthreads + 1) * L.node_bytes);
+    L.nodes[0] = off;   off += SRE_DEV_ALIGN((size_t) SRE_LIST_CAP(nthreads) * L.node_bytes);
+    L.nodes[1] = off;   off += SRE_DEV_ALIGN((size_t) SRE_LIST_CAP(nthreads) * L.node_bytes);
     L.matched = off;    off += SRE_DEV_ALIGN((size_t) (nslots + 1) * 8);
     L.work = off;       off += SRE_DEV_ALIGN((size_t) (nslots + 1) * 8);
     L.stack = off;      off += SRE_DEV_ALIGN((size_t) (len + 2) * sizeof(StackRec));
@@ -144,8 +150,8 @@ sre_thompson_layout(uint32_t len)
     sre_thompson_layout_t L;
     size_t                off = 64;
     L.tags = off;       off += SRE_DEV_ALIGN((size_t) (len + 1) * 4);
-    L.list[0] = off;    off += SRE_DEV_ALIGN((size_t) (len + 1) * 4);
-    L.list[1] = off;    off += SRE_DEV_ALIGN((size_t) (len + 1) * 4);
+    L.list[0] = off;    off += SRE_DEV_ALIGN((size_t) SRE_LIST_CAP(len) * 4);
+    L.list[1] = off;    off += SRE_DEV_ALIGN((size_t) SRE_LIST_CAP(len) * 4);
     L.stack = off;      off += SRE_DEV_ALIGN((size_t) (len + 2) * 4);
     L.total = off;
     return L;
@@ -184,7 +190,7 @@ struct Pike {
      * Here the list stops growing and the exec ends with SRE_ERROR. */
     __device__ inline int32_t node_new(int l, uint32_t pc, uint32_t seen_word)
     {
-        if (h->used[l] > P.h->nthreads) {
+        if (h->used[l] >= SRE_LIST_CAP(P.h->nthreads)) {
             h->overflow = 1;
             return -1;
         }
@@ -645,7 +651,7 @@ struct Thompson {
                         seen_word = (sp != 0 && is_word(this->in.at(sp - 1))) ? 1u : 0u;
                     }
                 }
-                if (h->count[l] > P.h->len) {
+                if (h->count[l] >= SRE_LIST_CAP(P.h->len)) {
                     h->overflow = 1;            /* see Pike::node_new */
                     break;
                 }
