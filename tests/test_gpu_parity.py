@@ -395,7 +395,7 @@ def test_scanner_random_patterns_vs_oracle(gpu, seg):
                 except RuntimeError:
                     continue
                 if seg:
-                    sc.set_segment_bytes(seg)
+                    sc.set_segment_bytes(int(os.environ.get("SRE_FUZZ_SEG", seg)))
                 engines[("scan", mode)] = sc
             tested += 1
             admitted += 1 if engines else 0
@@ -405,8 +405,8 @@ def test_scanner_random_patterns_vs_oracle(gpu, seg):
                     engines[("vm", mode)] = S.Scanner(pool, prog, mode, S.ENGINE_VM)
             if not engines:
                 continue
-            datas = [bytes(rng.choice(alphabet) for _ in range(rng.choice([0, 1, 7, 64, 65, 130, 400])))
-                     for _ in range(6)]
+            sizes = [0, 1, 7, 64, 65, 130, 400] + ([1500, 5000] if os.environ.get("SRE_FUZZ_BIG") else [])
+            datas = [bytes(rng.choice(alphabet) for _ in range(rng.choice(sizes))) for _ in range(6)]
             bufs = [S.DeviceBuffer.from_bytes(d) for d in datas]
             ptrs, lens = [b.ptr for b in bufs], [len(d) for d in datas]
             got = {key: sc.scan(ptrs, lens) for key, sc in engines.items()}
@@ -433,3 +433,29 @@ def test_scanner_random_patterns_vs_oracle(gpu, seg):
     assert admitted > 400, (tested, admitted)
     assert not bad, (len(bad), [(b["engine"], b["mode"], bytes.fromhex(b["re"][0]), b["got"][:4], b["want"][:4])
                                for b in bad[:6]])
+
+
+def test_recorded_fuzz_regressions(gpu):
+    """Cases the randomised tests once failed on (tests/golden/fuzz_regressions.jsonl:
+    engine, mode, segment size, patterns and subject in hex) stay fixed."""
+    import json
+    ora = harness.OracleEngine()
+    n = 0
+    for line in open(os.path.join(harness.ROOT, "tests", "golden", "fuzz_regressions.jsonl")):
+        c = json.loads(line)
+        pats = [bytes.fromhex(x) for x in c["re"]]
+        d = bytes.fromhex(c["s"])
+        with S.Pool() as pool:
+            re = S.parse(pool, pats)
+            prog = S.compile(pool, re)
+            first, cnt = _expect(ora, prog, re.ncaps, d)
+            want = first if c["mode"] == S.HIP_PIKE_FIRST else cnt
+            sc = S.Scanner(pool, prog, c["mode"], S.ENGINE_VM if c["engine"] == "vm" else S.ENGINE_SCAN)
+            if c["engine"] != "vm" and c["seg"]:
+                sc.set_segment_bytes(c["seg"])
+            buf = S.DeviceBuffer.from_bytes(d)
+            got = sc.scan([buf.ptr], [len(d)])[0]
+            buf.free()
+            assert got == want, (c["engine"], c["mode"], pats, d.hex())
+            n += 1
+    assert n >= 40

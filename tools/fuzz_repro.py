@@ -1,6 +1,6 @@
-"""Re-run recorded differential-test failures (tools/fuzz_cases.jsonl, written by
+"""Re-run recorded differential-test failures (default: tests/golden/fuzz_regressions.jsonl; written by
 tests/test_gpu_parity.py::test_scanner_random_patterns_vs_oracle) on the GPU.
-usage: python tools/fuzz_repro.py [index ...]"""
+usage: python tools/fuzz_repro.py [--file gpurun_out/fuzz_fail.jsonl] [index ...]"""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -9,8 +9,12 @@ import importlib.util
 spec = importlib.util.spec_from_file_location("tg", os.path.join(ROOT, "tests", "test_gpu_parity.py"))
 tg = importlib.util.module_from_spec(spec); spec.loader.exec_module(tg)
 ora = harness.OracleEngine()
-cases = [json.loads(l) for l in open(os.path.join(ROOT, "tools", "fuzz_cases.jsonl"))]
-want_idx = [int(a) for a in sys.argv[1:]] or range(len(cases))
+args = sys.argv[1:]
+path = os.path.join(ROOT, "tests", "golden", "fuzz_regressions.jsonl")
+if args[:1] == ["--file"]:
+    path, args = args[1], args[2:]
+cases = [json.loads(l) for l in open(path)]
+want_idx = [int(a) for a in args] or range(len(cases))
 for i in want_idx:
     c = cases[i]
     pats = [bytes.fromhex(x) for x in c["re"]]; d = bytes.fromhex(c["s"])
