@@ -459,3 +459,43 @@ def test_recorded_fuzz_regressions(gpu):
             assert got == want, (c["engine"], c["mode"], pats, d.hex())
             n += 1
     assert n >= 40
+
+
+def test_compat_api_random_patterns_vs_oracle(gpu):
+    """The unchanged C API (sre_vm_pike_exec / sre_vm_thompson_exec) on random
+    patterns: whole-buffer and byte-at-a-time calls exactly as the reference CLI
+    makes them (temp captures and pending matches of every AGAIN included),
+    against the oracle driven through the same sequence."""
+    import random
+    ora = harness.OracleEngine()
+    eng = harness.ProductEngine()
+    rng = random.Random(int(os.environ.get("SRE_FUZZ_SEED", "20261004")) * 7 + 1)
+    alphabet = b"abcx \n_."
+    bad = []
+    n = 0
+    for _ in range(120):
+        nre = 1 if rng.random() < 0.8 else rng.randrange(2, 4)
+        pats = [harness.random_regex(rng) for _ in range(nre)]
+        with S.Pool() as pool:
+            re = S.parse(pool, pats)
+            prog = S.compile(pool, re)
+            # programs on which the reference VM itself diverges (DESIGN.md §5) have no expectation
+            try:
+                S.Scanner(pool, prog, S.HIP_PIKE_FIRST, S.ENGINE_SCAN)
+            except RuntimeError:
+                if prog_has_lookahead(pats):
+                    continue
+            for _ in range(2):
+                d = bytes(rng.choice(alphabet) for _ in range(rng.choice([0, 1, 5, 17, 40])))
+                want = harness.cli_lines(ora, prog, d, re.ncaps)
+                got = harness.cli_lines(eng, prog, d, re.ncaps)
+                n += 1
+                if got != want:
+                    bad.append((pats, d, got, want))
+            eng.recycle()
+    assert n > 150, n
+    assert not bad, (len(bad), bad[:3])
+
+
+def prog_has_lookahead(pats):
+    return any(tok in p for p in pats for tok in (b"$", b"\\b", b"\\B", b"\\z"))
