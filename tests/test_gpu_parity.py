@@ -407,8 +407,10 @@ def test_scanner_random_patterns_vs_oracle(gpu, seg):
                 continue
             sizes = [0, 1, 7, 64, 65, 130, 400] + ([1500, 5000] if os.environ.get("SRE_FUZZ_BIG") else [])
             datas = [bytes(rng.choice(alphabet) for _ in range(rng.choice(sizes))) for _ in range(6)]
-            bufs = [S.DeviceBuffer.from_bytes(d) for d in datas]
-            ptrs, lens = [b.ptr for b in bufs], [len(d) for d in datas]
+            # streams start at arbitrary byte offsets (unaligned rows in the staging loads)
+            offs = [rng.randrange(0, 16) for _ in datas]
+            bufs = [S.DeviceBuffer.from_bytes(b"#" * o + d) for o, d in zip(offs, datas)]
+            ptrs, lens = [b.ptr + o for b, o in zip(bufs, offs)], [len(d) for d in datas]
             got = {key: sc.scan(ptrs, lens) for key, sc in engines.items()}
             for i, d in enumerate(datas):
                 first, cnt = _expect(ora, prog, re.ncaps, d)
