@@ -252,7 +252,7 @@ __device__ void slow_run(Walk &w, int64_t p, int64_t p_to, bool warm, uint32_t w
     const sre_scan_tables_t &T = *w.T;
     const uint32_t           nsym = T.ncls + 1;
 
-    if (w.skip_next) {
+    if (MODE == SRE_HIP_PIKE_COUNT && w.skip_next) {
         w.skip_next = false;
         p++;                        /* w.st is already the list of the search that starts behind it */
     }
@@ -635,7 +635,7 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
             /* exact carry from the verified predecessor */
             const sre_seg_summary_t &c = sum[g - 1];
             w.st = c.s_out & ~SRE_STATE_SKIP;
-            w.skip_next = (c.s_out & SRE_STATE_SKIP) != 0;
+            w.skip_next = MODE == SRE_HIP_PIKE_COUNT && (c.s_out & SRE_STATE_SKIP) != 0;
             w.cur_sp = c.cur_sp;
             if (c.flags & SRE_SUM_PENDING) {
                 w.has_ev = true;
@@ -646,10 +646,12 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
                 w.ev_apos = c.pe_apos;
                 w.ev_astate = c.pe_astate;
                 w.ev_kind = T.trans[(size_t) c.pe_state * (T.ncls + 1) + c.pe_sym].kind;
-                in_pending = true;
-                in_pe_pos = c.pe_pos;
-                in_pe_state = c.pe_state;
-                in_pe_sym = c.pe_sym;
+                if (MODE == SRE_HIP_PIKE_COUNT) {
+                    in_pending = true;
+                    in_pe_pos = c.pe_pos;
+                    in_pe_state = c.pe_state;
+                    in_pe_sym = c.pe_sym;
+                }
             }
         } else {
             /* speculative: assume the state reached by a warm-up over the WARM
@@ -665,7 +667,7 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
             }
             w.st = seed;
         }
-        s_in = w.st | (w.skip_next ? SRE_STATE_SKIP : 0u);      /* what the chain check compares */
+        s_in = w.st | (MODE == SRE_HIP_PIKE_COUNT && w.skip_next ? SRE_STATE_SKIP : 0u);   /* what the chain check compares */
         /* row = [seg_a - WARM, seg_b): the warm-up rounds, then the segment */
         mine.addr = (uint64_t) reinterpret_cast<uintptr_t>(w.data) + (uint64_t) (seg_a - WARM);
         /* the warm-up of a stream's second segment may be cut short by the stream start */
@@ -785,10 +787,12 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
                     s_in = w.st;
                     w.cur_sp = -1;
                     if (w.st == 0) w.finished = true;
-                    in_pending = w.has_ev;
-                    in_pe_pos = w.ev_pos;
-                    in_pe_state = w.ev_state;
-                    in_pe_sym = w.ev_sym;
+                    if (MODE == SRE_HIP_PIKE_COUNT) {
+                        in_pending = w.has_ev;
+                        in_pe_pos = w.ev_pos;
+                        in_pe_state = w.ev_state;
+                        in_pe_sym = w.ev_sym;
+                    }
                 }
                 continue;
             }
@@ -833,10 +837,12 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
             s_in = w.st;
             w.cur_sp = -1;                  /* search starts seen in the warm-up are not verified */
             if (w.st == 0) w.finished = true;
-            in_pending = w.has_ev;          /* ... nor is the pending match: the chain check compares it */
-            in_pe_pos = w.ev_pos;
-            in_pe_state = w.ev_state;
-            in_pe_sym = w.ev_sym;
+            if (MODE == SRE_HIP_PIKE_COUNT) {
+                in_pending = w.has_ev;      /* ... nor is the pending match: the chain check compares it */
+                in_pe_pos = w.ev_pos;
+                in_pe_state = w.ev_state;
+                in_pe_sym = w.ev_sym;
+            }
         }
     }
 
@@ -853,7 +859,7 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
 
     sre_seg_summary_t out;
     out.s_in = w.unresolved ? 0xffffffffu : s_in;
-    out.s_out = w.st | (w.skip_next ? SRE_STATE_SKIP : 0u);
+    out.s_out = w.st | (MODE == SRE_HIP_PIKE_COUNT && w.skip_next ? SRE_STATE_SKIP : 0u);
     out.flags = 0;
     out.pad = 0;
     out.count = w.count;
