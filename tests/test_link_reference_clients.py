@@ -12,7 +12,8 @@ import sregex_amd as S
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = "/root/reference"
-OUT = os.path.join(ROOT, "tests", "_build")
+# binaries built from reference sources live under oracle/_ref/ (git-ignored), like the oracle's
+OUT = os.path.join(ROOT, "oracle", "_ref", "clients")
 
 pytestmark = pytest.mark.skipif(not os.path.exists(REF + "/src/sre_cli.c"),
                                 reason="reference sources not present on this machine")
