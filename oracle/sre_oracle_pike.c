@@ -280,6 +280,17 @@ add_thread(sre_oracle_pike_ctx_t *ctx, tlist_t *l, uint32_t pc, cap_t *cap,
         break;
     }
 
+    /* Test-harness guard, NOT reference behaviour: on programs whose assertion
+     * splice cycles (a look-ahead assertion inside an empty loop, e.g.
+     * (\n?|^$)+?) the reference lists threads without bound until it runs out
+     * of memory or crashes (verified with oracle/_ref/sregex-cli).  The exec
+     * stops with SRE_ERROR here so that tests can skip such a case. */
+    if (l->count > 64u * (ctx->prog->len + 16u)) {
+        ctx->oom = 1;
+        cap_release(ctx, cap);
+        return SRE_ERROR;
+    }
+
     /* :903-938 append to the tail */
     t = ctx->free_thrs;
     if (t) {

@@ -399,8 +399,11 @@ def test_scanner_random_patterns_vs_oracle(gpu, seg):
                 engines[("scan", mode)] = sc
             tested += 1
             admitted += 1 if engines else 0
-            if seg == 0 and os.environ.get("SRE_FUZZ_VM"):
+            if seg == 0 and os.environ.get("SRE_FUZZ_VM") and \
+                    (("scan", S.HIP_PIKE_FIRST) in engines or not prog_has_lookahead(pats)):
                 # opt-in: the exact VM kernels take every program: same subjects, same expectations
+                # (not the look-ahead programs the builder declines: the reference VM itself may
+                # diverge on them)
                 for mode in modes:
                     engines[("vm", mode)] = S.Scanner(pool, prog, mode, S.ENGINE_VM)
             if not engines:
