@@ -367,8 +367,8 @@ def test_full_size_streams_closed_form_properties(gpu):
 @pytest.mark.parametrize("seg", [64, 0])
 def test_scanner_random_patterns_vs_oracle(gpu, seg):
     """Differential test: random patterns x random subjects, every mode the
-    scanner admits (tiny segments force speculation) and, with SRE_FUZZ_VM=1 and
-    seg == 0, the exact VM kernels too, against the oracle.  Failing cases are also written to
+    scanner admits (tiny segments force speculation) and, for seg == 0, the exact
+    VM kernels too (SRE_FUZZ_VM=0 leaves them out), against the oracle.  Failing cases are also written to
     gpurun_out/fuzz_fail.jsonl (pattern / subject in hex) for reproduction."""
     import json
     import random
@@ -399,9 +399,9 @@ def test_scanner_random_patterns_vs_oracle(gpu, seg):
                 engines[("scan", mode)] = sc
             tested += 1
             admitted += 1 if engines else 0
-            if seg == 0 and os.environ.get("SRE_FUZZ_VM") and \
+            if seg == 0 and os.environ.get("SRE_FUZZ_VM", "1") != "0" and \
                     (("scan", S.HIP_PIKE_FIRST) in engines or not prog_has_lookahead(pats)):
-                # opt-in: the exact VM kernels take every program: same subjects, same expectations
+                # the exact VM kernels take every program: same subjects, same expectations
                 # (not the look-ahead programs the builder declines: the reference VM itself may
                 # diverge on them)
                 for mode in modes:
