@@ -277,6 +277,10 @@ def random_regex(rng, depth=0):
     parser accepts: literals, classes, '.', groups, alternation, greedy and lazy
     quantifiers, counted repeats, and every assertion."""
     atoms = [b"a", b"b", b"c", b"x", b".", b"[ab]", b"[^a]", b"\\w", b"\\s", b"\\n", b"[a-c]"]
+    if os.environ.get("SRE_FUZZ_WIDE"):
+        # more of the lexer: escapes, negated shorthands, upper case (for caseless flags), high bytes
+        atoms += [b"A", b"X", b"\\.", b"\\W", b"\\S", b"\\d", b"\\D", b"[^\\s]", b"[\\w.]", b"\\x41",
+                  b"\\xff", b"[\\x80-\\xff]", b"_", b"[A-C]"]
     asserts = [b"^", b"$", b"\\b", b"\\B", b"\\A", b"\\z"]
     n = rng.randrange(1, 5 if depth == 0 else 4)
     seq = []

@@ -1,0 +1,77 @@
+"""Front end (parser + compiler) against the LIVE reference CLI on random and
+randomly damaged patterns (build container only: needs oracle/_ref/sregex-cli,
+the real reference compiled by oracle/Makefile).  Compared: AST dump, capture
+count, program dump — or the syntax-error offset."""
+import os
+import random
+import subprocess
+
+import pytest
+
+import sregex_amd as S
+import harness
+
+CLI = os.path.join(harness.ROOT, "oracle", "_ref", "sregex-cli")
+pytestmark = pytest.mark.skipif(not os.path.exists(CLI), reason="oracle/_ref/sregex-cli not built")
+
+
+def _ours(pat):
+    with S.Pool() as pool:
+        try:
+            re = S.parse(pool, [pat])
+        except S.SyntaxError_ as e:
+            return {"err": str(e)}
+        prog = S.compile(pool, re)
+        return {"ast": re.dump().rstrip("\n"), "ncaps": re.ncaps, "prog": prog.dump().rstrip("\n")}
+
+
+def _theirs(pat):
+    p = subprocess.run([CLI, pat, b""], capture_output=True, timeout=20)
+    if p.returncode < 0:
+        return None                      # the reference crashed on this one
+    err = p.stderr.decode("latin-1").strip()
+    if "[error]" in err:
+        return {"err": err.splitlines()[0]}
+    if p.returncode != 0 and not p.stdout:
+        return None                      # an option-like argument, not a pattern
+    out = p.stdout.decode("latin-1").split("\n## ")[0].split("\n")
+    return {"ast": out[0], "ncaps": int(out[1].split(":")[1]), "prog": "\n".join(out[2:]).rstrip("\n")}
+
+
+def test_random_and_damaged_patterns_parse_like_the_reference(monkeypatch):
+    monkeypatch.setenv("SRE_FUZZ_WIDE", "1")
+    rng = random.Random(int(os.environ.get("SRE_FUZZ_SEED", "99")))
+    junk = b"()[]{}*+?|\\^$.,-0123456789abx:=!<>"
+    bad = []
+    n = crashed = rejected = 0
+    for _ in range(1200):
+        pat = harness.random_regex(rng)
+        if rng.random() < 0.4:           # damage it: insert / delete / replace a byte
+            b = bytearray(pat)
+            for _ in range(rng.randrange(1, 3)):
+                k = rng.randrange(0, len(b) + 1)
+                op = rng.randrange(3)
+                if op == 0 or not b:
+                    b.insert(k, rng.choice(junk))
+                elif op == 1:
+                    del b[min(k, len(b) - 1)]
+                else:
+                    b[min(k, len(b) - 1)] = rng.choice(junk)
+            pat = bytes(b)
+        if not pat or b"\0" in pat or pat.startswith(b"-"):
+            continue
+        try:
+            want = _theirs(pat)
+        except subprocess.TimeoutExpired:
+            crashed += 1
+            continue
+        if want is None:
+            crashed += 1
+            continue
+        got = _ours(pat)
+        n += 1
+        rejected += "err" in want
+        if got != want:
+            bad.append((pat, got.get("err") or got.get("ast"), want.get("err") or want.get("ast")))
+    assert n > 1000 and rejected > 50, (n, rejected, crashed)
+    assert not bad, (len(bad), bad[:5])
