@@ -75,3 +75,42 @@ def test_random_and_damaged_patterns_parse_like_the_reference(monkeypatch):
             bad.append((pat, got.get("err") or got.get("ast"), want.get("err") or want.get("ast")))
     assert n > 1000 and rejected > 50, (n, rejected, crashed)
     assert not bad, (len(bad), bad[:5])
+
+
+def test_oracle_matches_the_live_reference_on_random_patterns():
+    """The oracle (oracle/*.c) against the real reference executors, through the
+    reference CLI's own call sequence: thompson / splitted thompson / pike /
+    splitted pike lines (captures, temp captures, pending matches) on random
+    patterns — assertions, lazy quantifiers, counted repeats — and subjects."""
+    ora = harness.OracleEngine()
+    rng = random.Random(int(os.environ.get("SRE_FUZZ_SEED", "99")) + 1000)
+    alphabet = b"abcx \n_."
+    bad = []
+    n = crashed = 0
+    for _ in range(500):
+        pat = harness.random_regex(rng)
+        if pat.startswith(b"-"):
+            continue
+        subject = bytes(rng.choice(alphabet) for _ in range(rng.choice([0, 1, 3, 9, 20, 33])))
+        if subject.startswith(b"-"):
+            continue
+        with S.Pool() as pool:
+            re = S.parse(pool, [pat])
+            prog = S.compile(pool, re)
+            try:
+                p = subprocess.run([CLI, pat, subject], capture_output=True, timeout=20)
+            except subprocess.TimeoutExpired:
+                crashed += 1
+                continue
+            if p.returncode != 0:
+                crashed += 1                # the reference crashes on some programs (DESIGN.md §5)
+                continue
+            # the six engine lines close the output (the subject itself may hold newlines)
+            lines = [l for l in p.stdout.decode("latin-1").split("\n") if l][-6:]
+            want = [l for l in lines if "jitted" not in l]
+            got = harness.cli_lines(ora, prog, subject, re.ncaps)
+            n += 1
+            if got != want:
+                bad.append((pat, subject, got, want))
+    assert n > 400, (n, crashed)
+    assert not bad, (len(bad), bad[:3])
