@@ -88,17 +88,19 @@ def test_oracle_matches_the_live_reference_on_random_patterns():
     bad = []
     n = crashed = 0
     for _ in range(500):
-        pat = harness.random_regex(rng)
-        if pat.startswith(b"-"):
+        pats = [harness.random_regex(rng) for _ in range(1 if rng.random() < 0.75 else rng.randrange(2, 4))]
+        if any(p.startswith(b"-") for p in pats):
             continue
         subject = bytes(rng.choice(alphabet) for _ in range(rng.choice([0, 1, 3, 9, 20, 33])))
         if subject.startswith(b"-"):
             continue
+        pat = pats
         with S.Pool() as pool:
-            re = S.parse(pool, [pat])
+            re = S.parse(pool, pats)
             prog = S.compile(pool, re)
+            argv = [CLI] + (["-n", str(len(pats))] if len(pats) > 1 else []) + pats + [subject]
             try:
-                p = subprocess.run([CLI, pat, subject], capture_output=True, timeout=20)
+                p = subprocess.run(argv, capture_output=True, timeout=20)
             except subprocess.TimeoutExpired:
                 crashed += 1
                 continue
