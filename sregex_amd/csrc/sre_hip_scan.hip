@@ -661,9 +661,28 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
             warm = true;
             seed = T.init[0];
             if (lo != nullptr && lo[sidx] > 0) {
-                const uint32_t cs = sum[G.seg_first[sidx] + lo[sidx] - 1].s_out & ~SRE_STATE_SKIP;
-                /* COUNT cannot resolve a pending match it has not seen */
-                if (cs != 0 && !(MODE == SRE_HIP_PIKE_COUNT && (T.state_flags[cs] & 1))) seed = cs;
+                const sre_seg_summary_t &c = sum[G.seg_first[sidx] + lo[sidx] - 1];
+                const uint32_t           cs = c.s_out & ~SRE_STATE_SKIP;
+                if (cs != 0) {
+                    if (!(MODE == SRE_HIP_PIKE_COUNT && (T.state_flags[cs] & 1))) {
+                        seed = cs;
+                    } else if (c.flags & SRE_SUM_PENDING) {
+                        /* COUNT cannot resolve a pending match it has not seen — but it
+                         * can take over the one the verified prefix ends with: a match
+                         * whose list lives on for long (a.*b with no b in sight) is then
+                         * believed by every lane behind it, and the chain check compares
+                         * exactly that belief */
+                        seed = cs;
+                        w.has_ev = true;
+                        w.ev_state = c.pe_state;
+                        w.ev_sym = c.pe_sym;
+                        w.ev_pos = c.pe_pos;
+                        w.ev_sp = c.pe_sp;
+                        w.ev_apos = -1;
+                        w.ev_astate = 0;
+                        w.ev_kind = T.trans[(size_t) c.pe_state * (T.ncls + 1) + c.pe_sym].kind;
+                    }
+                }
             }
             w.st = seed;
         }

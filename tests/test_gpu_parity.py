@@ -247,6 +247,29 @@ def test_scanner_fixup_rounds_are_reported(gpu):
         assert sc.last_fixups >= 1
 
 
+def test_scanner_count_long_pending_match_converges_quickly(gpu):
+    """COUNT: a match whose list lives on for the rest of the stream (a.*b with no
+    b in sight) is pending at every segment boundary behind it.  Lanes of a
+    fix-up round take the verified prefix's pending match as their belief, so
+    the chain closes in a round or two instead of one segment per round."""
+    ora = harness.OracleEngine()
+    cases = [(rb"(?:a.*b|a)", b"xa" + b"c" * 20000),
+             (rb"(?:a.*b|a)", b"xa" + b"c" * 9000 + b"b" + b"ca" + b"c" * 9000),
+             (rb"(a)[^b]*(b)?", b"za" + b"c" * 30000 + b"aa")]
+    for pat, data in cases:
+        with S.Pool() as pool:
+            re = S.parse(pool, [pat])
+            prog = S.compile(pool, re)
+            first, cnt = _expect(ora, prog, re.ncaps, data)
+            sc = S.Scanner(pool, prog, S.HIP_PIKE_COUNT, S.ENGINE_SCAN)
+            sc.set_segment_bytes(64)
+            buf = S.DeviceBuffer.from_bytes(data)
+            got = sc.scan([buf.ptr], [len(data)])[0]
+            buf.free()
+            assert got == cnt, (pat, got[:6], cnt[:6])
+            assert sc.last_fixups <= 4, (pat, sc.last_fixups)
+
+
 @pytest.mark.parametrize("seg", [64, 4096])
 def test_scanner_long_lineage_uses_ancestor_maps(gpu, seg):
     """A match that starts at offset 0 and ends at the far end of the stream:
