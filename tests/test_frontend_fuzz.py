@@ -15,18 +15,18 @@ CLI = os.path.join(harness.ROOT, "oracle", "_ref", "sregex-cli")
 pytestmark = pytest.mark.skipif(not os.path.exists(CLI), reason="oracle/_ref/sregex-cli not built")
 
 
-def _ours(pat):
+def _ours(pat, caseless=False):
     with S.Pool() as pool:
         try:
-            re = S.parse(pool, [pat])
+            re = S.parse(pool, [pat], [S.SRE_REGEX_CASELESS] if caseless else None)
         except S.SyntaxError_ as e:
             return {"err": str(e)}
         prog = S.compile(pool, re)
         return {"ast": re.dump().rstrip("\n"), "ncaps": re.ncaps, "prog": prog.dump().rstrip("\n")}
 
 
-def _theirs(pat):
-    p = subprocess.run([CLI, pat, b""], capture_output=True, timeout=20)
+def _theirs(pat, caseless=False):
+    p = subprocess.run([CLI] + (["--flags", "i"] if caseless else []) + [pat, b""], capture_output=True, timeout=20)
     if p.returncode < 0:
         return None                      # the reference crashed on this one
     err = p.stderr.decode("latin-1").strip()
@@ -60,15 +60,16 @@ def test_random_and_damaged_patterns_parse_like_the_reference(monkeypatch):
             pat = bytes(b)
         if not pat or b"\0" in pat or pat.startswith(b"-"):
             continue
+        caseless = rng.random() < 0.3       # applied at parse time (sre_yyparser.y:244-279, sre_regex.c:170-214)
         try:
-            want = _theirs(pat)
+            want = _theirs(pat, caseless)
         except subprocess.TimeoutExpired:
             crashed += 1
             continue
         if want is None:
             crashed += 1
             continue
-        got = _ours(pat)
+        got = _ours(pat, caseless)
         n += 1
         rejected += "err" in want
         if got != want:
