@@ -18,32 +18,51 @@
 #include <stdio.h>
 #include <string.h>
 
-static uint32_t
-count_insns(const sre_regex_t *r, uint32_t *nranges)
+/* Largest program the compiler emits.  The parser shares ONE subtree between all
+ * copies of a counted quantifier, so nested {n} makes the instruction count
+ * grow exponentially in the pattern length (the reference counts it in 64-bit
+ * sre_uint_t, sre_regex_compiler.c:244, and then fails its single allocation).
+ * Counting saturates here and stops walking once the cap is passed. */
+#define SRE_MAX_PROGRAM_LEN  (1u << 24)
+
+static void
+count_insns(const sre_regex_t *r, uint64_t *n, uint64_t *nranges)
 {
+    if (*n > SRE_MAX_PROGRAM_LEN) return;       /* saturated: end the walk early */
     switch (r->type) {
     case SRE_RE_ALT:
-        return 2 + count_insns(r->left, nranges) + count_insns(r->right, nranges);
+        *n += 2;
+        count_insns(r->left, n, nranges);
+        count_insns(r->right, n, nranges);
+        break;
     case SRE_RE_CAT:
-        return count_insns(r->left, nranges) + count_insns(r->right, nranges);
+        count_insns(r->left, n, nranges);
+        count_insns(r->right, n, nranges);
+        break;
     case SRE_RE_CLASS:
     case SRE_RE_NCLASS:
         *nranges += r->ranges.n;
-        return 1;
+        *n += 1;
+        break;
     case SRE_RE_LIT:
     case SRE_RE_DOT:
     case SRE_RE_ASSERT:
-        return 1;
+        *n += 1;
+        break;
     case SRE_RE_PAREN:
     case SRE_RE_STAR:
-        return 2 + count_insns(r->left, nranges);
+        *n += 2;
+        count_insns(r->left, n, nranges);
+        break;
     case SRE_RE_QUEST:
     case SRE_RE_PLUS:
     case SRE_RE_TOPLEVEL:
-        return 1 + count_insns(r->left, nranges);
+        *n += 1;
+        count_insns(r->left, n, nranges);
+        break;
     case SRE_RE_NIL:
     default:
-        return 0;
+        break;
     }
 }
 
@@ -215,10 +234,14 @@ sre_regex_compile(sre_pool_t *pool, sre_regex_t *re)
 {
     sre_program_t *prog;
     sre_emit_t     e;
-    uint32_t       n, nranges = 0, i;
+    uint32_t       n, nranges, i;
+    uint64_t       n64 = 0, nranges64 = 0;
     uint8_t       *seen;
 
-    n = count_insns(re, &nranges);
+    count_insns(re, &n64, &nranges64);
+    if (n64 > SRE_MAX_PROGRAM_LEN || nranges64 > 16ull * SRE_MAX_PROGRAM_LEN) return NULL;
+    n = (uint32_t) n64;
+    nranges = (uint32_t) nranges64;
     prog = sre_pcalloc(pool, sizeof(sre_program_t));
     if (prog == NULL) return NULL;
     prog->pool = pool;

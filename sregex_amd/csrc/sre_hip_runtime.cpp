@@ -52,6 +52,15 @@ extern "C" struct sre_hip_program_s *
 sre_hip_program_get(sre_program_t *prog)
 {
     if (prog->dev) {
+        /* one process drives one GPU (multi-GPU): the image, the scanners
+         * and the stream contexts built from this program live on the device that
+         * was current when it was first used */
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess || cur != prog->dev->device) {
+            fprintf(stderr, "[sregex-hip] program was bound to device %d but device %d is current: "
+                            "compile one program per device\n", prog->dev->device, cur);
+            return NULL;
+        }
         return prog->dev;
     }
     if (sre_hip_ready() != 0) {

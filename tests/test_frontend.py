@@ -72,3 +72,27 @@ def test_newline_flag_turns_dot_into_not_newline(lib):
         re = S.parse(pool, [b"a.\\C"], [S.SRE_REGEX_NEWLINE])
         assert re.dump() == ("Cat(NgStar(Dot), TOPLEVEL(0, Paren(0, Cat(Cat(Lit(97), NCLASS([10, 10])), "
                              "NCLASS([10, 10])))))")
+
+
+def test_nested_counted_quantifiers_do_not_overflow_the_instruction_count(lib):
+    """The parser shares one subtree between the copies of a counted quantifier,
+    so nested {n} has an instruction count beyond 2^32.  The reference counts in
+    64 bits (sre_regex_compiler.c:244) and fails its allocation; here the count
+    saturates and sre_regex_compile() returns NULL — it must neither wrap nor
+    write past its buffers (round-1 advisor finding: SIGSEGV)."""
+    import time
+    with S.Pool() as pool:
+        for src in (rb"(?:(?:(?:a{499}){499}){499}){35}", rb"(?:(?:(?:(?:[a-c]{499}){499}){499}){499}){499}",
+                    rb"(?:(?:a{499}){499}){100}"):
+            re = S.parse(pool, [src])
+            t0 = time.time()
+            try:
+                S.compile(pool, re)
+            except RuntimeError:
+                pass
+            else:
+                raise AssertionError("compiled %r" % src)
+            assert time.time() - t0 < 20.0
+        # just below the cap still compiles, with the exact length
+        prog = S.compile(pool, S.parse(pool, [rb"(?:(?:a{499}){499}){60}"]))
+        assert prog.dump().count("\n") == 499 * 499 * 60 + 6
