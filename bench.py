@@ -32,6 +32,16 @@ GIB = 1 << 30
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return None
+
+
 def cpu_baseline(sample_bytes=32 << 20):
     """The reference's own Pike path on the host cores of this box, one core
     (the reference is single-threaded; bench/sregex.c times one exec with
@@ -39,7 +49,7 @@ def cpu_baseline(sample_bytes=32 << 20):
     import sregex_amd as S
     data = S.gen_data_host(sample_bytes, b"aaabbccb")
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "sregex-bench")
-    out = {"unit": "GB/s", "cores": 1}
+    out = {"unit": "GB/s", "cores": 1, "cpu_model": cpu_model()}
     if os.path.exists(ref_bin):
         path = "/tmp/sre_bench_sample.txt"
         with open(path, "wb") as f:
@@ -78,10 +88,159 @@ def cpu_baseline(sample_bytes=32 << 20):
                               % (sample_bytes >> 20))
         else:
             out["port_value"] = port
-        out["sample_rc"] = rc
+        out["port_rc"] = rc        # what the port returned on the sample (-5 = SRE_DECLINED: no '@' in it)
     except Exception as e:              # noqa: BLE001
         out["port_error"] = repr(e)
     return out
+
+
+CFG3 = [b"a", b"ab", b"c", b"a(bc)", b"e(f)", b"gh", b"A", b"b", b"BLAH", rb"\s+", b"abcd", b"bc"]
+URI = rb"([a-z]+)://([^/ ]+)(/[^ ?]*)?(\?[^ ]*)?"
+# a program the <= 55-state step automaton declines (256+ ordered lists) with 19 list-able
+# threads: runs on the 64-bit-mask NFA tier
+NFA_PAT = rb"(?:a|b)*a(?:a|b){7}@"
+
+
+def workload_spec(name, S, nbytes, rank=0, world=1):
+    """name -> dict(pats, mode, lens, tails, text, check(lens, tails, recs))"""
+    from sregex_amd import shard
+    pats, mode = [PATTERN], S.HIP_PIKE_FIRST
+    if name == "many":
+        per = 64 << 20
+        nstreams = max(1, nbytes // per)
+        # stream g lives on rank g mod world; even g carries a matching tail
+        mine = shard.shard_streams(nstreams * world, rank, world)
+        tails = [(b" a@abc.cc " if g % 2 == 0 else b"aaabbccb") for g in mine]
+        lens = [S.gen_data_length(per, len(t)) for t in tails]
+        text = ("configs[4] shape: %d streams x 64 MiB per GPU (round-robin over %d GPUs), "
+                "/[a-z]+@[a-z]+\\.[a-z]+/ Pike, RCCL all-reduce of match counts" % (nstreams, world))
+    else:
+        tail = b"aaabbccb"
+        text = "configs[1]: /[a-z]+@[a-z]+\\.[a-z]+/ Pike first-match + captures"
+        if name == "cfg2m":
+            tail, text = b"@abc.cc ", text + ", matching tail '@abc.cc '"
+        elif name == "cfg3":
+            pats, mode = CFG3, S.HIP_PIKE_COUNT
+            text = "configs[2]: 12 regexes of t/04-multi.t combined, find-all count"
+        elif name == "cfg4":
+            pats, tail = [URI], b" abc://abc.cc/ab/c?a=b "
+            text = "configs[3]: URI pattern, 4 capture groups, matching tail"
+        elif name == "cfg1":
+            pats, mode, text = [b"a?a?a?aaa"], S.HIP_THOMPSON, "configs[0] pattern a?a?a?aaa, Thompson"
+        elif name == "nfa":
+            pats, tail = [NFA_PAT], b" abbabaabab@ "
+            text = "declined by the step automaton: /(?:a|b)*a(?:a|b){7}@/ Pike first-match, NFA tier"
+        n = S.gen_data_length(nbytes, len(tail))
+        lens, tails = [n], [tail]
+        text = "%s; 1 stream x %.2f GiB gen-data (abccc.. + %r)" % (text, n / GIB, tail.decode())
+
+    def check(recs):
+        # correctness of what is being timed (size-independent closed forms, each
+        # validated against the oracle at small size in tests/test_gpu_parity.py)
+        for n, t, r in zip(lens, tails, recs):
+            if name == "cfg3":
+                assert r == [7, n, n - 1, n, -1, -1], (r, n)     # every byte is a match of a / b / c
+            elif name == "cfg4":
+                assert r == [0, 1, n - 22, n - 1, n - 22, n - 19, n - 16, n - 10, n - 10, n - 5, n - 5, n - 1], r
+            elif name == "cfg1":
+                assert r[:2] == [0, 1], r
+            elif name == "nfa":
+                assert r[:4] == [0, 1, n - 12, n - 1], (r, n)
+            elif t == b"@abc.cc ":
+                assert r[:4] == [0, 1, 0, n - 1], (r, n)         # the match spans the whole stream
+            elif b"@" in t:
+                assert r[:4] == [0, 1, n - 9, n - 1], (r, n)      # "a@abc.cc" in front of the last space
+            else:
+                assert r[0] == S.SRE_DECLINED and r[1] == 0, r
+    return dict(name=name, pats=pats, mode=mode, lens=lens, tails=tails, text=text, check=check)
+
+
+class Resident:
+    """device buffers of the rank, re-used by every workload of a run"""
+
+    def __init__(self, torch, lib, hstream):
+        self.torch, self.lib, self.hstream, self.bufs = torch, lib, hstream, []
+
+    def fill(self, lens, tails):
+        need = [max(n, 16) for n in lens]
+        if [b.numel() for b in self.bufs] != need:
+            self.bufs = []
+            self.torch.cuda.empty_cache()
+            self.bufs = [self.torch.empty(n, dtype=self.torch.uint8, device="cuda") for n in need]
+        for b, n, t in zip(self.bufs, lens, tails):
+            assert self.lib.sre_hip_gen_data(b.data_ptr(), n, t, len(t), self.hstream) == 0
+        return [b.data_ptr() for b in self.bufs]
+
+
+def measure(spec, S, torch, res, hstream, stream, steps, warmup, barrier):
+    """W untimed + K timed passes of one workload over this rank's resident input,
+    through the public batched C ABI, results included."""
+    ptrs = res.fill(spec["lens"], spec["tails"])
+    lens = spec["lens"]
+    pool = S.Pool()
+    prog = S.compile(pool, S.parse(pool, spec["pats"]))
+    # two scanners take turns: step i is queued before the results of step i-1
+    # are collected (they travel to pinned memory as part of the queued work),
+    # so the GPU goes from one pass straight into the next
+    scs = [S.Scanner(pool, prog, spec["mode"], S.ENGINE_AUTO) for _ in range(2)]
+    sc = scs[0]
+    if sc.engine == S.ENGINE_VM and sum(lens) > (64 << 20):
+        pool.destroy()
+        raise RuntimeError("no throughput engine admits this program: the exact VM runs at MB/s, not benchmarked at this size")
+
+    def run(nsteps):
+        recs, kms, inflight = None, [], None
+        for i in range(nsteps):
+            cur = scs[i % 2]
+            cur.enqueue(ptrs, lens, hstream)
+            if inflight is not None:
+                recs = inflight.results()
+                kms.append(inflight.last_kernel_ms)
+            inflight = cur
+        if inflight is not None:
+            recs = inflight.results()
+            kms.append(inflight.last_kernel_ms)
+        return recs, kms
+
+    recs, _ = run(max(warmup, 2))       # both scanners allocate their buffers outside the timed region
+    spec["check"](recs)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    barrier()
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    recs, kernel_ms = run(steps)
+    ev1.record(stream)
+    barrier()
+    dt = time.perf_counter() - t0
+    spec["check"](recs)
+    total = sum(lens)
+    kms = sum(kernel_ms) / len(kernel_ms)
+    step_gpu_ms = ev0.elapsed_time(ev1) / steps     # every kernel and copy of a step, and the gaps between them
+    out = dict(dt=dt, total=total, recs=recs, kernel_ms=kms, step_gpu_ms=step_gpu_ms,
+               matches=sum(1 for r in recs if r[0] >= 0),
+               segment_bytes=sc.last_segment_bytes, fixup_rounds=sc.last_fixups,
+               lineage_passes=sc.last_lineage_passes, engine=sc.engine_name, kernel=sc.kernel_name)
+    pool.destroy()
+    return out
+
+
+def roofline(m):
+    """whole-step fraction first (all kernels of the step), the dominant kernel alone beside it"""
+    whole = m["total"] / (m["step_gpu_ms"] * 1e-3) / 1e9
+    scan = m["total"] / (m["kernel_ms"] * 1e-3) / 1e9 if m["kernel_ms"] > 0 else None
+    return {"bound": "hbm", "achieved": whole, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": whole / HBM_PEAK_GBS, "traffic": None,
+            "step_gpu_ms": m["step_gpu_ms"], "kernel": m["kernel"], "kernel_ms": m["kernel_ms"],
+            "kernel_achieved": scan, "kernel_frac": scan / HBM_PEAK_GBS if scan else None,
+            "algorithmic_bytes_per_launch": m["total"]}
+
+
+def git_commit():
+    try:
+        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True,
+                              text=True, timeout=10).stdout.strip() or None
+    except Exception:       # noqa: BLE001
+        return None
 
 
 def main():
@@ -92,11 +251,13 @@ def main():
     ap.add_argument("--bytes", type=int, default=0,
                     help="bytes per GPU (default: 4 GiB single stream at N=1, 8 GiB = 128 x 64 MiB streams at N>1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--config", default="cfg2", choices=["cfg1", "cfg2", "cfg2m", "cfg3", "cfg4"],
-                    help="N=1 workload: cfg2 = BASELINE configs[1] (default, the headline); cfg2m = "
-                         "same with a matching tail (captures span the whole stream); cfg3 = "
-                         "configs[2] multi-regex find-all count; cfg4 = configs[3] URI, 4 groups; "
-                         "cfg1 = configs[0]'s pattern, Thompson")
+    ap.add_argument("--no-variants", action="store_true",
+                    help="N=1: do not measure the other configurations beside the headline (config.variants)")
+    ap.add_argument("--config", default="cfg2", choices=["cfg1", "cfg2", "cfg2m", "cfg3", "cfg4", "nfa"],
+                    help="N=1 headline workload: cfg2 = BASELINE configs[1] (default); cfg2m = same with a "
+                         "matching tail (captures span the whole stream); cfg3 = configs[2] multi-regex "
+                         "find-all count; cfg4 = configs[3] URI, 4 groups; cfg1 = configs[0]'s pattern, "
+                         "Thompson; nfa = a program the step automaton declines (NFA tier)")
     ap.add_argument("--many-streams", action="store_true",
                     help="use the N>1 workload shape (64 MiB streams) even on one GPU")
     args = ap.parse_args()
@@ -113,165 +274,108 @@ def main():
     # rehearsal knobs (one-GPU box): SRE_BENCH_DEVICE pins every rank to one
     # device, SRE_BENCH_BACKEND=gloo replaces RCCL (which refuses two ranks on one GPU)
     device = int(os.environ.get("SRE_BENCH_DEVICE", local_rank))
+    backend = os.environ.get("SRE_BENCH_BACKEND", "nccl")       # "nccl" == RCCL
     torch.cuda.set_device(device)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group(os.environ.get("SRE_BENCH_BACKEND", "nccl"))    # "nccl" == RCCL
+        dist.init_process_group(backend)
     lib = S.load_library()
     assert lib.sre_hip_set_device(device) == 0
     stream = torch.cuda.current_stream()
     hstream = ctypes.c_void_p(stream.cuda_stream)
-
-    # ---- resident input -------------------------------------------------
-    pats, mode = [PATTERN], S.HIP_PIKE_FIRST
-    if args.bytes <= 0:
-        args.bytes = 4 * GIB if (world == 1 and not args.many_streams) else 8 * GIB
-    if world == 1 and not args.many_streams:
-        tail = b"aaabbccb"
-        name = "configs[1]: /[a-z]+@[a-z]+\\.[a-z]+/ Pike first-match + captures"
-        if args.config == "cfg2m":
-            tail, name = b"@abc.cc ", name + ", matching tail '@abc.cc '"
-        elif args.config == "cfg3":
-            pats = [b"a", b"ab", b"c", b"a(bc)", b"e(f)", b"gh", b"A", b"b", b"BLAH", rb"\s+", b"abcd", b"bc"]
-            mode, name = S.HIP_PIKE_COUNT, "configs[2]: 12 regexes of t/04-multi.t combined, find-all count"
-        elif args.config == "cfg4":
-            pats = [rb"([a-z]+)://([^/ ]+)(/[^ ?]*)?(\?[^ ]*)?"]
-            tail, name = b" abc://abc.cc/ab/c?a=b ", "configs[3]: URI pattern, 4 capture groups, matching tail"
-        elif args.config == "cfg1":
-            pats, mode, name = [b"a?a?a?aaa"], S.HIP_THOMPSON, "configs[0] pattern a?a?a?aaa, Thompson"
-        n = S.gen_data_length(args.bytes, len(tail))
-        lens = [n]
-        tails = [tail]
-        workload = "%s; 1 stream x %.2f GiB gen-data (abccc.. + %r)" % (name, n / GIB, tail.decode())
-    else:
-        per = 64 << 20
-        nstreams = max(1, args.bytes // per)
-        # stream g lives on rank g mod world; even g carries a matching tail
-        mine = shard.shard_streams(nstreams * world, rank, world)
-        tails = [(b" a@abc.cc " if g % 2 == 0 else b"aaabbccb") for g in mine]
-        lens = [S.gen_data_length(per, len(t)) for t in tails]
-        workload = ("configs[4] shape: %d streams x 64 MiB per GPU (round-robin over %d GPUs), "
-                    "/[a-z]+@[a-z]+\\.[a-z]+/ Pike, RCCL all-reduce of match counts" % (nstreams, world))
-    bufs = [torch.empty(max(n, 16), dtype=torch.uint8, device="cuda") for n in lens]
-    for b, n, t in zip(bufs, lens, tails):
-        assert lib.sre_hip_gen_data(b.data_ptr(), n, t, len(t), hstream) == 0
-    ptrs = [b.data_ptr() for b in bufs]
-    total = sum(lens)
-
-    pool = S.Pool()
-    prog = S.compile(pool, S.parse(pool, pats))
-    # two scanners take turns: step i is queued before the results of step i-1
-    # are collected (they travel to pinned memory as part of the queued work),
-    # so the GPU goes from one pass straight into the next
-    scs = [S.Scanner(pool, prog, mode, S.ENGINE_SCAN) for _ in range(2)]
-    sc = scs[0]
-
-    def run(nsteps):
-        """nsteps passes over the resident batch; returns (last records, kernel ms of every pass)"""
-        recs, kms, inflight = None, [], None
-        for i in range(nsteps):
-            cur = scs[i % 2]
-            cur.enqueue(ptrs, lens, hstream)
-            if inflight is not None:
-                recs = inflight.results()
-                kms.append(inflight.last_kernel_ms)
-            inflight = cur
-        if inflight is not None:
-            recs = inflight.results()
-            kms.append(inflight.last_kernel_ms)
-        return recs, kms
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    args.warmup = max(args.warmup, 2)       # both scanners allocate their buffers outside the timed region
-    recs, _ = run(args.warmup)
-    # correctness of what is being timed (size-independent property): a stream
-    # matches iff its tail holds the '@' form, and then spans the whole stream
-    for n, t, r in zip(lens, tails, recs):
-        if args.config == "cfg3":
-            assert r == [7, n, n - 1, n, -1, -1], (r, n)     # every byte is a match of a / b / c
-        elif args.config == "cfg4":
-            assert r == [0, 1, n - 22, n - 1, n - 22, n - 19, n - 16, n - 10, n - 10, n - 5, n - 5, n - 1], r
-        elif args.config == "cfg1":
-            assert r[:2] == [0, 1], r
-        elif t == b"@abc.cc ":
-            assert r[:4] == [0, 1, 0, n - 1], (r, n)         # the match spans the whole stream
-        elif b"@" in t:
-            assert r[:4] == [0, 1, n - 9, n - 1], (r, n)      # "a@abc.cc" in front of the last space
-        else:
-            assert r[0] == S.SRE_DECLINED and r[1] == 0, r
+    many = world > 1 or args.many_streams
+    if args.bytes <= 0:
+        args.bytes = 8 * GIB if many else 4 * GIB
+    res = Resident(torch, lib, hstream)
+    head = workload_spec("many" if many else args.config, S, args.bytes, rank, world)
+    m = measure(head, S, torch, res, hstream, stream, args.steps, args.warmup, barrier)
 
-    barrier()
-    t0 = time.perf_counter()
-    recs, kernel_ms = run(args.steps)
-    barrier()
-    dt = time.perf_counter() - t0
-
-    matches = sum(1 for r in recs if r[0] >= 0)
-    dt = shard.allreduce_max(dt, "cuda")                        # slowest rank
-    matches, total_all = shard.allreduce_counts([matches, total], "cuda")   # the path's only exchange step
+    dt = shard.allreduce_max(m["dt"], "cuda")                        # slowest rank
+    matches, total_all = shard.allreduce_counts([m["matches"], m["total"]], "cuda")   # the path's only exchange step
+    devices = shard.allgather_ints(device, "cuda")                   # which ordinal each rank drives
 
     if rank == 0:
-        ms_per_step = dt / args.steps * 1e3
-        value = total_all * args.steps / dt / 1e9
-        kms = sum(kernel_ms) / len(kernel_ms)
-        achieved = total / (kms * 1e-3) / 1e9           # this rank's kernel: 1 B per input byte
         line = {
             "metric": "GB/s input scanned (whole job), gen-data stream resident in HBM",
-            "value": value, "unit": "GB/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "value": total_all * args.steps / dt / 1e9, "unit": "GB/s", "n_gpus": world, "steps": args.steps,
+            "warmup": max(args.warmup, 2), "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": workload, "bytes_per_gpu": total, "streams_per_gpu": len(lens),
-                       "segment_bytes": sc.last_segment_bytes, "fixup_rounds": sc.last_fixups,
-                       "matches": matches, "engine": "scan", "lineage_passes": sc.last_lineage_passes},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "sre_k_scan<%d, %d>" % (2 if mode == S.HIP_PIKE_COUNT else 1, sc.class_bits),
-                         "kernel_ms": kms,
-                         "algorithmic_bytes_per_launch": total},
+            "config": {"workload": head["text"], "bytes_per_gpu": m["total"], "streams_per_gpu": len(head["lens"]),
+                       "segment_bytes": m["segment_bytes"], "fixup_rounds": m["fixup_rounds"],
+                       "matches": matches, "engine": m["engine"], "lineage_passes": m["lineage_passes"],
+                       "backend": ("rccl" if backend == "nccl" else backend) if world > 1 else None,
+                       "world_size": world, "devices": devices, "commit": git_commit()},
+            "roofline": roofline(m),
         }
-        prof = os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")
-        if world == 1 and args.config == "cfg2" and not args.many_streams and total == 4 * GIB - 3 \
-                and os.path.exists(prof):
-            # HBM bytes per launch from the separate rocprofv3 --pmc passes of this
-            # same command (profiles/README.md): 2 x FETCH_SIZE (gfx950 correction,
-            # MI355X_MICROARCH.md HBM section) + WRITE_SIZE, KB -> bytes
-            pm = {(r["counter"], "sre_k_scan<1, 2>" in r["kernel"]): r["mean_value_KB"]
-                  for r in json.load(open(prof))}
+        if world > 1 and len(set(devices)) != world:
+            # ranks sharing a GPU: a plumbing rehearsal, not a scaling record
+            line["config"]["rehearsal"] = True
+            line["value_comparable"] = False
+        prof = os.path.join(ROOT, "profiles", "r02_pmc_hbm.json")
+        if world == 1 and head["name"] == "cfg2" and m["total"] == 4 * GIB - 3 and os.path.exists(prof):
+            # HBM bytes per launch of the dominant kernel from separate rocprofv3 --pmc passes
+            # of this same command (profiles/README.md): 2 x FETCH_SIZE (gfx950 correction,
+            # MI355X_MICROARCH.md HBM section) + WRITE_SIZE, KB -> bytes.  A stored
+            # measurement (PMC counters cannot be read from inside the run): source named.
+            pj = json.load(open(prof))
+            pm = {(r["counter"], "sre_k_scan<1, 2>" in r["kernel"]): r["mean_value_KB"] for r in pj["counters"]}
             if ("FETCH_SIZE", True) in pm:
                 line["roofline"]["traffic"] = (2 * pm[("FETCH_SIZE", True)] + pm[("WRITE_SIZE", True)]) * 1024
-                line["roofline"]["traffic_source"] = "profiles/r01_pmc_hbm.json"
-        if world == 1 and not args.many_streams:
+                line["roofline"]["traffic_source"] = "profiles/r02_pmc_hbm.json (commit %s, %s)" % (
+                    pj.get("commit"), pj.get("date"))
+        if world == 1 and not many:
             # measured streaming-read ceiling of this box, same buffer
+            ptr0, len0 = res.bufs[0].data_ptr(), head["lens"][0]
             ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            lib.sre_hip_read_ceiling(ptrs[0], lens[0], hstream)
+            lib.sre_hip_read_ceiling(ptr0, len0, hstream)
             ev0.record(stream)
             for _ in range(5):
-                lib.sre_hip_read_ceiling(ptrs[0], lens[0], hstream)
+                lib.sre_hip_read_ceiling(ptr0, len0, hstream)
             ev1.record(stream)
             torch.cuda.synchronize()
-            line["roofline"]["measured_read_ceiling"] = lens[0] * 5 / (ev0.elapsed_time(ev1) * 1e-3) / 1e9
+            line["roofline"]["measured_read_ceiling"] = len0 * 5 / (ev0.elapsed_time(ev1) * 1e-3) / 1e9
             # ... and of the scanner's own staging pattern with no automaton work
             # (one row per lane, whole 128-byte lines, one stage ahead)
-            seg = sc.last_segment_bytes
-            if seg % 128 == 0 and lens[0] >= seg:
-                lib.sre_hip_read_pattern(ptrs[0], lens[0], seg, 128, 16384, hstream)
+            seg = m["segment_bytes"]
+            if seg and seg % 128 == 0 and len0 >= seg:
+                lib.sre_hip_read_pattern(ptr0, len0, seg, 128, 16384, hstream)
                 ev0.record(stream)
                 for _ in range(5):
-                    lib.sre_hip_read_pattern(ptrs[0], lens[0], seg, 128, 16384, hstream)
+                    lib.sre_hip_read_pattern(ptr0, len0, seg, 128, 16384, hstream)
                 ev1.record(stream)
                 torch.cuda.synchronize()
                 line["roofline"]["measured_staging_ceiling"] = \
-                    (lens[0] // seg * seg) * 5 / (ev0.elapsed_time(ev1) * 1e-3) / 1e9
-            if not args.no_cpu_baseline:
-                line["cpu_baseline"] = cpu_baseline()
+                    (len0 // seg * seg) * 5 / (ev0.elapsed_time(ev1) * 1e-3) / 1e9
+        if world == 1 and not args.no_variants and head["name"] == "cfg2" and not args.many_streams:
+            # the other configurations of BASELINE.json on this GPU, same harness: whole-step
+            # time and whole-step fraction of the HBM peak (every kernel of the step), the
+            # dominant kernel alone beside it
+            variants = {}
+            for name in ("cfg2m", "cfg3", "cfg4", "nfa", "many"):
+                try:
+                    vs = workload_spec(name, S, 8 * GIB if name == "many" else args.bytes)
+                    vm = measure(vs, S, torch, res, hstream, stream, min(args.steps, 6), 2, barrier)
+                    r = roofline(vm)
+                    variants[name] = {"workload": vs["text"], "ms_per_step": vm["dt"] / min(args.steps, 6) * 1e3,
+                                      "step_gpu_ms": vm["step_gpu_ms"], "GBps": r["achieved"], "frac": r["frac"],
+                                      "kernel": vm["kernel"], "kernel_ms": vm["kernel_ms"],
+                                      "kernel_frac": r["kernel_frac"], "engine": vm["engine"],
+                                      "matches": vm["matches"], "fixup_rounds": vm["fixup_rounds"],
+                                      "lineage_passes": vm["lineage_passes"]}
+                except Exception as e:          # noqa: BLE001 - a variant must not take the headline down
+                    variants[name] = {"error": repr(e)}
+            line["config"]["variants"] = variants
+        if world == 1 and not many and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
-    pool.destroy()
 
 
 if __name__ == "__main__":

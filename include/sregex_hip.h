@@ -37,7 +37,10 @@ enum {
 enum {
     SRE_HIP_ENGINE_AUTO = 0, /* table-driven scanner when the program admits one  */
     SRE_HIP_ENGINE_VM   = 1, /* exact bytecode VM kernel, one lane per stream     */
-    SRE_HIP_ENGINE_SCAN = 2  /* table-driven segment-parallel scanner, or fail    */
+    SRE_HIP_ENGINE_SCAN = 2, /* table-driven segment-parallel scanner, or fail    */
+    SRE_HIP_ENGINE_NFA  = 3  /* bit-parallel NFA scanner (<= 64 list-able threads held as
+                                a 64-bit mask per lane), or fail: the tier for programs
+                                whose ordered-list automaton is too large */
 };
 
 typedef struct sre_hip_scanner_s  sre_hip_scanner_t;
@@ -56,7 +59,7 @@ SRE_API int sre_hip_set_device(int ordinal);
 SRE_API sre_hip_scanner_t *sre_hip_scanner_create(sre_pool_t *pool,
     sre_program_t *prog, int mode, int engine);
 
-/* engine actually chosen: SRE_HIP_ENGINE_VM or SRE_HIP_ENGINE_SCAN */
+/* engine actually chosen: SRE_HIP_ENGINE_VM, SRE_HIP_ENGINE_SCAN or SRE_HIP_ENGINE_NFA */
 SRE_API int sre_hip_scanner_engine(sre_hip_scanner_t *sc);
 
 /*
@@ -78,6 +81,10 @@ SRE_API int sre_hip_scanner_last_lineage_passes(sre_hip_scanner_t *sc);
  * lookup advances 8 / bits bytes); 0 for the VM engine.  Names the kernel
  * variant (sre_k_scan<mode, bits>) in profiles. */
 SRE_API int sre_hip_scanner_class_bits(sre_hip_scanner_t *sc);
+
+/* name of the dominant kernel of a scan with this scanner, as rocprofv3 prints it
+ * (e.g. "sre_k_scan<1, 2>"); owned by the scanner */
+SRE_API const char *sre_hip_scanner_kernel_name(sre_hip_scanner_t *sc);
 
 /* measurement: duration (ms) of the segment-scan kernel of the last enqueued
  * scan, from hipEvents recorded on the caller's stream around that launch;

@@ -23,7 +23,7 @@ import tempfile
 SRE_OK, SRE_ERROR, SRE_AGAIN, SRE_BUSY, SRE_DONE, SRE_DECLINED = 0, -1, -2, -3, -4, -5
 SRE_REGEX_CASELESS, SRE_REGEX_NEWLINE = 1, 2
 HIP_THOMPSON, HIP_PIKE_FIRST, HIP_PIKE_COUNT = 0, 1, 2
-ENGINE_AUTO, ENGINE_VM, ENGINE_SCAN = 0, 1, 2
+ENGINE_AUTO, ENGINE_VM, ENGINE_SCAN, ENGINE_NFA = 0, 1, 2, 3
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libsregex.so")
@@ -61,6 +61,7 @@ API = {
     "sre_hip_scanner_last_fixups": (ctypes.c_int, [_vp]),
     "sre_hip_scanner_last_lineage_passes": (ctypes.c_int, [_vp]),
     "sre_hip_scanner_class_bits": (ctypes.c_int, [_vp]),
+    "sre_hip_scanner_kernel_name": (ctypes.c_char_p, [_vp]),
     "sre_hip_scanner_last_kernel_ms": (ctypes.c_double, [_vp]),
     "sre_hip_scanner_last_segment_bytes": (_sz, [_vp]),
     "sre_hip_scan_enqueue": (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_sz), _sz, _vp]),
@@ -279,6 +280,15 @@ class Scanner:
     def set_segment_bytes(self, nbytes):
         if self.lib.sre_hip_scanner_set_segment_bytes(self.h, nbytes) != 0:
             raise ValueError("segment size must be a multiple of 64")
+
+    @property
+    def engine_name(self):
+        return {ENGINE_VM: "vm", ENGINE_SCAN: "scan", ENGINE_NFA: "nfa"}.get(self.engine, "?")
+
+    @property
+    def kernel_name(self):
+        """the dominant kernel of a scan, as rocprofv3 names it"""
+        return self.lib.sre_hip_scanner_kernel_name(self.h).decode()
 
     @property
     def last_lineage_passes(self):

@@ -4,6 +4,7 @@
  * A scanner binds one compiled program, one mode and one engine:
  *   ENGINE_VM    exact bytecode VM kernel, one lane per stream (sre_hip_vm.hip)
  *   ENGINE_SCAN  table-driven segment-parallel scanner        (sre_hip_scan.hip)
+ *   ENGINE_NFA   bit-parallel NFA scanner + exact VM window   (sre_hip_nfa.hip)
  * Stream pointers/lengths are staged to the device per call; results come back
  * as fixed-stride records.  Everything enqueues on the caller's hipStream_t so
  * a driver can bracket the scan with its own events.
@@ -13,6 +14,8 @@
 #include "sre_hip_scan.h"
 #include "sre_scan_host.h"
 #include "sre_dfa.h"
+#include "sre_nfa.h"
+#include "sre_hip_nfa.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -22,6 +25,7 @@ struct sre_hip_scanner_s {
     sre_program_t     *prog;
     sre_hip_program_s *dp;
     int                mode, engine;
+    char               kernel_name[48];
     uint32_t           ovec_slots;      /* 2 * (max_ncaps + 1) */
     /* per-call staging, grown on demand */
     size_t             cap_streams;
@@ -65,6 +69,15 @@ struct sre_hip_scanner_s {
      * call costs one small copy in and one out */
     uint64_t                 *d_in, *h_in;
     unsigned char            *d_out, *h_out;
+    /* ENGINE_NFA */
+    sre_nfa_t                *nfa;
+    sre_nfa_tables_t          ntab;             /* device pointers inside */
+    sre_nfa_summary_t        *d_nsum;
+    size_t                    nsum_cap;
+    uint64_t                 *d_belief;
+    uint8_t                  *d_bvalid;
+    void                     *d_nacc;
+    sre_nfa_status_t         *d_nstatus, *h_nstatus;
 };
 
 static void
@@ -86,9 +99,43 @@ scanner_release(void *data)
     if (sc->ev0) (void) hipEventDestroy(sc->ev0);
     if (sc->ev1) (void) hipEventDestroy(sc->ev1);
     if (sc->ev_done) (void) hipEventDestroy(sc->ev_done);
+    if (sc->d_nsum) (void) hipFree(sc->d_nsum);
+    if (sc->d_belief) (void) hipFree(sc->d_belief);
+    if (sc->d_bvalid) (void) hipFree(sc->d_bvalid);
+    if (sc->d_nacc) (void) hipFree(sc->d_nacc);
+    if (sc->ntab.accept) (void) hipFree(const_cast<uint64_t *>(sc->ntab.accept));
+    if (sc->ntab.follow) (void) hipFree(const_cast<uint64_t *>(sc->ntab.follow));
+    sre_nfa_free(sc->nfa);
     sre_scan_tables_release(sc->tab);
     sre_dfa_free(sc->dfa);
     free(sc);
+}
+
+/* device copies of the bit-parallel tables, padded to the slice count the
+ * kernel variant is compiled for */
+static int
+nfa_upload(sre_hip_scanner_t *sc)
+{
+    const sre_nfa_t *n = sc->nfa;
+    uint32_t         ns = n->nslices <= 4 ? n->nslices : n->nslices <= 6 ? 6 : 8;
+    if (ns == 0) ns = 1;
+    std::vector<uint64_t> fol((size_t) ns * 256, 0);
+    memcpy(fol.data(), n->follow.data(), n->follow.size() * sizeof(uint64_t));
+    uint64_t *d_acc = NULL, *d_fol = NULL;
+    SRE_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_acc), 256 * sizeof(uint64_t)));
+    sc->ntab.accept = d_acc;
+    SRE_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_fol), fol.size() * sizeof(uint64_t)));
+    sc->ntab.follow = d_fol;
+    SRE_HIP_TRY(hipMemcpy(d_acc, n->accept, 256 * sizeof(uint64_t), hipMemcpyHostToDevice));
+    SRE_HIP_TRY(hipMemcpy(d_fol, fol.data(), fol.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    sc->ntab.nbits = n->nbits;
+    sc->ntab.nslices = ns;
+    for (int v = 0; v < 3; v++) sc->ntab.init[v] = n->init[v];
+    sc->ntab.any_bits = n->any_bits;
+    sc->ntab.match_bits = n->match_bits;
+    return 0;
+hip_failed:
+    return -1;
 }
 
 extern "C" SRE_API int
@@ -125,7 +172,7 @@ sre_hip_scanner_create(sre_pool_t *pool, sre_program_t *prog, int mode, int engi
     sc->ovec_slots = 2 * (maxcaps + 1);
     sc->engine = SRE_HIP_ENGINE_VM;
 
-    if (engine != SRE_HIP_ENGINE_VM) {
+    if (engine == SRE_HIP_ENGINE_AUTO || engine == SRE_HIP_ENGINE_SCAN) {
         /* compile step: step automaton + device tables (independent of any input) */
         const char *why = NULL;
         sc->dfa = sre_dfa_build(prog, 4 * SRE_SCAN_MAX_STATES, &why);
@@ -135,6 +182,21 @@ sre_hip_scanner_create(sre_pool_t *pool, sre_program_t *prog, int mode, int engi
         } else if (engine == SRE_HIP_ENGINE_SCAN) {
             fprintf(stderr, "[sregex-hip] table-driven scanner not available: %s\n",
                     why ? why : "unknown");
+            scanner_release(sc);
+            return NULL;
+        }
+    }
+    if (sc->engine == SRE_HIP_ENGINE_VM && (engine == SRE_HIP_ENGINE_AUTO || engine == SRE_HIP_ENGINE_NFA)) {
+        /* the ordered-list automaton is too large (or was not asked for): the
+         * bit-parallel form, if the program has one */
+        const char *why = NULL;
+        if (mode == SRE_HIP_PIKE_COUNT) why = "COUNT mode needs the ordered list at every match";
+        else sc->nfa = sre_nfa_build(prog, &why);
+        if (sc->nfa && nfa_upload(sc) == 0) {
+            sc->engine = SRE_HIP_ENGINE_NFA;
+        } else if (engine == SRE_HIP_ENGINE_NFA) {
+            fprintf(stderr, "[sregex-hip] bit-parallel NFA scanner not available: %s\n",
+                    why ? why : "device allocation failed");
             scanner_release(sc);
             return NULL;
         }
@@ -180,6 +242,23 @@ sre_hip_scanner_class_bits(sre_hip_scanner_t *sc)
     return sc->engine == SRE_HIP_ENGINE_SCAN ? (int) sc->tab->h.class_bits : 0;
 }
 
+extern "C" SRE_API const char *
+sre_hip_scanner_kernel_name(sre_hip_scanner_t *sc)
+{
+    if (sc->kernel_name[0] == 0) {
+        if (sc->engine == SRE_HIP_ENGINE_SCAN) {
+            snprintf(sc->kernel_name, sizeof(sc->kernel_name), "sre_k_scan<%d, %d>",
+                     sc->mode == SRE_HIP_PIKE_COUNT ? 2 : 1, (int) sc->tab->h.class_bits);
+        } else if (sc->engine == SRE_HIP_ENGINE_NFA) {
+            sre_nfa_kernel_name(sc->mode, sc->ntab.nslices, sc->kernel_name, sizeof(sc->kernel_name));
+        } else {
+            snprintf(sc->kernel_name, sizeof(sc->kernel_name), "%s",
+                     sc->mode == SRE_HIP_THOMPSON ? "sre_k_thompson_scan" : "sre_k_pike_scan");
+        }
+    }
+    return sc->kernel_name;
+}
+
 extern "C" SRE_API int
 sre_hip_scanner_last_lineage_passes(sre_hip_scanner_t *sc)
 {
@@ -199,7 +278,7 @@ sre_hip_scanner_last_kernel_ms(sre_hip_scanner_t *sc)
 extern "C" SRE_API size_t
 sre_hip_scanner_last_segment_bytes(sre_hip_scanner_t *sc)
 {
-    return sc->engine == SRE_HIP_ENGINE_SCAN ? sc->geom.seg_bytes : 0;
+    return sc->engine != SRE_HIP_ENGINE_VM ? sc->geom.seg_bytes : 0;
 }
 
 static size_t
@@ -225,13 +304,21 @@ scanner_reserve(sre_hip_scanner_t *sc, size_t n)
         sc->d_lo = sc->h_lo = NULL;
         sc->cap_streams = 0;
         const size_t in_bytes = (3 * n + 1) * sizeof(uint64_t);
-        const size_t out_bytes = record_bytes(sc, n) + n * sizeof(sre_stream_status_t);
+        const size_t out_bytes = record_bytes(sc, n) + n * sizeof(sre_stream_status_t);   /* >= sre_nfa_status_t */
+        static_assert(sizeof(sre_nfa_status_t) <= sizeof(sre_stream_status_t), "status block");
+        static_assert(sizeof(sre_nfa_status_t) == sizeof(sre_nfa_window_t), "window layout");
         SRE_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&sc->d_in), in_bytes));
         SRE_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&sc->h_in), in_bytes, 0));
         SRE_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&sc->d_out), out_bytes));
         SRE_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&sc->h_out), out_bytes, 0));
         SRE_HIP_TRY(hipMalloc(&sc->d_acc, sre_scan_verify_acc_bytes((uint32_t) n)));
         SRE_HIP_TRY(sre_scan_verify_acc_init(sc->d_acc, (uint32_t) n, NULL));
+        if (sc->engine == SRE_HIP_ENGINE_NFA) {
+            if (sc->d_nacc) (void) hipFree(sc->d_nacc);
+            sc->d_nacc = NULL;
+            SRE_HIP_TRY(hipMalloc(&sc->d_nacc, sre_nfa_verify_acc_bytes((uint32_t) n)));
+            SRE_HIP_TRY(sre_nfa_verify_acc_init(sc->d_nacc, (uint32_t) n, NULL));
+        }
         SRE_HIP_TRY(hipStreamSynchronize(NULL));
         SRE_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&sc->d_lo), n * sizeof(int64_t)));
         SRE_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&sc->h_lo), n * sizeof(int64_t), 0));
@@ -248,7 +335,11 @@ scanner_reserve(sre_hip_scanner_t *sc, size_t n)
     sc->h_records = reinterpret_cast<sre_int_t *>(sc->h_out);
     sc->d_status = reinterpret_cast<sre_stream_status_t *>(sc->d_out + record_bytes(sc, n));
     sc->h_status = reinterpret_cast<sre_stream_status_t *>(sc->h_out + record_bytes(sc, n));
-    if (sc->engine == SRE_HIP_ENGINE_VM && n * sc->ctx_stride > sc->ctx_cap) {
+    sc->d_nstatus = reinterpret_cast<sre_nfa_status_t *>(sc->d_status);
+    sc->h_nstatus = reinterpret_cast<sre_nfa_status_t *>(sc->h_status);
+    if ((sc->engine == SRE_HIP_ENGINE_VM || (sc->engine == SRE_HIP_ENGINE_NFA && sc->mode != SRE_HIP_THOMPSON))
+        && n * sc->ctx_stride > sc->ctx_cap)
+    {
         if (sc->d_ctx) (void) hipFree(sc->d_ctx);
         sc->d_ctx = NULL;
         sc->ctx_cap = 0;
@@ -279,7 +370,10 @@ scan_geometry(sre_hip_scanner_t *sc, size_t nstreams)
         /* as few rounds of resident workgroups as keep a segment <= ~16 KiB:
          * longer segments mean fewer summaries to verify, shorter ones keep
          * every CU busy; measured flat between 5.5 and 16 KiB on MI355X */
-        if (sc->blocks_per_cu == 0) sc->blocks_per_cu = sre_scan_blocks_per_cu(&sc->tab->h);
+        if (sc->blocks_per_cu == 0) {
+            sc->blocks_per_cu = sc->engine == SRE_HIP_ENGINE_NFA ? sre_nfa_blocks_per_cu(sc->mode, sc->ntab.nslices)
+                                                                 : sre_scan_blocks_per_cu(&sc->tab->h);
+        }
         const uint64_t resident = 256ull * (uint64_t) sc->blocks_per_cu * SRE_SCAN_BLOCK;
         uint64_t       rounds = (total + resident * 16384 - 1) / (resident * 16384);
         if (rounds < 1) rounds = 1;
@@ -302,6 +396,22 @@ scan_geometry(sre_hip_scanner_t *sc, size_t nstreams)
     sc->geom.seg_bytes = (uint32_t) seg;
     sc->geom.nsegs = nsegs;
 
+    if (sc->engine == SRE_HIP_ENGINE_NFA) {
+        if (nsegs > sc->nsum_cap) {
+            if (sc->d_nsum) (void) hipFree(sc->d_nsum);
+            if (sc->d_belief) (void) hipFree(sc->d_belief);
+            if (sc->d_bvalid) (void) hipFree(sc->d_bvalid);
+            sc->d_nsum = NULL;
+            sc->d_belief = NULL;
+            sc->d_bvalid = NULL;
+            sc->nsum_cap = 0;
+            SRE_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&sc->d_nsum), nsegs * sizeof(sre_nfa_summary_t)));
+            SRE_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&sc->d_belief), nsegs * sizeof(uint64_t)));
+            SRE_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&sc->d_bvalid), nsegs));
+            sc->nsum_cap = nsegs;
+        }
+        return 0;
+    }
     if (nsegs > sc->sum_cap) {
         if (sc->d_sum) (void) hipFree(sc->d_sum);
         sc->d_sum = NULL;
@@ -318,6 +428,25 @@ scan_geometry(sre_hip_scanner_t *sc, size_t nstreams)
             SRE_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&sc->d_scratch), need * sizeof(uint16_t)));
             sc->scratch_cap = need;
         }
+    }
+    return 0;
+hip_failed:
+    return -1;
+}
+
+/* chain check of the set pass and, for Pike, the exact VM over the window of every
+ * stream that is verified and holds an event (d_lo: the streams of this fix-up round) */
+static int
+nfa_finish(sre_hip_scanner_t *sc, const int64_t *d_lo, hipStream_t stream)
+{
+    const uint32_t n = sc->geom.nstreams;
+    SRE_HIP_TRY(sre_launch_nfa_verify(sc->mode, sc->geom, sc->d_nsum, sc->d_nacc, sc->d_nstatus,
+                                      sc->d_belief, sc->d_bvalid, sc->d_records, sc->ovec_slots, d_lo, stream));
+    if (sc->mode != SRE_HIP_THOMPSON) {
+        if (d_lo == NULL) SRE_HIP_TRY(hipMemsetAsync(sc->d_ctx, 0, (size_t) n * sc->ctx_stride, stream));
+        SRE_HIP_TRY(sre_launch_pike_window(sc->dp->d_blob, sc->d_ptrs, sc->d_lens, n, sc->d_ctx, sc->ctx_stride,
+                                           sc->d_records, sc->ovec_slots,
+                                           reinterpret_cast<const sre_nfa_window_t *>(sc->d_nstatus), d_lo, stream));
     }
     return 0;
 hip_failed:
@@ -351,6 +480,20 @@ sre_hip_scan_enqueue(sre_hip_scanner_t *sc, const void *const *d_streams, const 
         SRE_HIP_TRY(sre_launch_vm_scan(sc->dp->d_blob, sc->mode, sc->d_ptrs, sc->d_lens,
                                        (uint32_t) nstreams, sc->d_ctx, sc->ctx_stride,
                                        sc->d_records, sc->ovec_slots, stream));
+    } else if (sc->engine == SRE_HIP_ENGINE_NFA) {
+        if (scan_geometry(sc, nstreams) != 0) return -1;
+        SRE_HIP_TRY(hipMemcpyAsync(sc->d_in, sc->h_in, (3 * nstreams + 1) * sizeof(uint64_t),
+                                   hipMemcpyHostToDevice, stream));
+        if (sc->ev0 == NULL) {
+            SRE_HIP_TRY(hipEventCreate(&sc->ev0));
+            SRE_HIP_TRY(hipEventCreate(&sc->ev1));
+        }
+        /* set pass, chain check, and (Pike) the exact VM over each stream's window */
+        SRE_HIP_TRY(hipEventRecord(sc->ev0, stream));
+        SRE_HIP_TRY(sre_launch_nfa_scan(sc->mode, sc->ntab, sc->geom, sc->d_nsum, NULL, NULL, NULL, stream));
+        SRE_HIP_TRY(hipEventRecord(sc->ev1, stream));
+        sc->ev_valid = 1;
+        if (nfa_finish(sc, NULL, stream) != 0) return -1;
     } else {
         if (scan_geometry(sc, nstreams) != 0) return -1;
         SRE_HIP_TRY(hipMemcpyAsync(sc->d_in, sc->h_in, (3 * nstreams + 1) * sizeof(uint64_t),
@@ -373,7 +516,7 @@ sre_hip_scan_enqueue(sre_hip_scanner_t *sc, const void *const *d_streams, const 
     /* records (and the scanner's status words behind them) in one copy */
     SRE_HIP_TRY(hipMemcpyAsync(sc->h_out, sc->d_out,
                                record_bytes(sc, nstreams)
-                                   + (sc->engine == SRE_HIP_ENGINE_SCAN ? nstreams * sizeof(sre_stream_status_t) : 0),
+                                   + (sc->engine != SRE_HIP_ENGINE_VM ? nstreams * sizeof(sre_stream_status_t) : 0),
                                hipMemcpyDeviceToHost, stream));
     if (sc->ev_done == NULL) SRE_HIP_TRY(hipEventCreateWithFlags(&sc->ev_done, hipEventDisableTiming));
     SRE_HIP_TRY(hipEventRecord(sc->ev_done, stream));
@@ -396,6 +539,38 @@ sre_hip_scan_results(sre_hip_scanner_t *sc, sre_int_t *results)
 
     /* everything enqueue() queued for this call, result copies included */
     SRE_HIP_TRY(hipEventSynchronize(sc->ev_done));
+    if (sc->engine == SRE_HIP_ENGINE_NFA) {
+        /* segments behind a wrong entry set are re-run: the first one from the
+         * exact carried set, the ones behind it from what their predecessor's lane
+         * ended in last round (sets only grow towards the truth, so corrections
+         * travel many segments per round) */
+        for (bool first = true;; first = false) {
+            if (!first) {
+                SRE_HIP_TRY(hipMemcpyAsync(sc->h_nstatus, sc->d_nstatus, n * sizeof(sre_nfa_status_t),
+                                           hipMemcpyDeviceToHost, stream));
+                SRE_HIP_TRY(hipStreamSynchronize(stream));
+            }
+            size_t pending = 0;
+            for (size_t i = 0; i < n; i++) {
+                if (sc->h_nstatus[i].done) {
+                    sc->h_lo[i] = -1;
+                } else {
+                    sc->h_lo[i] = sc->h_nstatus[i].first_bad;
+                    pending++;
+                }
+            }
+            if (pending == 0) break;
+            settled = false;
+            if (++sc->fixup_rounds > 1000000) {
+                fprintf(stderr, "[sregex-hip] NFA scanner fix-up did not converge\n");
+                return -1;
+            }
+            SRE_HIP_TRY(hipMemcpyAsync(sc->d_lo, sc->h_lo, n * sizeof(int64_t), hipMemcpyHostToDevice, stream));
+            SRE_HIP_TRY(sre_launch_nfa_scan(sc->mode, sc->ntab, sc->geom, sc->d_nsum, sc->d_lo, sc->d_belief,
+                                            sc->d_bvalid, stream));
+            if (nfa_finish(sc, sc->d_lo, stream) != 0) return -1;
+        }
+    }
     if (sc->engine == SRE_HIP_ENGINE_SCAN) {
         /* segments behind a broken state chain are re-run from the exact carried
          * state until every stream's verified prefix reaches its end */

@@ -1,0 +1,490 @@
+/*
+ * sre_hip_nfa.hip — the bit-parallel NFA scanner (gfx950): the throughput tier
+ * for programs whose ordered-list automaton is too large for the table-driven
+ * scanner (sre_hip_scan.hip) but whose list-able threads fit a 64-bit mask.
+ *
+ * Same data layout as the table-driven scanner: a stream is cut into segments,
+ * ONE LANE walks ONE SEGMENT, 64 bytes per round, staged through LDS in whole
+ * 128-byte lines (sre_hip_tile.h).  The lane's state is the SET of live threads
+ * as a bit mask (sre_nfa.h); per input byte
+ *      T = S & accept[byte];   S = OR_k follow[k][(T >> 8k) & 255]
+ * with both tables in LDS: NSLICE + 1 lookups and no classification pass (the
+ * accept table is indexed by the raw byte).  MATCH bits are sticky in the device
+ * tables (accepted by every byte, following to themselves), so the common round
+ * tests for an event once, after its 64 steps; a round with an event is replayed
+ * byte by byte from its entry set to find the exact step.
+ *
+ * Exactness: sets are exact for Thompson (sre_vm_thompson.c:88-258) and, for
+ * Pike, up to the first MATCH event (sre_vm_pike.c:535-553 cuts threads only
+ * then).  The lane reports the first event of its segment and a CLEAN position
+ * in front of it — one where only the ".*?" thread consumed the previous byte,
+ * so the list there is the freshly seeded initial closure and nothing else; the
+ * exact VM (sre_hip_vm.hip, sre_k_pike_window) then runs from that position.
+ * Entry sets are speculative (a 128-byte warm-up, which can only UNDER-estimate
+ * the true set: the step is monotone) and verified by the chain check below;
+ * nothing is reported from an unverified segment.
+ */
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <type_traits>
+#include "sre_hip_nfa.h"
+#include "sre_hip_tile.h"
+
+#define RC_DECLINED (-5)
+#define RC_ERROR    (-1)
+
+namespace {
+
+__device__ inline uint32_t
+nfa_stream_of(const sre_scan_geom_t &G, uint64_t g)
+{
+    uint32_t a = 0, b = G.nstreams;
+    while (b - a > 1) {
+        uint32_t m = (a + b) >> 1;
+        if (G.seg_first[m] <= g) a = m; else b = m;
+    }
+    return a;
+}
+
+/* ((v >> 8K) & 255) << sh in ONE instruction: the SDWA byte select feeds the
+ * shifter, so a table lookup by a byte of a mask costs one address op */
+template <int K>
+__device__ inline uint32_t
+byte_shl(uint32_t v, uint32_t sh)
+{
+    uint32_t r;
+    if (K == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(sh), "v"(v));
+    if (K == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(sh), "v"(v));
+    if (K == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(sh), "v"(v));
+    if (K == 3) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(sh), "v"(v));
+    return r;
+}
+
+/* OR of the follow-table entries selected by the bytes of t: slice K of the table
+ * at byte offset K * 256 * sizeof(M) behind `fol_base` (an LDS address) */
+template <typename M, int NSLICE, int K>
+struct FollowOr {
+    typedef const __attribute__((address_space(3))) M *lds_m_t;
+    static __device__ inline M get(M t, uint32_t fol_base, uint32_t sh)
+    {
+        const uint32_t word = K < 4 ? (uint32_t) t : (uint32_t) ((uint64_t) t >> 32);
+        const M        v = *(lds_m_t) (uintptr_t) (fol_base + K * 256 * (uint32_t) sizeof(M) + byte_shl<(K & 3)>(word, sh));
+        return v | FollowOr<M, NSLICE, K + 1>::get(t, fol_base, sh);
+    }
+};
+template <typename M, int NSLICE>
+struct FollowOr<M, NSLICE, NSLICE> {
+    static __device__ inline M get(M, uint32_t, uint32_t) { return 0; }
+};
+
+/*
+ * MODE 0: Thompson (events only); MODE 1: Pike first match (events + clean
+ * positions).  NSLICE = byte slices of the mask; masks are 32-bit up to 4
+ * slices, 64-bit above.
+ */
+template <int MODE, int NSLICE>
+__global__ __launch_bounds__(SRE_SCAN_BLOCK) void
+sre_k_nfa(sre_nfa_tables_t T, sre_scan_geom_t G, sre_nfa_summary_t *__restrict__ sum,
+          const int64_t *__restrict__ lo, const uint64_t *__restrict__ belief,
+          const uint8_t *__restrict__ bvalid)
+{
+    typedef typename std::conditional<(NSLICE <= 4), uint32_t, uint64_t>::type M;
+    typedef const __attribute__((address_space(3))) M *lds_m_t;
+    constexpr int      TILE = SRE_SCAN_ROUND;
+    constexpr int      WARM = SRE_SCAN_LINE;
+    constexpr uint32_t ROWRAW = TILE;               /* raw bytes per round */
+    constexpr uint32_t ROWB = 2 * ROWRAW + 16;      /* see tile_store */
+    /* static LDS: table addresses are compile-time constants and fold into the
+     * offset field of the lookups */
+    __shared__ __attribute__((aligned(16))) M acc_w[256];
+    __shared__ __attribute__((aligned(16))) M fol_w[NSLICE * 256];
+    __shared__ __attribute__((aligned(16))) uint8_t tile[SRE_SCAN_BLOCK * ROWB];
+    __shared__ RowDesc rows[SRE_SCAN_BLOCK];
+
+    const uint32_t tid = threadIdx.x;
+    const M  match = (M) T.match_bits, any = (M) T.any_bits;
+    /* sticky MATCH bits: see the file comment */
+    acc_w[tid] = (M) T.accept[tid] | match;
+#pragma unroll
+    for (int k = 0; k < NSLICE; k++) {
+        const M slice_match = (M) ((T.match_bits >> (8 * k)) & 0xffu) & (M) tid;
+        fol_w[k * 256 + tid] = (M) T.follow[k * 256 + tid] | (slice_match << (8 * k));
+    }
+    const uint32_t acc_base = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) M *) acc_w;
+    const uint32_t fol_base = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) M *) fol_w;
+    const uint32_t sh = sizeof(M) == 4 ? 2u : 3u;      /* log2 of a table entry, in a register for SDWA */
+
+    /* ---- which segment am I ---- */
+    const uint64_t g = (uint64_t) blockIdx.x * SRE_SCAN_BLOCK + tid;
+    bool           active = g < G.nsegs;
+    uint32_t       sidx = 0;
+    uint64_t       k = 0;
+    if (active) {
+        sidx = nfa_stream_of(G, g);
+        k = g - G.seg_first[sidx];
+        if (lo != nullptr && (lo[sidx] < 0 || (int64_t) k < lo[sidx])) active = false;
+    }
+
+    const uint8_t *data = nullptr;
+    int64_t        n = 0, seg_a = 0, seg_b = 0;
+    M              S = 0, s_in = 0;
+    bool           warm = false, finished = false;
+    int64_t        first_ev = -1, last_clean = -1;
+    int32_t        clean_mode = 0;
+    RowDesc        mine;
+    mine.addr = 0;
+    mine.lo = 0;
+    mine.hi16 = -1;
+    if (active) {
+        data = G.streams[sidx];
+        n = (int64_t) G.lens[sidx];
+        seg_a = (int64_t) k * G.seg_bytes;
+        seg_b = seg_a + G.seg_bytes;
+        if (seg_b > n) seg_b = n;
+        if (k == 0) {
+            S = (M) T.init[G.init_variant];
+            last_clean = 0;                     /* the search starts here */
+        } else if (lo != nullptr && ((int64_t) k == lo[sidx] || bvalid[g])) {
+            /* exact carry of the verified prefix, or (later segments of a fix-up
+             * round) what the previous round's lane in front of this one ended in */
+            S = (M) belief[g];
+        } else {
+            warm = true;
+            /* a search that is (re)started in the middle of a stream: ^ false */
+            S = (M) T.init[seg_a <= WARM ? G.init_variant : 2];
+        }
+        s_in = S;
+        mine.addr = (uint64_t) reinterpret_cast<uintptr_t>(data) + (uint64_t) (seg_a - WARM);
+        mine.lo = warm ? (seg_a >= WARM ? 0 : (int32_t) (WARM - seg_a)) : WARM;
+        mine.hi16 = (int32_t) (WARM + (seg_b - seg_a)) - 16;
+    }
+    rows[tid] = mine;
+
+    /*
+     * How the reference ARRIVES at a clean position q (the list there is the fresh
+     * initial closure): by an ordinary step, or as the target of its leading-byte
+     * skip (sre_vm_pike.c:256-309).  The two differ in one flag: a skip target is
+     * stepped without a new "is this the initial state" check and keeps
+     * seen_start_state set (:286-306 fall through to :312), which decides whether a
+     * later check can re-seed a search that already holds a match.  The skip fires
+     * at q - 1 iff the list there equals the snapshot taken at offset 0 (:266-273;
+     * the byte at q - 1 cannot start a match, or q would not be clean):
+     *   the SET in front of q - 1 differs from the snapshot's  -> an ordinary step (0)
+     *   it is equal and q - 1 is clean too (same list, fresh)   -> a skip target   (1)
+     *   equal as a set but not known to be the same list        -> unusable        (-1)
+     */
+    const M snap = (M) T.init[G.init_variant];
+    auto clean_kind = [&](M s_before, bool prev_clean) -> int {
+        if (s_before != snap) return 0;
+        return prev_clean ? 1 : -1;
+    };
+    /* one step on the byte selected from a word of the row: J = its byte index */
+    auto accept_of = [&](uint32_t word, int j) -> M {
+        const uint32_t a = (j & 3) == 0 ? byte_shl<0>(word, sh) : (j & 3) == 1 ? byte_shl<1>(word, sh)
+                         : (j & 3) == 2 ? byte_shl<2>(word, sh) : byte_shl<3>(word, sh);
+        return *(lds_m_t) (uintptr_t) (acc_base + a);
+    };
+    auto step = [&](M s, M a, M &t_out) -> M {
+        const M t = s & a;
+        t_out = t;
+        return FollowOr<M, NSLICE, 0>::get(t, fol_base, sh);
+    };
+
+    const uint32_t nrounds = WARM / TILE + G.seg_bytes / TILE;
+    const uint32_t lag = (tid >> 5) & 1u;
+    uint4          regs[4];
+    __syncthreads();                        /* tables and row descriptors are complete */
+    tile_fetch(regs, rows, tid, 0);
+    for (uint32_t s = 0; s <= nrounds; s++) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        tile_store<8>(regs, tile, nullptr, tid, s);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (s < nrounds) tile_fetch(regs, rows, tid, s + 1);
+
+        if (s < lag || s - lag >= nrounds) continue;
+        const uint32_t r = s - lag;
+        const bool     warm_round = (r < WARM / TILE);
+        if (!active || finished || (warm_round && !warm)) continue;
+        const int64_t base = seg_a - WARM + (int64_t) r * TILE;
+        if (base >= seg_b || base < 0) continue;
+
+        uint32_t roww[TILE / 4];
+        {
+            const uint8_t *src = tile + tid * ROWB + (r & 1u) * ROWRAW;
+#pragma unroll
+            for (int x = 0; x < TILE / 16; x++) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(src + 16 * x);
+                roww[4 * x] = v.x; roww[4 * x + 1] = v.y; roww[4 * x + 2] = v.z; roww[4 * x + 3] = v.w;
+            }
+        }
+        const M s0 = S;
+        if (base + TILE <= seg_b) {
+            /* the common round: 64 steps, then one look at the sticky MATCH bits */
+            int32_t clean_at = -1, clean_how = 0;
+            M       t14 = 0;
+#pragma unroll
+            for (int j = 0; j < TILE; j++) {
+                M       t;
+                const M s_before = S;
+                S = step(S, accept_of(roww[j >> 2], j), t);
+                if (MODE == 1 && (j & 15) == 14) t14 = t;
+                /* clean positions are sampled at the end of every 16-byte group */
+                if (MODE == 1 && (j & 15) == 15 && t <= any) {
+                    const int how = clean_kind(s_before, t14 <= any);
+                    if (how >= 0) {
+                        clean_at = j + 1;
+                        clean_how = how;
+                    }
+                }
+            }
+            if (!(S & match)) {
+                if (warm_round) {
+                    if (r + 1 == WARM / TILE) s_in = S;
+                } else if (MODE == 1 && clean_at >= 0) {
+                    last_clean = base + clean_at;
+                    clean_mode = clean_how;
+                }
+                continue;
+            }
+            if (warm_round) {
+                /* an event in front of the segment is somebody else's; drop the
+                 * sticky bits and go on */
+                S &= ~match;
+                if (r + 1 == WARM / TILE) s_in = S;
+                continue;
+            }
+            S = s0;
+        }
+        /* byte by byte: a round with an event, or the ragged end of the stream */
+        {
+            const int64_t end = base + TILE <= seg_b ? base + TILE : seg_b;
+            bool          prev_clean = (base == 0);     /* the list at offset 0 is the initial one */
+#pragma unroll 1
+            for (int64_t p = base; p < end; p++) {
+                M              t;
+                const M        s_before = S;
+                /* from memory, not from the tile: a 16-byte piece that crosses the end
+                 * of the stream is not staged (sre_hip_tile.h) */
+                const uint32_t b = data[p];
+                S = step(S, accept_of(b, 0), t);
+                if (S & match) {
+                    if (!warm_round) {
+                        first_ev = p;
+                        finished = true;
+                        break;
+                    }
+                    S &= ~match;
+                    prev_clean = false;
+                } else if (MODE == 1 && !warm_round && t <= any) {
+                    const int how = clean_kind(s_before, prev_clean);
+                    if (how >= 0) {
+                        last_clean = p + 1;
+                        clean_mode = how;
+                    }
+                    prev_clean = true;
+                } else {
+                    prev_clean = false;
+                }
+            }
+            if (warm_round && r + 1 == WARM / TILE) s_in = S;
+        }
+    }
+
+    if (!active) return;
+    sre_nfa_summary_t out;
+    out.s_in = (uint64_t) s_in;
+    out.s_out = (uint64_t) S;
+    out.first_ev = first_ev;
+    out.last_clean = last_clean < 0 ? -1 : last_clean * 2 + clean_mode;
+    sum[g] = out;
+}
+
+/* ===================================================================== verify */
+
+struct NfaAcc {
+    unsigned long long bad, end;        /* init ~0 */
+    unsigned long long clean;           /* init 0: 1 + latest clean position in the verified prefix */
+};
+
+__global__ __launch_bounds__(256) void
+sre_k_nfa_verify_a(sre_scan_geom_t G, const sre_nfa_summary_t *__restrict__ sum, NfaAcc *__restrict__ acc,
+                   uint64_t *__restrict__ belief, uint8_t *__restrict__ bvalid)
+{
+    const uint64_t g = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G.nsegs) return;
+    const uint32_t s = nfa_stream_of(G, g);
+    const uint64_t k = g - G.seg_first[s];
+    if (k > 0) {
+        const sre_nfa_summary_t &p = sum[g - 1];
+        /* behind a segment that ended the scan nothing is needed */
+        if (p.first_ev < 0 && sum[g].s_in != p.s_out) atomicMin(&acc[s].bad, (unsigned long long) k);
+        belief[g] = p.s_out;
+        bvalid[g] = p.first_ev < 0 ? 1 : 0;
+    } else {
+        bvalid[g] = 0;
+    }
+    if (sum[g].first_ev >= 0) atomicMin(&acc[s].end, (unsigned long long) k);
+}
+
+__global__ __launch_bounds__(256) void
+sre_k_nfa_verify_b(sre_scan_geom_t G, const sre_nfa_summary_t *__restrict__ sum, NfaAcc *__restrict__ acc)
+{
+    const uint64_t g = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= G.nsegs) return;
+    const uint32_t s = nfa_stream_of(G, g);
+    const uint64_t k = g - G.seg_first[s];
+    const uint64_t nseg = G.seg_first[s + 1] - G.seg_first[s];
+    uint64_t       bad = acc[s].bad, end = acc[s].end;
+    if (bad > nseg) bad = nseg;
+    if (end > nseg) end = nseg;
+    const uint64_t limit = end < bad ? end + 1 : bad;
+    if (k < limit && sum[g].last_clean >= 0) {
+        atomicMax(&acc[s].clean, (unsigned long long) sum[g].last_clean + 1);     /* position * 2 + mode */
+    }
+}
+
+/* per stream: the status word, and the record of every stream that needs no VM
+ * window (no event; Thompson) */
+__global__ void
+sre_k_nfa_verify_c(int mode, sre_scan_geom_t G, const sre_nfa_summary_t *__restrict__ sum,
+                   NfaAcc *__restrict__ accs, sre_nfa_status_t *__restrict__ status,
+                   int64_t *__restrict__ records, uint32_t ovec_slots, const int64_t *__restrict__ lo)
+{
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= G.nstreams) return;
+    /* take this stream's accumulator and leave it reset for the next pass */
+    const NfaAcc acc = accs[s];
+    accs[s].bad = accs[s].end = ~0ull;
+    accs[s].clean = 0;
+    if (lo != nullptr && lo[s] < 0) return;     /* settled in an earlier round */
+    const uint64_t first = G.seg_first[s], nseg = G.seg_first[s + 1] - first;
+    uint64_t       bad = acc.bad, end = acc.end;
+    if (bad > nseg) bad = nseg;
+    if (end > nseg) end = nseg;
+    sre_nfa_status_t st;
+    st.first_bad = (int64_t) bad;
+    st.done = ((end < bad) || (bad >= nseg)) ? 1 : 0;
+    st.ev_pos = (st.done && end < nseg) ? sum[first + end].first_ev : -1;
+    st.clean_pos = acc.clean ? (int64_t) ((acc.clean - 1) >> 1) : 0;
+    st.clean_mode = acc.clean ? (int32_t) ((acc.clean - 1) & 1) : 0;
+    status[s] = st;
+
+    int64_t *rec = records + (size_t) s * (2 + ovec_slots);
+    for (uint32_t q = 0; q < ovec_slots; q++) rec[2 + q] = -1;
+    if (!st.done) {
+        rec[0] = RC_ERROR;
+        rec[1] = 0;
+    } else if (st.ev_pos < 0) {
+        rec[0] = RC_DECLINED;
+        rec[1] = 0;
+    } else {
+        rec[0] = mode == 0 ? 0 : RC_ERROR;      /* Pike: the window kernel fills it in */
+        rec[1] = 1;
+    }
+}
+
+typedef void (*nfa_kernel_t)(sre_nfa_tables_t, sre_scan_geom_t, sre_nfa_summary_t *, const int64_t *,
+                             const uint64_t *, const uint8_t *);
+
+template <int MODE>
+nfa_kernel_t
+nfa_kernel_slices(uint32_t nslices)
+{
+    switch (nslices) {
+    case 1: return sre_k_nfa<MODE, 1>;
+    case 2: return sre_k_nfa<MODE, 2>;
+    case 3: return sre_k_nfa<MODE, 3>;
+    case 4: return sre_k_nfa<MODE, 4>;
+    case 5: case 6: return sre_k_nfa<MODE, 6>;
+    default: return sre_k_nfa<MODE, 8>;
+    }
+}
+
+/* the slice count a variant is compiled for */
+uint32_t
+nfa_round_slices(uint32_t nslices)
+{
+    return nslices <= 4 ? (nslices ? nslices : 1) : nslices <= 6 ? 6 : 8;
+}
+
+nfa_kernel_t
+nfa_kernel(int mode, uint32_t nslices)
+{
+    return mode == 0 ? nfa_kernel_slices<0>(nslices) : nfa_kernel_slices<1>(nslices);
+}
+
+}  // namespace
+
+extern "C" size_t
+sre_nfa_lds_bytes(uint32_t nslices)
+{
+    const uint32_t ns = nfa_round_slices(nslices);
+    const size_t   w = ns <= 4 ? 4 : 8;
+    /* all of it static: tables, tile, row descriptors */
+    return (size_t) (1 + ns) * 256 * w + (size_t) SRE_SCAN_BLOCK * (2 * SRE_SCAN_ROUND + 16)
+           + (size_t) SRE_SCAN_BLOCK * 16;
+}
+
+extern "C" const char *
+sre_nfa_kernel_name(int mode, uint32_t nslices, char *buf, size_t n)
+{
+    snprintf(buf, n, "sre_k_nfa<%d, %u>", mode == 0 ? 0 : 1, nfa_round_slices(nslices));
+    return buf;
+}
+
+extern "C" int
+sre_nfa_blocks_per_cu(int mode, uint32_t nslices)
+{
+    int        n = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, nfa_kernel(mode, nslices), SRE_SCAN_BLOCK, 0);
+    if (e != hipSuccess || n < 1) n = 1;
+    if (n > 8) n = 8;
+    return n;
+}
+
+extern "C" hipError_t
+sre_launch_nfa_scan(int mode, sre_nfa_tables_t tab, sre_scan_geom_t geom, sre_nfa_summary_t *d_sum,
+                    const int64_t *d_lo, const uint64_t *d_belief, const uint8_t *d_bvalid,
+                    hipStream_t stream)
+{
+    if (geom.nsegs == 0) return hipSuccess;
+    /* the compiled variant may have more slices than the program needs: the
+     * extra slices of the device tables are zero (sre_hip_batch.cpp pads them) */
+    const uint32_t grid = (uint32_t) ((geom.nsegs + SRE_SCAN_BLOCK - 1) / SRE_SCAN_BLOCK);
+    nfa_kernel_t   kern = nfa_kernel(mode, tab.nslices);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(SRE_SCAN_BLOCK), 0, stream, tab, geom, d_sum, d_lo,
+                       d_belief, d_bvalid);
+    return hipGetLastError();
+}
+
+extern "C" size_t
+sre_nfa_verify_acc_bytes(uint32_t nstreams)
+{
+    return (size_t) nstreams * sizeof(NfaAcc);
+}
+
+extern "C" hipError_t
+sre_nfa_verify_acc_init(void *d_acc, uint32_t nstreams, hipStream_t stream)
+{
+    hipError_t e = hipMemset2DAsync(d_acc, sizeof(NfaAcc), 0xff, 2 * sizeof(unsigned long long), nstreams, stream);
+    if (e != hipSuccess) return e;
+    return hipMemset2DAsync(static_cast<char *>(d_acc) + 2 * sizeof(unsigned long long), sizeof(NfaAcc), 0,
+                            sizeof(unsigned long long), nstreams, stream);
+}
+
+extern "C" hipError_t
+sre_launch_nfa_verify(int mode, sre_scan_geom_t geom, const sre_nfa_summary_t *d_sum, void *d_acc,
+                      sre_nfa_status_t *d_status, uint64_t *d_belief, uint8_t *d_bvalid,
+                      int64_t *d_records, uint32_t ovec_slots, const int64_t *d_lo, hipStream_t stream)
+{
+    if (geom.nstreams == 0) return hipSuccess;
+    NfaAcc        *acc = static_cast<NfaAcc *>(d_acc);
+    const uint32_t gseg = (uint32_t) ((geom.nsegs + 255) / 256);
+    hipLaunchKernelGGL(sre_k_nfa_verify_a, dim3(gseg), dim3(256), 0, stream, geom, d_sum, acc, d_belief, d_bvalid);
+    hipLaunchKernelGGL(sre_k_nfa_verify_b, dim3(gseg), dim3(256), 0, stream, geom, d_sum, acc);
+    hipLaunchKernelGGL(sre_k_nfa_verify_c, dim3((geom.nstreams + 63) / 64), dim3(64), 0, stream, mode, geom,
+                       d_sum, acc, d_status, d_records, ovec_slots, d_lo);
+    return hipGetLastError();
+}

@@ -30,6 +30,7 @@
 #define SRE_SCAN_MAX_STATES   55u     /* the fast table (1 KiB per state) must end below 64 KiB of LDS */
 #define SRE_SCAN_BLOCK        256u    /* lanes = segments per workgroup */
 #define SRE_SCAN_LDS_LIMIT    (128u * 1024u)  /* dynamic LDS a scan workgroup may ask for (160 KiB per CU) */
+#define SRE_CAPTURE_LDS_LIMIT  (144u * 1024u)  /* ... and the capture walker / lineage kernels (one workgroup per CU then) */
 #define SRE_SCAN_ROUND        64u     /* bytes a lane consumes per LDS round */
 #define SRE_SCAN_LINE         128u    /* staging granule: whole lines, half a wave per stage; also the warm-up */
 #define SRE_SCAN_SEG_ALIGN    256u    /* segments are a multiple of the line size */

@@ -28,9 +28,23 @@ __host__ __device__ sre_pike_layout_t sre_pike_layout(uint32_t len, uint32_t nth
     uint32_t nslots);
 __host__ __device__ sre_thompson_layout_t sre_thompson_layout(uint32_t len);
 
+/* per-stream window of the exact VM behind the NFA scanner: layout-identical to
+ * sre_nfa_status_t (sre_hip_nfa.h) */
+typedef struct {
+    int64_t first_bad;
+    int64_t ev_pos;         /* first MATCH event, -1 none: no window */
+    int64_t clean_pos;      /* the VM starts here */
+    int32_t done;
+    int32_t clean_mode;     /* 1: the reference reaches clean_pos as a leading-byte skip target */
+} sre_nfa_window_t;
+
 #ifdef __cplusplus
 extern "C" {
 #endif
+hipError_t sre_launch_pike_window(const void *blob, const void *const *d_streams,
+    const uint64_t *d_lens, uint32_t nstreams, void *d_ctx, uint64_t ctx_stride,
+    int64_t *d_records, uint32_t ovec_slots, const sre_nfa_window_t *d_win, const int64_t *d_lo,
+    hipStream_t stream);
 hipError_t sre_launch_pike_exec(const void *blob, const sre_dev_req_t *d_reqs,
     uint32_t nreqs, hipStream_t stream);
 hipError_t sre_launch_thompson_exec(const void *blob, const sre_dev_req_t *d_reqs,

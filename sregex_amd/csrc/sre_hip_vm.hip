@@ -381,9 +381,19 @@ struct Pike {
         ov[1] = a1;
     }
 
+    /* `start` > 0 (fresh contexts only): the search is picked up at offset `start`
+     * of the buffer, where the list is known to be the freshly seeded initial
+     * closure and nothing else (a CLEAN position found by the NFA scanner,
+     * sre_hip_nfa.hip).  The list the reference holds there is closure(0) at that
+     * offset; its initial-state snapshot (:218-229) is still the one taken at
+     * offset 0.  start_is_skip_target: the reference is, at `start`, inside a
+     * leading-byte skip that began in front of it (:256-309): it re-seeds at the
+     * next byte that can start a match and steps that byte WITHOUT another
+     * initial-state check, seen_start_state still set. */
     __device__ int64_t exec(uint64_t size, unsigned eof, bool want_pending,
                             sre_dev_result_t *res, int64_t *ov, uint64_t ovec_slots,
-                            const sre_dev_req_t *preset = nullptr)
+                            const sre_dev_req_t *preset = nullptr, int64_t start = 0,
+                            bool start_is_skip_target = false)
     {
         const bool fresh = (h->magic != PIKE_MAGIC);
         if (fresh) {
@@ -417,6 +427,7 @@ struct Pike {
         int     cl = (int) h->cur, nl = cl ^ 1;
         int64_t sp = 0, last = (int64_t) size;
         bool    has_matched = h->has_matched != 0;
+        bool    no_check_once = false, skip_ran_out = false;
 
         h->last_matched_pos = -1;
         if (h->empty_capture) {                                    /* :179-196 */
@@ -443,12 +454,26 @@ struct Pike {
             for (int32_t i = h->head[cl]; i >= 0 && node(cl, i)->next >= 0; i = node(cl, i)->next) {
                 initial[k++] = node(cl, i)->pc;
             }
+            if (start > sp) {
+                /* pick the search up at a clean position */
+                sp = start;
+                if (P.h->nleading && start_is_skip_target) {
+                    sp = find_first_byte(sp, last);
+                    no_check_once = true;
+                    if (sp == last) skip_ran_out = true;            /* :304-306 */
+                }
+                h->tag++;
+                list_reset(cl);
+                closure(cl, h->head[cl], h->tail[cl], 0, sp, false);
+            }
         }
 
-        for (; sp < last || (eof && sp == last); sp++) {           /* :235 */
+        for (; !skip_ran_out && (sp < last || (eof && sp == last)); sp++) {   /* :235 */
             if (h->head[cl] < 0) break;
 
-            if (P.h->nleading && h->seen_start_state) {            /* :256-309 */
+            if (no_check_once) {
+                no_check_once = false;
+            } else if (P.h->nleading && h->seen_start_state) {     /* :256-309 */
                 h->seen_start_state = 0;
                 bool same = (sp != last) && (h->count[cl] == h->initial_count);
                 uint32_t k = 0;
@@ -840,6 +865,63 @@ sre_k_pike_scan(const uint8_t *__restrict__ blob, const uint8_t *const *__restri
      * (sre_vm_pike.c:660-666 writes nothing) */
     rec[0] = (rc == RC_ERROR) ? rc : (count > 0 ? last_rc : rc);
     rec[1] = count;
+}
+
+/*
+ * The exact Pike VM over a WINDOW of each stream: from the clean position the
+ * bit-parallel NFA scanner found in front of the stream's first MATCH event
+ * (sre_hip_nfa.hip) to the end of the search.  Streams without an event, or not
+ * yet verified, already have their record.
+ */
+extern "C" __global__ void
+sre_k_pike_window(const uint8_t *__restrict__ blob, const uint8_t *const *__restrict__ streams,
+                  const uint64_t *__restrict__ lens, uint32_t nstreams, uint8_t *ctx_base,
+                  uint64_t ctx_stride, int64_t *__restrict__ records, uint32_t ovec_slots,
+                  const sre_nfa_window_t *__restrict__ win, const int64_t *__restrict__ lo)
+{
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nstreams) return;
+    if (lo != nullptr && lo[i] < 0) return;     /* settled in an earlier round */
+    if (!win[i].done || win[i].ev_pos < 0) return;
+
+    Pike vm;
+    vm.P = prog_view(blob);
+    const sre_pike_layout_t L = sre_pike_layout(vm.P.h->len, vm.P.h->nthreads, vm.P.h->nslots);
+    uint8_t *base = ctx_base + (size_t) i * ctx_stride;
+    vm.h = reinterpret_cast<PikeHdr *>(base);
+    vm.tags = reinterpret_cast<uint32_t *>(base + L.tags);
+    vm.initial = reinterpret_cast<uint32_t *>(base + L.initial);
+    vm.nodes[0] = base + L.nodes[0];
+    vm.nodes[1] = base + L.nodes[1];
+    vm.matched = reinterpret_cast<int64_t *>(base + L.matched);
+    vm.work = reinterpret_cast<int64_t *>(base + L.work);
+    vm.stack = reinterpret_cast<StackRec *>(base + L.stack);
+    vm.node_bytes = L.node_bytes;
+    vm.nslots = vm.P.h->nslots;
+    vm.in.inl = 0;
+    vm.in.p = streams[i];       /* the context is zero-filled (fresh) by the caller */
+
+    int64_t         *rec = records + (size_t) i * (2 + ovec_slots);
+    sre_dev_result_t res;
+    for (uint32_t k = 0; k < ovec_slots; k++) rec[2 + k] = -1;
+    const int64_t rc = vm.exec(lens[i], 1u, false, &res, rec + 2, ovec_slots, nullptr, win[i].clean_pos,
+                               win[i].clean_mode != 0);
+    rec[0] = rc;
+    rec[1] = rc >= 0 ? 1 : 0;
+}
+
+extern "C" hipError_t
+sre_launch_pike_window(const void *blob, const void *const *d_streams, const uint64_t *d_lens,
+                       uint32_t nstreams, void *d_ctx, uint64_t ctx_stride, int64_t *d_records,
+                       uint32_t ovec_slots, const sre_nfa_window_t *d_win, const int64_t *d_lo,
+                       hipStream_t stream)
+{
+    uint32_t block = 64, grid = (nstreams + block - 1) / block;
+    hipLaunchKernelGGL(sre_k_pike_window, dim3(grid), dim3(block), 0, stream,
+                       static_cast<const uint8_t *>(blob),
+                       reinterpret_cast<const uint8_t *const *>(d_streams), d_lens, nstreams,
+                       static_cast<uint8_t *>(d_ctx), ctx_stride, d_records, ovec_slots, d_win, d_lo);
+    return hipGetLastError();
 }
 
 extern "C" __global__ void

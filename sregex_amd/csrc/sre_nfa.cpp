@@ -1,0 +1,198 @@
+/*
+ * sre_nfa.cpp — builds the bit-parallel form described in sre_nfa.h.
+ *
+ * The closure mirrors sre_vm_pike.c:756-942 / sre_vm_thompson.c:273-345 on sets:
+ * JMP and SPLIT are followed, SAVE is skipped, ^ and \A are decided from the
+ * byte just consumed, every list-able instruction reached becomes a member.
+ * (The Pike SPLIT re-descent, :774-784, changes the ORDER in which members are
+ * listed, never the set.)
+ */
+#include "sre_nfa.h"
+#include <string.h>
+#include <set>
+
+namespace {
+
+struct NfaBuilder {
+    const sre_program_t *prog;
+
+    bool consumes(const sre_insn_t &in, unsigned c) const
+    {
+        switch (in.opcode) {
+        case SRE_OP_CHAR:  return c == in.ch;
+        case SRE_OP_ANY:   return true;
+        case SRE_OP_IN:    return sre_in_ranges(&prog->ranges[in.x], in.nranges, c) != 0;
+        case SRE_OP_NOTIN: return sre_in_ranges(&prog->ranges[in.x], in.nranges, c) == 0;
+        default:           return false;
+        }
+    }
+
+    /* list-able instructions reachable from pc0 through epsilon edges */
+    void closure(uint32_t pc0, bool a_ok, bool caret_ok, std::set<uint32_t> &out) const
+    {
+        std::vector<uint32_t> stack(1, pc0);
+        std::vector<uint8_t>  seen(prog->len + 1, 0);
+        while (!stack.empty()) {
+            uint32_t pc = stack.back();
+            stack.pop_back();
+            while (pc < prog->len && !seen[pc]) {
+                seen[pc] = 1;
+                const sre_insn_t &in = prog->insns[pc];
+                if (in.opcode == SRE_OP_JMP) {
+                    pc = in.x;
+                } else if (in.opcode == SRE_OP_SPLIT) {
+                    stack.push_back(in.y);
+                    pc = in.x;
+                } else if (in.opcode == SRE_OP_SAVE) {
+                    pc++;
+                } else if (in.opcode == SRE_OP_ASSERT) {
+                    /* only \A and ^ get here (look-ahead programs are declined) */
+                    if (!(in.ch == SRE_ASSERT_BIG_A ? a_ok : caret_ok)) break;
+                    pc++;
+                } else {
+                    out.insert(pc);
+                    break;
+                }
+            }
+        }
+    }
+};
+
+}  // namespace
+
+extern "C" void
+sre_nfa_free(sre_nfa_t *nfa)
+{
+    delete nfa;
+}
+
+extern "C" sre_nfa_t *
+sre_nfa_build(const sre_program_t *prog, const char **why)
+{
+    static const char *dummy;
+    if (why == NULL) why = &dummy;
+    *why = NULL;
+    if (prog->lookahead_asserts) {
+        *why = "look-ahead assertions ($ \\z \\b \\B) have no bit-parallel form here";
+        return NULL;
+    }
+    if (prog->nthreads > SRE_NFA_MAX_BITS || prog->len > 4096) {
+        *why = "more than 64 list-able threads";
+        return NULL;
+    }
+    NfaBuilder b;
+    b.prog = prog;
+
+    /* pc-level follow sets, without and with ^ true */
+    std::vector<std::set<uint32_t>> fol[2];
+    fol[0].resize(prog->len);
+    fol[1].resize(prog->len);
+    std::vector<uint32_t> listable;
+    for (uint32_t pc = 0; pc < prog->len; pc++) {
+        const sre_insn_t &in = prog->insns[pc];
+        switch (in.opcode) {
+        case SRE_OP_CHAR: case SRE_OP_IN: case SRE_OP_NOTIN: case SRE_OP_ANY:
+            b.closure(pc + 1, false, false, fol[0][pc]);
+            b.closure(pc + 1, false, true, fol[1][pc]);
+            listable.push_back(pc);
+            break;
+        case SRE_OP_MATCH:
+            listable.push_back(pc);
+            break;
+        default:
+            break;
+        }
+    }
+
+    /* bit numbering: pc 1 (the ".*?" ANY thread) first, then program order; a
+     * thread that can consume '\n' and whose closure differs with ^ true gets a
+     * twin bit right behind its own */
+    sre_nfa_t *n = new sre_nfa_t();
+    std::vector<int> bit_of(prog->len, -1), twin_of(prog->len, -1);
+    auto needs_twin = [&](uint32_t pc) {
+        const sre_insn_t &in = prog->insns[pc];
+        if (in.opcode == SRE_OP_MATCH || !b.consumes(in, '\n') || fol[0][pc] == fol[1][pc]) return false;
+        for (unsigned c = 0; c < 256; c++) {
+            if (c != '\n' && b.consumes(in, c)) return true;
+        }
+        return false;       /* consumes nothing but '\n': ^ is always true behind it */
+    };
+    auto assign = [&](uint32_t pc) {
+        if (bit_of[pc] >= 0) return;
+        bit_of[pc] = (int) n->bit_pc.size();
+        n->bit_pc.push_back(pc);
+        if (needs_twin(pc)) {
+            twin_of[pc] = (int) n->bit_pc.size();
+            n->bit_pc.push_back(pc);
+        }
+    };
+    if (prog->len > 1 && prog->insns[1].opcode == SRE_OP_ANY) assign(1);
+    for (uint32_t pc : listable) assign(pc);
+    n->nbits = (uint32_t) n->bit_pc.size();
+    if (n->nbits > SRE_NFA_MAX_BITS) {
+        *why = "more than 64 thread bits (threads plus their newline twins)";
+        delete n;
+        return NULL;
+    }
+    n->nslices = (n->nbits + 7) / 8;
+
+    auto mask_of = [&](const std::set<uint32_t> &pcs) {
+        uint64_t m = 0;
+        for (uint32_t pc : pcs) {
+            m |= 1ull << bit_of[pc];
+            if (twin_of[pc] >= 0) m |= 1ull << twin_of[pc];
+        }
+        return m;
+    };
+
+    n->any_bits = 0;
+    if (bit_of.size() > 1 && bit_of[1] >= 0) {
+        n->any_bits = 1ull << bit_of[1];
+        if (twin_of[1] >= 0) n->any_bits |= 1ull << twin_of[1];
+    }
+    n->match_bits = 0;
+    memset(n->accept, 0, sizeof(n->accept));
+    std::vector<uint64_t> fbit(n->nbits, 0);        /* follow mask per bit */
+    for (uint32_t pc : listable) {
+        const sre_insn_t &in = prog->insns[pc];
+        if (in.opcode == SRE_OP_MATCH) {
+            n->match_bits |= 1ull << bit_of[pc];
+            continue;
+        }
+        for (unsigned c = 0; c < 256; c++) {
+            if (!b.consumes(in, c)) continue;
+            if (twin_of[pc] >= 0 && c == '\n') n->accept[c] |= 1ull << twin_of[pc];
+            else n->accept[c] |= 1ull << bit_of[pc];
+        }
+        /* a thread that consumes nothing but '\n' always sees ^ true behind it */
+        bool only_nl = b.consumes(in, '\n');
+        for (unsigned c = 0; only_nl && c < 256; c++) {
+            if (c != '\n' && b.consumes(in, c)) only_nl = false;
+        }
+        fbit[bit_of[pc]] = mask_of(fol[only_nl ? 1 : 0][pc]);
+        if (twin_of[pc] >= 0) fbit[twin_of[pc]] = mask_of(fol[1][pc]);
+    }
+
+    for (int v = 0; v < 3; v++) {
+        std::set<uint32_t> s;
+        b.closure(0, v == 0, v != 2, s);
+        n->init[v] = mask_of(s);
+    }
+    if (n->init[0] & n->match_bits) {
+        *why = "nullable regex: the first match event is at offset 0, nothing to skip";
+        delete n;
+        return NULL;
+    }
+
+    n->follow.assign((size_t) n->nslices * 256, 0);
+    for (uint32_t k = 0; k < n->nslices; k++) {
+        for (uint32_t v = 0; v < 256; v++) {
+            uint64_t m = 0;
+            for (uint32_t j = 0; j < 8 && 8 * k + j < n->nbits; j++) {
+                if ((v >> j) & 1) m |= fbit[8 * k + j];
+            }
+            n->follow[(size_t) k * 256 + v] = m;
+        }
+    }
+    return n;
+}

@@ -1,0 +1,66 @@
+/*
+ * sre_nfa.h — the BIT-PARALLEL form of a compiled program: every list-able
+ * instruction (CHAR / IN / NOTIN / ANY / MATCH) is one bit of a 64-bit mask, the
+ * accounting the reference's Thompson JIT uses for its 64-bit ADDED register
+ * (reference src/sregex/sre_vm_thompson_x64.dasc:81-130 test-and-set per thread,
+ * :264-290 thread numbering; sre_vm_thompson_jit.c:226-241 "<= 64 threads stay in
+ * a register").
+ *
+ * One step of the reference byte loop (sre_vm_pike.c:235-581,
+ * sre_vm_thompson.c:88-258) on SETS of threads is
+ *
+ *      T  = S & accept[byte]                    which listed threads consume it
+ *      S' = OR over i in T of follow[i]         their epsilon closures (:756-942)
+ *
+ * and `follow` is a union-homomorphism, so it is tabulated per byte slice of T:
+ * S' = OR_k slice[k][(T >> 8k) & 255].  This is exact for WHICH threads are
+ * listed; it carries no priority order.  It therefore decides Thompson
+ * (match / no match) exactly, and for Pike it is exact up to and including the
+ * first MATCH event — before any match has cut lower-priority threads
+ * (sre_vm_pike.c:535-553) the VM's list, as a set, is S.  The exact VM then runs
+ * only over the window from the last CLEAN position (the list consists of the
+ * freshly seeded initial closure only) to the end of the search.
+ *
+ * ^ holds iff the byte just consumed is a newline (sre_vm_pike.c:851-860): a
+ * thread whose closure contains ^ and which can consume '\n' gets a TWIN bit —
+ * the plain bit accepts every byte but '\n', the twin accepts '\n' only and
+ * carries the closure computed with ^ true — so the step needs no case split.
+ * \A never holds behind a consumed byte (:841-848); it only shapes the initial
+ * sets.  Look-ahead assertions ($ \z \b \B) are not admitted in this form.
+ */
+#ifndef SRE_NFA_H
+#define SRE_NFA_H
+
+#include "sre_program.h"
+
+#ifdef __cplusplus
+#include <vector>
+
+#define SRE_NFA_MAX_BITS 64u
+
+struct sre_nfa_s {
+    uint32_t nbits;             /* bits in use (<= 64) */
+    uint32_t nslices;           /* ceil(nbits / 8) */
+    uint64_t init[3];           /* SRE_DFA_INIT_* -> initial set */
+    uint64_t any_bits;          /* the ".*?" ANY thread (pc 1): bit 0, and bit 1 when it has a twin */
+    uint64_t match_bits;
+    uint64_t accept[256];
+    std::vector<uint64_t> follow;   /* [nslices][256] */
+    std::vector<uint32_t> bit_pc;   /* [nbits] */
+};
+typedef struct sre_nfa_s sre_nfa_t;
+
+extern "C" {
+#else
+typedef struct sre_nfa_s sre_nfa_t;
+#endif
+
+/* NULL + *why when the program has no bit-parallel form (more than 64 bits,
+ * look-ahead assertions, or a nullable regex: its first event is at offset 0) */
+sre_nfa_t *sre_nfa_build(const sre_program_t *prog, const char **why);
+void sre_nfa_free(sre_nfa_t *nfa);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

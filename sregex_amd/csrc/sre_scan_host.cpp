@@ -222,14 +222,19 @@ sre_scan_tables_build(const sre_program_t *prog, const sre_dfa_t *d, int mode, c
     {
         /* the scan kernel addresses its fast table (first in dynamic LDS, behind
          * at most 8.5 KiB of static LDS) with 16-bit LDS addresses and may ask
-         * for SRE_SCAN_LDS_LIMIT in all; the capture walker stays within the
-         * default 64 KiB.  Otherwise the exact VM engine takes the program. */
+         * for SRE_SCAN_LDS_LIMIT in all; the capture walker and the lineage kernel
+         * may take SRE_CAPTURE_LDS_LIMIT.  Otherwise the exact VM engine takes the
+         * program. */
         const size_t tr = ((size_t) d->nstates * nsym + 3) * sizeof(sre_dev_trans_t);
         const size_t scan_lds = sre_scan_lds_bytes(&h);
         const size_t fast_end = (size_t) h.fast_bytes + 4096 + 4096 + 512;
         const size_t cap_lds = (size_t) h.fast_bytes + 256 + tr + (size_t) h.lin_total * 9
                                + ((size_t) d->nstates + 1 + h.list_total) * 4 + 16 + 512;
-        if (scan_lds > SRE_SCAN_LDS_LIMIT || fast_end > 64 * 1024 || cap_lds > 64 * 1024) {
+        const size_t lin_lds = 256 + (size_t) d->nstates * nsym * sizeof(sre_dev_trans_t)
+                               + 2 * (size_t) ((h.lin_total + 15u) & ~15u) + 512;
+        if (scan_lds > SRE_SCAN_LDS_LIMIT || fast_end > 64 * 1024 || cap_lds > SRE_CAPTURE_LDS_LIMIT
+            || lin_lds > SRE_CAPTURE_LDS_LIMIT)
+        {
             *why = "automaton tables exceed the LDS budget of the scanner";
             delete t;
             return NULL;

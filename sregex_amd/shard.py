@@ -34,3 +34,17 @@ def allreduce_max(value, device=None):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def allgather_ints(value, device=None):
+    """One int64 per rank, gathered on every rank (which device ordinal each rank
+    drives: bench.py reports it so that a rehearsal with ranks sharing a GPU is
+    told apart from a scaling run)."""
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([int(value)], dtype=torch.int64, device=device or "cpu")
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        out = [torch.zeros_like(t) for _ in range(dist.get_world_size())]
+        dist.all_gather(out, t)
+        return [int(x.item()) for x in out]
+    return [int(value)]

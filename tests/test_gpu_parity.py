@@ -385,6 +385,167 @@ def test_full_size_streams_closed_form_properties(gpu):
     buf.free()
 
 
+def test_configs4_per_gpu_shape_128_streams_of_64MiB(gpu):
+    """BASELINE.json configs[4] as ONE GPU sees it: 128 independent 64 MiB streams
+    (stream g of the 1024 lives on rank g mod 8), tails alternating matching /
+    non-matching => 64 matches on this GPU.  Expected records are closed forms in
+    the stream length, first checked against the oracle on short streams with the
+    same tails; the same batch also runs through COUNT and Thompson."""
+    ora = harness.OracleEngine()
+    pats = [rb"[a-z]+@[a-z]+\.[a-z]+"]
+    tails = [b" a@abc.cc ", b"aaabbccb"]
+
+    def expect(L, tail, mode):
+        hit = b"@" in tail
+        if mode == S.HIP_THOMPSON:
+            return [0 if hit else S.SRE_DECLINED, 1 if hit else 0, -1, -1]
+        return [0, 1, L - 9, L - 1] if hit else [S.SRE_DECLINED, 0, -1, -1]
+
+    with S.Pool() as pool:
+        re = S.parse(pool, pats)
+        prog = S.compile(pool, re)
+        for tail in tails:                                  # the closed forms against the oracle
+            small = S.gen_data_host(30000, tail)
+            first, cnt = _expect(ora, prog, re.ncaps, small)
+            assert first == expect(len(small), tail, S.HIP_PIKE_FIRST)
+            assert cnt == expect(len(small), tail, S.HIP_PIKE_COUNT)
+        per, nstreams = 64 << 20, 128
+        lens = [S.gen_data_length(per, len(tails[g % 2])) for g in range(nstreams)]
+        bufs = [S.DeviceBuffer(per) for _ in range(nstreams)]
+        for g, b in enumerate(bufs):
+            t = tails[g % 2]
+            assert gpu.sre_hip_gen_data(b.ptr, lens[g], t, len(t), None) == 0
+        ptrs = [b.ptr for b in bufs]
+        for mode in (S.HIP_PIKE_FIRST, S.HIP_PIKE_COUNT, S.HIP_THOMPSON):
+            sc = S.Scanner(pool, prog, mode, S.ENGINE_SCAN)
+            recs = sc.scan(ptrs, lens)
+            assert sum(1 for r in recs if r[0] >= 0) == 64
+            for g, r in enumerate(recs):
+                assert r == expect(lens[g], tails[g % 2], mode), (mode, g, r)
+            assert sc.last_fixups == 0
+        for b in bufs:
+            b.free()
+
+
+# ------------------------------------------------------------ bit-parallel NFA tier
+
+NFA_ZOO = [
+    # ordered-list automata beyond the table-driven scanner's 55 states
+    [rb"(?:a|b)*a(?:a|b){7}@"], [rb"(a|b)*a(a|b){5}(c)"], [rb"[ab]{3,9}c{2}(x)?"], [rb"x.{0,10}y"],
+    [rb"(a|ab|abc){2,6}x"], [rb"(?:[^,]*,){3,}d"], [rb"a[^x]{20}x"], [rb"(\w+ ){3}(\w+)"],
+    [rb"^a.{3}b", rb"\nc{2,4}"], [rb"(?:a|b)*a(?:a|b){12}"],
+    # and ones it would take anyway: the tier must agree with everything else
+    [rb"[a-z]+@[a-z]+\.[a-z]+"], [rb"([a-z]+)://([^/ ]+)(/[^ ?]*)?(\?[^ ]*)?"], [rb"a?a?a?aaa"],
+    [rb"(a+)(b+)?"], [rb"(?:a.*b|a)"], [rb"\Aab|\n^b"], [rb"^b+"], [rb"(^|a)b"], [rb"(x+x+)+y"],
+    [b"a", b"ab", b"c", b"a(bc)", b"e(f)", b"gh", b"A", b"b", b"BLAH", rb"\s+", b"abcd", b"bc"],
+]
+
+
+@pytest.mark.parametrize("seg", [64, 192, 0])
+def test_nfa_tier_segments_vs_oracle(gpu, seg):
+    """The bit-parallel NFA tier (thread set as a mask per lane, exact VM over the
+    window from the last clean position), forced, against the oracle: first match
+    + captures and Thompson; small segments force speculative entry sets, the
+    chain check and fix-up rounds."""
+    import random
+    ora = harness.OracleEngine()
+    rng = random.Random(99 + seg)
+    alphabets = [b"abc", b"ab c\n.x@:/?y,d", b"aaaaab", b"ab"]
+    for pats in NFA_ZOO:
+        with S.Pool() as pool:
+            re = S.parse(pool, pats)
+            prog = S.compile(pool, re)
+            scs = {m: S.Scanner(pool, prog, m, S.ENGINE_NFA) for m in (S.HIP_THOMPSON, S.HIP_PIKE_FIRST)}
+            for sc in scs.values():
+                assert sc.engine == S.ENGINE_NFA
+                if seg:
+                    sc.set_segment_bytes(seg)
+            datas = []
+            for i in range(12):
+                alpha = alphabets[i % len(alphabets)]
+                n = rng.choice([0, 1, 63, 64, 65, 200, 1000, 3000, 20000])
+                datas.append(bytes(rng.choice(alpha) for _ in range(n)))
+            datas.append(S.gen_data_host(2000, b"@abc.cc "))
+            datas.append(S.gen_data_host(1500, b" abc://abc.cc/ab/c?a=b "))
+            datas.append(S.gen_data_host(70000, b" abbabaabab@ "))
+            datas.append(b"ab" * 30000 + b"a" + b"ba" * 6 + b"c")
+            bufs = [S.DeviceBuffer.from_bytes(d) for d in datas]
+            ptrs, lens = [b.ptr for b in bufs], [len(d) for d in datas]
+            got = {m: sc.scan(ptrs, lens) for m, sc in scs.items()}
+            for i, d in enumerate(datas):
+                first, _ = _expect(ora, prog, re.ncaps, d)
+                assert got[S.HIP_PIKE_FIRST][i] == first, (pats, seg, d[:60], len(d), got[S.HIP_PIKE_FIRST][i], first)
+                assert got[S.HIP_THOMPSON][i][:2] == [0 if first[0] >= 0 else S.SRE_DECLINED,
+                                                     1 if first[0] >= 0 else 0], (pats, seg, d[:60])
+            for b in bufs:
+                b.free()
+
+
+def test_nfa_tier_takes_what_the_step_automaton_declines(gpu, blocks):
+    """ENGINE_AUTO: every reference block whose ordered-list automaton is too large
+    for the table-driven scanner and whose program has a bit-parallel form runs
+    on the NFA tier — first match + captures and Thompson equal the reference
+    CLI's lines."""
+    bad, n, engines = [], 0, {S.ENGINE_VM: 0, S.ENGINE_SCAN: 0, S.ENGINE_NFA: 0}
+    for blk in blocks:
+        subject = bytes.fromhex(blk["s"])
+        for name, regexes, flags, multi, ref in harness.block_variants(blk):
+            if ref["rc"] != 0:
+                continue
+            with S.Pool() as pool:
+                prog = S.compile(pool, S.parse(pool, regexes, flags, multi))
+                sc = S.Scanner(pool, prog, S.HIP_PIKE_FIRST, S.ENGINE_AUTO)
+                engines[sc.engine] += 1
+                if sc.engine != S.ENGINE_NFA:
+                    continue
+                buf = S.DeviceBuffer.from_bytes(subject)
+                rec = sc.scan([buf.ptr], [len(subject)])[0]
+                th = S.Scanner(pool, prog, S.HIP_THOMPSON, S.ENGINE_AUTO).scan([buf.ptr], [len(subject)])[0]
+                buf.free()
+                nov = 2 * (ref["ncaps"] + 1)
+                line = ("pike match %d%s" % (rec[0], harness._fmt_caps(rec[2:], nov)) if rec[0] >= 0
+                        else "pike no match")
+                tl = "thompson " + ("match" if th[0] == 0 else "no match")
+                n += 1
+                if line != ref["res"][4] or tl != ref["res"][0]:
+                    bad.append((blk["file"], blk["name"], name, line, ref["res"][4], tl, ref["res"][0]))
+    print("engine admission over the reference runs (AUTO, first match):", engines)
+    assert not bad, (len(bad), bad[:5])
+    assert n > 30, (n, engines)
+    assert engines[S.ENGINE_VM] < 600, engines
+
+
+def test_nfa_tier_large_stream_closed_form(gpu):
+    """A program the step automaton declines (19 list-able threads, > 256 ordered
+    lists) over a 1 GiB gen-data stream: ENGINE_AUTO must pick the NFA tier; the
+    expected record is a closed form in the length, first checked against the
+    oracle on a short stream."""
+    ora = harness.OracleEngine()
+    pats, tail = [rb"(?:a|b)*a(?:a|b){7}@"], b" abbabaabab@ "
+    expect = lambda L: [0, 1, L - 12, L - 1]
+    with S.Pool() as pool:
+        re = S.parse(pool, pats)
+        prog = S.compile(pool, re)
+        small = S.gen_data_host(30000, tail)
+        first, _ = _expect(ora, prog, re.ncaps, small)
+        assert first == expect(len(small)), (first, expect(len(small)))
+        big = 1 << 30
+        L = S.gen_data_length(big, len(tail))
+        buf = S.DeviceBuffer(big)
+        assert gpu.sre_hip_gen_data(buf.ptr, L, tail, len(tail), None) == 0
+        for mode in (S.HIP_PIKE_FIRST, S.HIP_THOMPSON):
+            sc = S.Scanner(pool, prog, mode, S.ENGINE_AUTO)
+            assert sc.engine == S.ENGINE_NFA
+            rec = sc.scan([buf.ptr], [L])[0]
+            assert rec == (expect(L) if mode == S.HIP_PIKE_FIRST else [0, 1, -1, -1]), (mode, rec)
+            assert sc.last_fixups == 0
+        # no match anywhere: the whole stream is scanned
+        assert gpu.sre_hip_gen_data(buf.ptr, L, b"aaabbccb", 8, None) == 0
+        rec = S.Scanner(pool, prog, S.HIP_PIKE_FIRST, S.ENGINE_AUTO).scan([buf.ptr], [L])[0]
+        assert rec == [S.SRE_DECLINED, 0, -1, -1], rec
+        buf.free()
+
+
 # ------------------------------------------------------------ randomised differential
 
 @pytest.mark.parametrize("seg", [64, 0])
@@ -400,7 +561,7 @@ def test_scanner_random_patterns_vs_oracle(gpu, seg):
     rng = random.Random(int(os.environ.get("SRE_FUZZ_SEED", "20261004")) + seg)
     alphabet = b"abcx \n_."
     modes = (S.HIP_THOMPSON, S.HIP_PIKE_FIRST, S.HIP_PIKE_COUNT)
-    tested = admitted = 0
+    tested = admitted = nfa_admitted = 0
     bad = []
     for _ in range(600):
         nre = 1 if rng.random() < 0.8 else rng.randrange(2, 4)
@@ -420,6 +581,17 @@ def test_scanner_random_patterns_vs_oracle(gpu, seg):
                 if seg:
                     sc.set_segment_bytes(int(os.environ.get("SRE_FUZZ_SEG", seg)))
                 engines[("scan", mode)] = sc
+            for mode in (S.HIP_THOMPSON, S.HIP_PIKE_FIRST):
+                # the bit-parallel NFA tier, forced (it is chosen by itself only when the
+                # step automaton declines): set pass + exact VM window
+                try:
+                    sc = S.Scanner(pool, prog, mode, S.ENGINE_NFA)
+                except RuntimeError:
+                    continue
+                if seg:
+                    sc.set_segment_bytes(int(os.environ.get("SRE_FUZZ_SEG", seg)))
+                engines[("nfa", mode)] = sc
+                nfa_admitted += 1
             tested += 1
             admitted += 1 if engines else 0
             if seg == 0 and os.environ.get("SRE_FUZZ_VM", "1") != "0" and \
@@ -459,6 +631,7 @@ def test_scanner_random_patterns_vs_oracle(gpu, seg):
             for rec in bad:
                 f.write(json.dumps(rec) + "\n")
     assert admitted > 400, (tested, admitted)
+    assert nfa_admitted > 300, nfa_admitted
     assert not bad, (len(bad), [(b["engine"], b["mode"], bytes.fromhex(b["re"][0]), b["got"][:4], b["want"][:4])
                                for b in bad[:6]])
 
@@ -478,7 +651,7 @@ def test_recorded_fuzz_regressions(gpu):
             prog = S.compile(pool, re)
             first, cnt = _expect(ora, prog, re.ncaps, d)
             want = first if c["mode"] == S.HIP_PIKE_FIRST else cnt
-            sc = S.Scanner(pool, prog, c["mode"], S.ENGINE_VM if c["engine"] == "vm" else S.ENGINE_SCAN)
+            sc = S.Scanner(pool, prog, c["mode"], {"vm": S.ENGINE_VM, "nfa": S.ENGINE_NFA}.get(c["engine"], S.ENGINE_SCAN))
             if c["engine"] != "vm" and c["seg"]:
                 sc.set_segment_bytes(c["seg"])
             buf = S.DeviceBuffer.from_bytes(d)

@@ -8,6 +8,22 @@ import sys
 from collections import defaultdict
 
 
+def short(name):
+    """'void (anonymous namespace)::sre_k_scan<2, 4>(args...)' -> 'sre_k_scan<2, 4>'"""
+    name = name.replace("(anonymous namespace)::", "")
+    if name.startswith("void "):
+        name = name[5:]
+    depth = 0
+    for i, ch in enumerate(name):
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0:
+            return name[:i].strip()
+    return name.strip()
+
+
 def main():
     want = sys.argv[1]
     acc = defaultdict(lambda: defaultdict(list))
@@ -18,9 +34,9 @@ def main():
             for row in csv.DictReader(open(f)):
                 if want not in row["Kernel_Name"]:
                     continue
-                key = (row["Kernel_Name"].split("(")[0], row["Dispatch_Id"], row["Counter_Name"])
+                key = (short(row["Kernel_Name"]), row["Dispatch_Id"], row["Counter_Name"])
                 per[key] += float(row["Counter_Value"])
-                meta[row["Kernel_Name"].split("(")[0]] = {
+                meta[short(row["Kernel_Name"])] = {
                     "vgpr": int(row["VGPR_Count"]), "lds": int(row["LDS_Block_Size"]),
                     "scratch": int(row["Scratch_Size"]), "grid": int(row["Grid_Size"])}
             for (k, _, c), v in per.items():
