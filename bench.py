@@ -128,7 +128,7 @@ def workload_spec(name, S, nbytes, rank=0, world=1):
         elif name == "cfg1":
             pats, mode, text = [b"a?a?a?aaa"], S.HIP_THOMPSON, "configs[0] pattern a?a?a?aaa, Thompson"
         elif name == "nfa":
-            pats, tail = [NFA_PAT], b" abbabaabab@ "
+            pats, tail = [NFA_PAT], b" abaabaabab@ "
             text = "declined by the step automaton: /(?:a|b)*a(?:a|b){7}@/ Pike first-match, NFA tier"
         n = S.gen_data_length(nbytes, len(tail))
         lens, tails = [n], [tail]

@@ -48,3 +48,42 @@ def allgather_ints(value, device=None):
         dist.all_gather(out, t)
         return [int(x.item()) for x in out]
     return [int(value)]
+
+
+def allreduce_counter_vector(counters, device=None):
+    """The path's counter vector: uint64[1 + nregexes] =
+    [streams with a match, matches of regex 0, matches of regex 1, ...], summed over
+    all ranks with ONE all-reduce."""
+    return allreduce_counts(counters, device)
+
+
+def gather_stream_records(local_records, nstreams, rank, world, device=None):
+    """Per-stream results {rc, count, ovector...} of ALL streams on every rank, in
+    GLOBAL stream order (one all-gather of n_streams/G x record).
+
+    `local_records` are this rank's records in the order of shard_streams(nstreams,
+    rank, world); every record has the same number of int64 slots.  Ranks that own
+    one stream fewer are padded for the collective (all_gather wants equal shapes)
+    and the padding is dropped again."""
+    import torch
+    import torch.distributed as dist
+    per = (nstreams + world - 1) // world                 # records of the fullest rank
+    slots = len(local_records[0]) if local_records else 0
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        s = torch.tensor([slots], dtype=torch.int64, device=device or "cpu")
+        dist.all_reduce(s, op=dist.ReduceOp.MAX)          # a rank without streams learns the width
+        slots = int(s.item())
+    t = torch.zeros((per, max(slots, 1)), dtype=torch.int64, device=device or "cpu")
+    if local_records:
+        t[:len(local_records), :slots] = torch.tensor(local_records, dtype=torch.int64, device=t.device)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        parts = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(parts, t)
+    else:
+        parts = [t]
+    out = [None] * nstreams
+    for r in range(world):
+        rows = parts[r].tolist()
+        for i, g in enumerate(shard_streams(nstreams, r, world)):
+            out[g] = [int(x) for x in rows[i][:slots]]
+    return out
