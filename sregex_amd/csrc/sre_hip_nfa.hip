@@ -332,16 +332,29 @@ __global__ __launch_bounds__(256) void
 sre_k_nfa_verify_b(sre_scan_geom_t G, const sre_nfa_summary_t *__restrict__ sum, NfaAcc *__restrict__ acc)
 {
     const uint64_t g = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= G.nsegs) return;
-    const uint32_t s = nfa_stream_of(G, g);
-    const uint64_t k = g - G.seg_first[s];
-    const uint64_t nseg = G.seg_first[s + 1] - G.seg_first[s];
-    uint64_t       bad = acc[s].bad, end = acc[s].end;
-    if (bad > nseg) bad = nseg;
-    if (end > nseg) end = nseg;
-    const uint64_t limit = end < bad ? end + 1 : bad;
-    if (k < limit && sum[g].last_clean >= 0) {
-        atomicMax(&acc[s].clean, (unsigned long long) sum[g].last_clean + 1);     /* position * 2 + mode */
+    unsigned long long mine = 0;
+    uint32_t           s = 0;
+    if (g < G.nsegs) {
+        s = nfa_stream_of(G, g);
+        const uint64_t k = g - G.seg_first[s];
+        const uint64_t nseg = G.seg_first[s + 1] - G.seg_first[s];
+        uint64_t       bad = acc[s].bad, end = acc[s].end;
+        if (bad > nseg) bad = nseg;
+        if (end > nseg) end = nseg;
+        const uint64_t limit = end < bad ? end + 1 : bad;
+        if (k < limit && sum[g].last_clean >= 0) mine = (unsigned long long) sum[g].last_clean + 1;    /* position * 2 + mode */
+    }
+    /* one atomic per wave and stream (nearly every segment has a clean position) */
+    const uint32_t     s0 = __shfl(s, 0, 64);
+    unsigned long long red = (s == s0) ? mine : 0;
+    for (int d = 32; d >= 1; d >>= 1) {
+        const unsigned long long o = __shfl_down(red, d, 64);
+        red = o > red ? o : red;
+    }
+    if ((threadIdx.x & 63u) == 0) {
+        if (red) atomicMax(&acc[s0].clean, red);
+    } else if (s != s0 && mine) {
+        atomicMax(&acc[s].clean, mine);
     }
 }
 

@@ -25,9 +25,24 @@
 #define SRE_FAST_SLOW       1u
 #define SRE_FAST_CNT_SHIFT  1u
 #define SRE_FAST_CNT_MASK   0xfu
+/*   bit  5       STABLE (tables without COUNT's folded restarts only): the step returns to
+ *                the SAME state without an event, and every thread of the state's neutral
+ *                set (sre_scan_tables_t.neutral) descends from ITSELF without saving a
+ *                capture slot — a thread list "looping in place" (x+ over a run of x).
+ *                The capture walker jumps over stretches made of such steps only. */
+#define SRE_FAST_STABLE     32u
 #define SRE_FAST_ROW_BYTES  1024u
 
-#define SRE_SCAN_MAX_STATES   55u     /* the fast table (1 KiB per state) must end below 64 KiB of LDS */
+/* In LDS the fast table has extra rows behind the automaton's own: one TRAP row (every
+ * entry points back into it, flagged SLOW; SLOW entries of the other rows point there,
+ * so a chain of lookups needs no per-step flag test: the flag is still there at its
+ * end) and up to SRE_SCAN_MAX_SHADOWS SHADOW rows: a copy of a state's row whose
+ * STABLE entries point to the copy itself, everything else to the ordinary rows.  A
+ * lane that starts a stretch in a shadow row and is still in one at its end has seen
+ * STABLE steps only. */
+#define SRE_SCAN_MAX_SHADOWS  2u
+#define SRE_SCAN_MAX_STATES   54u     /* rows (states + trap + shadows, 1 KiB each) must end below 64 KiB of LDS */
+#define SRE_SCAN_MAX_ROWS     55u
 #define SRE_SCAN_BLOCK        256u    /* lanes = segments per workgroup */
 #define SRE_SCAN_LDS_LIMIT    (128u * 1024u)  /* dynamic LDS a scan workgroup may ask for (160 KiB per CU) */
 #define SRE_CAPTURE_LDS_LIMIT  (144u * 1024u)  /* ... and the capture walker / lineage kernels (one workgroup per CU then) */
@@ -62,6 +77,8 @@ typedef struct {
     const uint32_t        *fast_plain;  /* same without COUNT's folded restarts (== fast otherwise) */
     const uint8_t         *cls;         /* [256] */
     const sre_dev_trans_t *trans;       /* [nstates][ncls + 1], then 3 pseudo rows for the initial closures */
+    const uint16_t        *trans2;      /* [nstates][ncls + 1] next | kind << 8: all the scan kernel's exact path
+                                           needs of a transition (2 bytes instead of 40 in its LDS) */
     const uint8_t         *lin_parent;
     const uint64_t        *lin_saves;
     const uint64_t        *lin_early;   /* NULL unless the program has look-ahead assertions: slots a
@@ -73,7 +90,12 @@ typedef struct {
     const uint32_t        *list_off;    /* [nstates + 1] */
     const uint32_t        *list_pcs;
     const uint32_t        *multi_ncaps; /* [nregexes] */
-    uint32_t nregexes, pad3;
+    uint32_t nregexes;
+    uint32_t nshadow;                   /* shadow rows in the LDS fast table (FIRST / Thompson tables) */
+    uint32_t fast_rows, pad4;           /* rows of the scan kernel's LDS copy: nstates + 1 (trap) + nshadow */
+    uint8_t  shadow_state[SRE_SCAN_MAX_SHADOWS];    /* the state each of them copies */
+    const uint16_t        *neutral;     /* [nstates] bit j: thread j of the state's list descends from itself,
+                                           without a save, in every STABLE step of the state (0: none) */
 } sre_scan_tables_t;
 
 /* what one lane learnt about its segment */
@@ -100,6 +122,11 @@ typedef struct {
      * chain check compares this with the predecessor's pe_* as well. */
     int64_t  in_pe_pos;
     uint32_t in_pe_state, in_pe_sym;
+    /* FIRST: the byte steps [0, stable_until) of the segment, counted from its start, were
+     * STABLE steps of the entry state s_in, and so were the steps [stable_from, length) of
+     * the exit state s_out (whole 64-byte rounds; stable_until == length: the whole segment,
+     * flag SRE_SUM_STABLE). */
+    uint32_t stable_until, stable_from;
 } sre_seg_summary_t;
 
 #define SRE_SUM_PENDING   1u
@@ -107,6 +134,7 @@ typedef struct {
 #define SRE_SUM_LASTEV    4u
 #define SRE_SUM_ERROR     8u   /* COUNT: ... and the iteration ended with SRE_ERROR */
 #define SRE_SUM_IN_PENDING 16u /* COUNT: the lane entered its segment holding a pending match (in_pe_*) */
+#define SRE_SUM_STABLE    32u  /* every byte step of the segment was a STABLE step of s_in == s_out */
 
 /* COUNT: an empty match ended on the segment's last byte boundary, so the
  * caller's one-byte skip (sre_vm_pike.c:179-196) falls on the first byte of the
@@ -140,6 +168,8 @@ typedef struct {
     uint32_t valid_from;    /* set by sre_k_captures: first segment whose recorded entry state belongs
                                to the event's search (see Tracer::entry_state) */
     int64_t  ev_seg;        /* segment holding the event */
+    int64_t  unst_seg;      /* last segment in front of ev_seg that is not SRE_SUM_STABLE, -1 none:
+                               the segments between the two are stable, all in one state */
     int32_t  done;          /* 1: result final, 0: needs a fix-up round from first_bad */
     int32_t  error;         /* COUNT: the iteration ended with SRE_ERROR */
     int32_t  need_maps;     /* set by sre_k_captures: lineage too long for the plain walk */

@@ -200,13 +200,25 @@ restart_variant(const uint8_t *data, int64_t sp)
     return data[sp - 1] == '\n' ? 1u : 2u;
 }
 
+enum : uint32_t {
+    F_HAS_EV = 1u, F_LM_VALID = 2u, F_FINISHED = 4u, F_ERROR = 8u, F_UNRESOLVED = 16u, F_SKIP_NEXT = 32u,
+    F_IN_PENDING = 64u, F_SP_DIRTY = 128u,
+    F_SHADOW = 256u     /* FIRST: the lane is inside a stable stretch (in a shadow row of the fast table) */
+};
+
 /* the search a lane is currently following */
 struct Walk {
     const sre_scan_tables_t *T;
     const uint8_t           *data;      /* stream base */
+    const uint16_t          *tr2;       /* [nstates][ncls + 1] next state | event kind << 8 (LDS) */
     int64_t                  n;         /* stream length */
     uint32_t st;                        /* automaton state */
-    bool     has_ev;                    /* the search in flight holds a match */
+    /* per-lane booleans as bits of ONE register: kept as separate `bool`s each would
+     * live in a scalar register pair (a lane mask), and a dozen of them made the scan
+     * loop spill scalar registers (57 v_readlane / v_writelane per 64-byte round) */
+    uint32_t fl;
+    __device__ inline bool f(uint32_t b) const { return (fl & b) != 0; }
+    __device__ inline void set(uint32_t b, bool v) { fl = v ? (fl | b) : (fl & ~b); }
     uint8_t  ev_kind;
     uint32_t ev_state, ev_sym;
     int64_t  ev_pos, ev_sp;
@@ -215,28 +227,27 @@ struct Walk {
     int64_t  cur_sp;                    /* start of the search in flight, -1 unknown */
     int64_t  anchor_pos;                /* start of the tile round being processed and the */
     uint32_t anchor_state;              /* state there (set by the kernel), -1 none */
-    bool     lm_valid;                  /* FIRST: last event seen; COUNT: last completed match */
+    /* F_LM_VALID: FIRST: last event seen; COUNT: last completed match */
     uint32_t lm_state, lm_sym;
     int64_t  lm_pos, lm_sp, lm_apos;
     uint32_t lm_astate;
     int64_t  count;
     int64_t  term_pos;
-    bool     finished, error, unresolved;
-    bool     skip_next;                 /* COUNT: the next position to be processed is the byte the
-                                           caller skips after an empty match; it lies beyond the span
-                                           that was being processed when the match completed */
+    /* F_FINISHED, F_ERROR, F_UNRESOLVED; F_SKIP_NEXT: COUNT: the next position to be
+     * processed is the byte the caller skips after an empty match; it lies beyond the
+     * span that was being processed when the match completed */
 
     __device__ void complete_match()
     {
         count++;
-        lm_valid = true;
+        fl |= F_LM_VALID;
         lm_state = ev_state;
         lm_sym = ev_sym;
         lm_pos = ev_pos;
         lm_sp = ev_sp;
         lm_apos = ev_apos;
         lm_astate = ev_astate;
-        has_ev = false;
+        fl &= ~F_HAS_EV;
     }
 };
 
@@ -253,11 +264,11 @@ __device__ void slow_run(Walk &w, int64_t p, int64_t p_to, bool warm, uint32_t w
     const sre_scan_tables_t &T = *w.T;
     const uint32_t           nsym = T.ncls + 1;
 
-    if (MODE == SRE_HIP_PIKE_COUNT && w.skip_next) {
-        w.skip_next = false;
+    if (MODE == SRE_HIP_PIKE_COUNT && w.f(F_SKIP_NEXT)) {
+        w.fl &= ~F_SKIP_NEXT;
         p++;                        /* w.st is already the list of the search that starts behind it */
     }
-    while (p < p_to && !w.finished) {
+    while (p < p_to && !w.f(F_FINISHED)) {
         if (p == w.n && ((T.state_flags[w.st] >> 1) & 3) == 2) {
             /* the leading-byte skip ran to the end of input: the reference
              * leaves its loop without the EOF step and returns with threads
@@ -265,22 +276,24 @@ __device__ void slow_run(Walk &w, int64_t p, int64_t p_to, bool warm, uint32_t w
              * 616-622): a pending match is returned, the next exec fails */
             w.term_pos = p;
             if (MODE == SRE_HIP_PIKE_COUNT) {
-                if (w.has_ev) {
+                if (w.f(F_HAS_EV)) {
                     w.complete_match();
-                    w.error = true;
+                    w.fl |= F_ERROR;
                 }
-            } else if (w.has_ev || (T.state_flags[w.st] & 1)) {
+            } else if (w.f(F_HAS_EV) || (T.state_flags[w.st] & 1)) {
                 /* a speculative lane may not have seen the event itself; the
                  * state says that a match is pending */
-                w.error = true;
+                w.fl |= F_ERROR;
             }
-            w.finished = true;
+            w.fl |= F_FINISHED;
             return;
         }
         const uint32_t         sym = p < w.n ? T.cls[w.data[p]] : T.ncls;
-        const sre_dev_trans_t &tr = T.trans[(size_t) w.st * nsym + sym];
+        /* all the exact step needs of a transition: where it goes and what it reports */
+        const uint32_t tr2 = w.tr2[w.st * nsym + sym];
+        struct { uint32_t next; uint8_t kind; } tr = {tr2 & 0xffu, (uint8_t) (tr2 >> 8)};
         if (tr.kind) {
-            w.has_ev = true;
+            w.fl |= F_HAS_EV;
             w.ev_kind = tr.kind;
             w.ev_state = w.st;
             w.ev_sym = sym;
@@ -298,7 +311,7 @@ __device__ void slow_run(Walk &w, int64_t p, int64_t p_to, bool warm, uint32_t w
                 w.ev_astate = 0;
             }
             if (MODE != SRE_HIP_PIKE_COUNT && !warm) {
-                w.lm_valid = true;
+                w.fl |= F_LM_VALID;
                 w.lm_state = w.st;
                 w.lm_sym = sym;
                 w.lm_pos = p;
@@ -316,23 +329,23 @@ __device__ void slow_run(Walk &w, int64_t p, int64_t p_to, bool warm, uint32_t w
         /* the thread list died: this search is over */
         if (warm) {
             w.st = warm_seed;
-            w.has_ev = false;
+            w.fl &= ~F_HAS_EV;
             w.cur_sp = -1;
             p++;
             continue;
         }
         if (MODE != SRE_HIP_PIKE_COUNT) {
             w.term_pos = p;
-            w.finished = true;
+            w.fl |= F_FINISHED;
             return;
         }
-        if (!w.has_ev) {
+        if (!w.f(F_HAS_EV)) {
             /* no match: only possible at end of input => DECLINED ends the
              * iteration.  Earlier it means this lane assumed a matched-mode
              * state whose event it never saw: it cannot resolve the restart. */
-            if (p < w.n) w.unresolved = true;
+            if (p < w.n) w.fl |= F_UNRESOLVED;
             w.term_pos = p;
-            w.finished = true;
+            w.fl |= F_FINISHED;
             return;
         }
         {
@@ -345,7 +358,7 @@ __device__ void slow_run(Walk &w, int64_t p, int64_t p_to, bool warm, uint32_t w
             if (empty) {
                 if (e >= w.n) {
                     w.term_pos = p;
-                    w.finished = true;      /* size == 0 && eof => DECLINED */
+                    w.fl |= F_FINISHED;      /* size == 0 && eof => DECLINED */
                     return;
                 }
                 w.cur_sp = e + 1;
@@ -356,7 +369,7 @@ __device__ void slow_run(Walk &w, int64_t p, int64_t p_to, bool warm, uint32_t w
             p = w.cur_sp;
             /* an empty match that ended with a consumed byte can put the skipped
              * byte just outside this span */
-            if (p > p_to && p_to <= w.n) w.skip_next = true;
+            if (p > p_to && p_to <= w.n) w.fl |= F_SKIP_NEXT;
             w.anchor_pos = -1;      /* the round's entry state belonged to the previous search */
         }
     }
@@ -375,8 +388,8 @@ struct SpanResult {
 };
 
 __device__ __attribute__((noinline)) SpanResult
-resolve_fast_span(const sre_scan_tables_t *Tp, const uint8_t *data, int64_t gpos, uint32_t len,
-                  uint32_t s0, int64_t sp0)
+resolve_fast_span(const sre_scan_tables_t *Tp, const uint16_t *tr2, const uint8_t *data, int64_t gpos,
+                  uint32_t len, uint32_t s0, int64_t sp0)
 {
     const sre_scan_tables_t &T = *Tp;
     SpanResult r;
@@ -386,7 +399,8 @@ resolve_fast_span(const sre_scan_tables_t *Tp, const uint8_t *data, int64_t gpos
     r.last_state = r.last_sym = 0;
     for (uint32_t b = 0; b < len; b++) {
         const uint32_t         sym = T.cls[data[gpos + b]];
-        const sre_dev_trans_t &tr = T.trans[(size_t) st * (T.ncls + 1) + sym];
+        const uint32_t t2 = tr2[st * (T.ncls + 1) + sym];
+        struct { uint32_t next; uint8_t kind; } tr = {t2 & 0xffu, (uint8_t) (t2 >> 8)};
         if (tr.kind && tr.next == 0) {
             r.last_pos = gpos + b;
             r.last_state = st;
@@ -398,6 +412,41 @@ resolve_fast_span(const sre_scan_tables_t *Tp, const uint8_t *data, int64_t gpos
             st = tr.next;
         }
     }
+    return r;
+}
+
+/* (a & 0xffff) + ((b >> 16 H) & 0xffff) in ONE instruction (H == 2: + b): the SDWA
+ * operand selects feed the adder, so a table lookup costs one address op */
+template <int H>
+__device__ inline uint32_t
+add_w0_w(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    if (H == 0) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_0" : "=v"(r) : "v"(a), "v"(b));
+    if (H == 1) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1" : "=v"(r) : "v"(a), "v"(b));
+    if (H == 2) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+/* a + (b >> 24): the COUNT field of a fast-table entry */
+__device__ inline uint32_t
+add_b3(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+/* ((v >> 8K) & 255) << sh */
+template <int K>
+__device__ inline uint32_t
+byte_x4(uint32_t v, uint32_t sh)
+{
+    uint32_t r;
+    if (K == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(sh), "v"(v));
+    if (K == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(sh), "v"(v));
+    if (K == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(sh), "v"(v));
+    if (K == 3) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(sh), "v"(v));
     return r;
 }
 
@@ -428,41 +477,55 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
     __shared__ sre_scan_tables_t Ts;
 
     const uint32_t tid = threadIdx.x;
-    /* LDS: [fast table][class map 256][transition records][state flags][tile] */
+    /* LDS: [fast table: states, trap row, shadow rows][class map 256][transitions, 2 B each]
+     *      [state flags][tile] */
+    const uint32_t nst = tabp->nstates, nrows = tabp->fast_rows, nsh = tabp->nshadow;
     uint32_t *fast = reinterpret_cast<uint32_t *>(lds);
-    uint8_t  *clsl = lds + tabp->fast_bytes;
+    uint8_t  *clsl = lds + nrows * SRE_FAST_ROW_BYTES;
     uint8_t  *trl = clsl + 256;
-    const uint32_t tr_bytes = tabp->nstates * (tabp->ncls + 1) * (uint32_t) sizeof(sre_dev_trans_t);
+    const uint32_t tr_bytes = (nst * (tabp->ncls + 1) * 2u + 15u) & ~15u;      /* compact: 2 bytes a transition */
     uint8_t  *sfl = trl + tr_bytes;
-    uint8_t  *tile = lds + (((size_t) (sfl - lds) + tabp->nstates + 15u) & ~(size_t) 15u);
+    uint8_t  *tile = lds + (((size_t) (sfl - lds) + nst + 15u) & ~(size_t) 15u);
+    (void) nrows;
     if (tid == 0) {
         Ts = *tabp;
         /* the exact path reads its tables from LDS too */
         Ts.cls = clsl;
-        Ts.trans = reinterpret_cast<const sre_dev_trans_t *>(trl);
         Ts.state_flags = sfl;
     }
     /* In LDS an entry is [matches completed : 8][flags : 8][LDS byte address of the
      * next state's row : 16] (the fast table lies below 64 KiB): a lookup address
      * is then one add of two 16-bit fields and the match count one add of a byte
-     * field, both selected by the add instruction itself. */
+     * field, both selected by the add instruction itself.  SLOW entries point to
+     * the TRAP row, whose entries all point back to it with the flag set: a chain
+     * of lookups carries no per-step flag test, the flag is there at its end. */
     constexpr uint32_t LDS_SLOW = 1u << 16;
     constexpr uint32_t LDS_CNT_SHIFT = 24;
     const uint32_t fast_lds = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) uint8_t *) lds;
-    for (uint32_t i = tid; i < tabp->fast_bytes / 16; i += SRE_SCAN_BLOCK) {
+    const uint32_t trap_lds = fast_lds + nst * SRE_FAST_ROW_BYTES;
+    const uint32_t shadow_lds = trap_lds + SRE_FAST_ROW_BYTES;      /* first shadow row */
+    auto to_lds = [fast_lds, trap_lds](uint32_t g) -> uint32_t {
+        if (g & SRE_FAST_SLOW) return trap_lds | LDS_SLOW;
+        return (fast_lds + (g & ~(SRE_FAST_ROW_BYTES - 1)))
+               | (((g >> SRE_FAST_CNT_SHIFT) & SRE_FAST_CNT_MASK) << LDS_CNT_SHIFT);
+    };
+    for (uint32_t i = tid; i < nst * 64; i += SRE_SCAN_BLOCK) {
         uint4 e = reinterpret_cast<const uint4 *>(tabp->fast)[i];
-        auto to_lds = [fast_lds](uint32_t g) -> uint32_t {
-            return (fast_lds + (g & ~(SRE_FAST_ROW_BYTES - 1))) | ((g & SRE_FAST_SLOW) ? LDS_SLOW : 0u)
-                   | (((g >> SRE_FAST_CNT_SHIFT) & SRE_FAST_CNT_MASK) << LDS_CNT_SHIFT);
-        };
         e.x = to_lds(e.x);
         e.y = to_lds(e.y);
         e.z = to_lds(e.z);
         e.w = to_lds(e.w);
         reinterpret_cast<uint4 *>(fast)[i] = e;
     }
-    for (uint32_t i = tid; i < tr_bytes / 8; i += SRE_SCAN_BLOCK) {
-        reinterpret_cast<uint64_t *>(trl)[i] = reinterpret_cast<const uint64_t *>(tabp->trans)[i];
+    fast[nst * 256 + tid] = trap_lds | LDS_SLOW;
+    for (uint32_t q = 0; q < nsh; q++) {
+        /* shadow of state s: its STABLE entries stay in the copy, all others leave it */
+        const uint32_t s = tabp->shadow_state[q], addr = shadow_lds + q * SRE_FAST_ROW_BYTES;
+        const uint32_t gl = tabp->fast[s * 256 + tid];
+        fast[(nst + 1 + q) * 256 + tid] = (gl & SRE_FAST_STABLE) ? addr : to_lds(gl);
+    }
+    for (uint32_t i = tid; i < nst * (tabp->ncls + 1); i += SRE_SCAN_BLOCK) {
+        reinterpret_cast<uint16_t *>(trl)[i] = tabp->trans2[i];
     }
     for (uint32_t i = tid; i < tabp->nstates; i += SRE_SCAN_BLOCK) sfl[i] = tabp->state_flags[i];
     clsl[tid] = tabp->cls[tid];
@@ -491,10 +554,10 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
 
     Walk w;
     w.T = &T;
+    w.tr2 = reinterpret_cast<const uint16_t *>(trl);
     w.data = nullptr;
     w.n = 0;
     w.st = 0;
-    w.has_ev = false;
     w.ev_kind = 0;
     w.ev_state = w.ev_sym = 0;
     w.ev_pos = w.ev_sp = -1;
@@ -503,19 +566,16 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
     w.cur_sp = -1;
     w.anchor_pos = -1;
     w.anchor_state = 0;
-    w.lm_valid = false;
     w.lm_state = w.lm_sym = 0;
     w.lm_pos = w.lm_sp = w.lm_apos = -1;
     w.lm_astate = 0;
     w.count = 0;
     w.term_pos = -1;
-    w.finished = w.error = w.unresolved = false;
-    w.skip_next = false;
+    w.fl = 0;
 
     int64_t  seg_a = 0, seg_b = 0;
     uint32_t s_in = 0, seed = 0;
     /* COUNT: the pending match this lane enters its segment with (see sre_seg_summary_t) */
-    bool     in_pending = false;
     int64_t  in_pe_pos = -1;
     uint32_t in_pe_state = 0, in_pe_sym = 0;
     bool     last_seg = false, warm = false;
@@ -539,19 +599,19 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
             /* exact carry from the verified predecessor */
             const sre_seg_summary_t &c = sum[g - 1];
             w.st = c.s_out & ~SRE_STATE_SKIP;
-            w.skip_next = MODE == SRE_HIP_PIKE_COUNT && (c.s_out & SRE_STATE_SKIP) != 0;
+            w.set(F_SKIP_NEXT, MODE == SRE_HIP_PIKE_COUNT && (c.s_out & SRE_STATE_SKIP) != 0);
             w.cur_sp = c.cur_sp;
             if (c.flags & SRE_SUM_PENDING) {
-                w.has_ev = true;
+                w.fl |= F_HAS_EV;
                 w.ev_state = c.pe_state;
                 w.ev_sym = c.pe_sym;
                 w.ev_pos = c.pe_pos;
                 w.ev_sp = c.pe_sp;
                 w.ev_apos = c.pe_apos;
                 w.ev_astate = c.pe_astate;
-                w.ev_kind = T.trans[(size_t) c.pe_state * (T.ncls + 1) + c.pe_sym].kind;
+                w.ev_kind = (uint8_t) (w.tr2[c.pe_state * (T.ncls + 1) + c.pe_sym] >> 8);
                 if (MODE == SRE_HIP_PIKE_COUNT) {
-                    in_pending = true;
+                    w.fl |= F_IN_PENDING;
                     in_pe_pos = c.pe_pos;
                     in_pe_state = c.pe_state;
                     in_pe_sym = c.pe_sym;
@@ -577,20 +637,20 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
                          * believed by every lane behind it, and the chain check compares
                          * exactly that belief */
                         seed = cs;
-                        w.has_ev = true;
+                        w.fl |= F_HAS_EV;
                         w.ev_state = c.pe_state;
                         w.ev_sym = c.pe_sym;
                         w.ev_pos = c.pe_pos;
                         w.ev_sp = c.pe_sp;
                         w.ev_apos = -1;
                         w.ev_astate = 0;
-                        w.ev_kind = T.trans[(size_t) c.pe_state * (T.ncls + 1) + c.pe_sym].kind;
+                        w.ev_kind = (uint8_t) (w.tr2[c.pe_state * (T.ncls + 1) + c.pe_sym] >> 8);
                     }
                 }
             }
             w.st = seed;
         }
-        s_in = w.st | (MODE == SRE_HIP_PIKE_COUNT && w.skip_next ? SRE_STATE_SKIP : 0u);   /* what the chain check compares */
+        s_in = w.st | (MODE == SRE_HIP_PIKE_COUNT && w.f(F_SKIP_NEXT) ? SRE_STATE_SKIP : 0u);   /* what the chain check compares */
         /* row = [seg_a - WARM, seg_b): the warm-up rounds, then the segment */
         mine.addr = (uint64_t) reinterpret_cast<uintptr_t>(w.data) + (uint64_t) (seg_a - WARM);
         /* the warm-up of a stream's second segment may be cut short by the stream start */
@@ -604,12 +664,11 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
      * completed match */
     int64_t  fcA_pos = -1, fcB_pos = -1, fc_sp0 = -1;
     uint32_t fcA_len = 0, fcA_s0 = 0, fcB_len = 0, fcB_s0 = 0;
-    bool     sp_dirty = false;
     /* a pure-fast span [pos, pos + len), entered in state s0, completed cnt matches */
     auto note_span = [&](int64_t pos, uint32_t len, uint32_t s0, uint32_t cnt, bool warm_round) {
-        w.has_ev = false;                       /* superseded */
+        w.fl &= ~F_HAS_EV;                       /* superseded */
         if (warm_round) return;
-        if (sp_dirty) {
+        if (w.f(F_SP_DIRTY)) {
             fcA_pos = fcB_pos;
             fcA_len = fcB_len;
             fcA_s0 = fcB_s0;
@@ -620,17 +679,17 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
         fcB_pos = pos;
         fcB_len = len;
         fcB_s0 = s0;
-        sp_dirty = true;
+        w.fl |= F_SP_DIRTY;
         w.count += cnt;
     };
     /* make w.cur_sp exact again and record the last completed match (lm_*) */
     auto settle = [&]() {
-        if (MODE != SRE_HIP_PIKE_COUNT || !sp_dirty) return;
+        if (MODE != SRE_HIP_PIKE_COUNT || !w.f(F_SP_DIRTY)) return;
         int64_t sp0 = fc_sp0;
-        if (fcA_pos >= 0) sp0 = resolve_fast_span(&T, w.data, fcA_pos, fcA_len, fcA_s0, -1).sp;
-        const SpanResult r = resolve_fast_span(&T, w.data, fcB_pos, fcB_len, fcB_s0, sp0);
+        if (fcA_pos >= 0) sp0 = resolve_fast_span(&T, w.tr2, w.data, fcA_pos, fcA_len, fcA_s0, -1).sp;
+        const SpanResult r = resolve_fast_span(&T, w.tr2, w.data, fcB_pos, fcB_len, fcB_s0, sp0);
         if (r.last_pos >= 0) {
-            w.lm_valid = true;
+            w.fl |= F_LM_VALID;
             w.lm_pos = r.last_pos;
             w.lm_state = r.last_state;
             w.lm_sym = r.last_sym;
@@ -639,8 +698,20 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
             w.lm_astate = 0;
         }
         w.cur_sp = r.sp;
-        sp_dirty = false;
+        w.fl &= ~F_SP_DIRTY;
     };
+
+    /* FIRST: stable stretches (sre_seg_summary_t.stable_until / stable_from), as offsets
+     * from the segment start */
+    constexpr uint32_t SU_UNSET = 0xffffffffu;
+    uint32_t           su = SU_UNSET, run_off = 0;
+    /* the (at most two) shadowed states and their rows, in uniform registers: the round
+     * loop maps state <-> shadow row by comparison, not by another dependent LDS lookup */
+    static_assert(SRE_SCAN_MAX_SHADOWS == 2, "two shadow rows");
+    const uint32_t sh_st0 = nsh > 0 ? tabp->shadow_state[0] : 0xffffu, sh_st1 = nsh > 1 ? tabp->shadow_state[1] : 0xffffu;
+    const uint32_t sh_ad0 = shadow_lds, sh_ad1 = shadow_lds + SRE_FAST_ROW_BYTES;
+    const uint32_t     two = 2;                 /* shift amount of byte_x4, in a register for SDWA */
+    (void) two;
 
     const uint32_t nrounds = WARM / TILE + G.seg_bytes / TILE;
     const uint32_t lag = (tid >> 5) & 1u;
@@ -661,7 +732,7 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
         if (s < lag || s - lag >= nrounds) continue;
         const uint32_t r = s - lag;                     /* this lane's round */
         const bool     warm_round = (r < WARM / TILE);
-        if (!active || w.finished || (warm_round && !warm)) continue;
+        if (!active || w.f(F_FINISHED) || (warm_round && !warm)) continue;
         const int64_t base = seg_a - WARM + (int64_t) r * TILE;
         if (base >= seg_b || base < 0) continue;
         w.anchor_pos = warm_round ? -1 : base;
@@ -686,32 +757,56 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
                 roww[0] = *reinterpret_cast<const uint32_t *>(src);
             }
         }
-        /* index j of the round as a byte offset into a fast-table row */
-        auto sidx = [&](int j) -> uint32_t {
-            return WIDE ? (roww[j >> 1] >> ((j & 1) * 16)) & 0xffffu
-                        : ((roww[j >> 2] >> ((j & 3) * 8)) & 0xffu) << 2;
-        };
         /* the common round: every byte in range, no transition needs the exact
-         * path, (COUNT) no match completes — one straight chain of lookups */
-        if (base + TILE <= seg_b && !(MODE == SRE_HIP_PIKE_COUNT && w.skip_next)) {
-            uint32_t t = fast_lds + w.st * SRE_FAST_ROW_BYTES, acc = 0, cnt = 0;
+         * path, (COUNT) no match completes — one straight chain of lookups:
+         * address = low half of the entry + the round's next 16-bit index (one
+         * SDWA add), load, (COUNT) add the entry's count byte (one SDWA add) */
+        if (base + TILE <= seg_b && !(MODE == SRE_HIP_PIKE_COUNT && w.f(F_SKIP_NEXT))) {
+            uint32_t t = fast_lds + w.st * SRE_FAST_ROW_BYTES, cnt = 0;
+            if (MODE != SRE_HIP_PIKE_COUNT && !warm_round) {
+                /* a stable stretch starts (or goes on) in the state's shadow row */
+                const uint32_t sha = w.st == sh_st0 ? sh_ad0 : w.st == sh_st1 ? sh_ad1 : 0u;
+                if (!w.f(F_SHADOW)) {
+                    if (sha) {
+                        w.fl |= F_SHADOW;
+                        run_off = (uint32_t) (base - seg_a);
+                    } else if (su == SU_UNSET) {
+                        su = (uint32_t) (base - seg_a);
+                    }
+                }
+                if (w.f(F_SHADOW)) t = sha;
+            }
 #pragma unroll
             for (int j = 0; j < TILE * BITS / 8; j++) {
-                t = *(lds_u32_t) (uintptr_t) ((t & 0xffffu) + sidx(j));
-                acc |= t;
-                if (MODE == SRE_HIP_PIKE_COUNT) cnt += t >> LDS_CNT_SHIFT;
+                uint32_t a;
+                if (WIDE) {
+                    a = (j & 1) ? add_w0_w<1>(t, roww[j >> 1]) : add_w0_w<0>(t, roww[j >> 1]);
+                } else {
+                    const uint32_t wj = roww[j >> 2];
+                    const uint32_t ix = (j & 3) == 0 ? byte_x4<0>(wj, two) : (j & 3) == 1 ? byte_x4<1>(wj, two)
+                                      : (j & 3) == 2 ? byte_x4<2>(wj, two) : byte_x4<3>(wj, two);
+                    a = add_w0_w<2>(t, ix);
+                }
+                t = *(lds_u32_t) (uintptr_t) a;
+                if (MODE == SRE_HIP_PIKE_COUNT) cnt = add_b3(cnt, t);
             }
-            if (!(acc & LDS_SLOW)) {
+            if (!(t & LDS_SLOW)) {
                 /* matches completed in the round, each followed by a restart at
                  * the next byte, are only counted here (see note_span) */
                 if (MODE == SRE_HIP_PIKE_COUNT && cnt) note_span(base, TILE, w.st, cnt, warm_round);
-                w.st = ((t & 0xffffu) - fast_lds) / SRE_FAST_ROW_BYTES;
+                const uint32_t ridx = ((t & 0xffffu) - fast_lds) / SRE_FAST_ROW_BYTES;
+                w.st = MODE == SRE_HIP_PIKE_COUNT ? ridx : ridx <= nst ? ridx : ridx == nst + 1 ? sh_st0 : sh_st1;
+                if (MODE != SRE_HIP_PIKE_COUNT && w.f(F_SHADOW) && ridx <= nst) {
+                    /* left the shadow rows: the stable stretch ended in this round */
+                    w.fl &= ~F_SHADOW;
+                    if (su == SU_UNSET) su = (uint32_t) (base - seg_a);
+                }
                 if (r + 1 == WARM / TILE) {
                     s_in = w.st;
                     w.cur_sp = -1;
-                    if (w.st == 0) w.finished = true;
+                    if (w.st == 0) w.fl |= F_FINISHED;
                     if (MODE == SRE_HIP_PIKE_COUNT) {
-                        in_pending = w.has_ev;
+                        w.set(F_IN_PENDING, w.f(F_HAS_EV));
                         in_pe_pos = w.ev_pos;
                         in_pe_state = w.ev_state;
                         in_pe_sym = w.ev_sym;
@@ -720,15 +815,20 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
                 continue;
             }
         }
+        if (MODE != SRE_HIP_PIKE_COUNT && !warm_round) {
+            /* a round that takes the exact path ends any stable stretch */
+            w.fl &= ~F_SHADOW;
+            if (su == SU_UNSET) su = (uint32_t) (base - seg_a);
+        }
         /* otherwise group by group (16 bytes); a real loop, the indices of a
          * group re-read from the tile: this is the uncommon path and must not
          * weigh on the registers of the common one */
 #pragma unroll 1
         for (uint32_t q = 0; q < TILE / 16; q++) {
             const int64_t gp = base + q * 16;
-            if (gp >= seg_b || w.finished) break;
+            if (gp >= seg_b || w.f(F_FINISHED)) break;
             const int64_t g_end = gp + 16 <= seg_b ? gp + 16 : seg_b;   /* ragged tail of the stream */
-            bool          exact = (g_end != gp + 16) || (MODE == SRE_HIP_PIKE_COUNT && w.skip_next);
+            bool          exact = (g_end != gp + 16) || (MODE == SRE_HIP_PIKE_COUNT && w.f(F_SKIP_NEXT));
             uint32_t      t = fast_lds + w.st * SRE_FAST_ROW_BYTES, cnt = 0;
             if (!exact) {
                 constexpr int GW = GIDX * (WIDE ? 2 : 1) / 4;           /* dwords of indices per group */
@@ -736,32 +836,30 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
                 const uint32_t *gsrc = reinterpret_cast<const uint32_t *>(tile + tid * ROWB + (r & 1u) * ROWRAW) + q * GW;
 #pragma unroll
                 for (int x = 0; x < GW; x++) gw[x] = gsrc[x];
-                uint32_t acc = 0;
 #pragma unroll
                 for (int j = 0; j < GIDX; j++) {
                     const uint32_t ix = WIDE ? (gw[j >> 1] >> ((j & 1) * 16)) & 0xffffu
                                              : ((gw[j >> 2] >> ((j & 3) * 8)) & 0xffu) << 2;
                     t = *(lds_u32_t) (uintptr_t) ((t & 0xffffu) + ix);
-                    acc |= t;
                     if (MODE == SRE_HIP_PIKE_COUNT) cnt += t >> LDS_CNT_SHIFT;
                 }
-                exact = (acc & LDS_SLOW) != 0;
+                exact = (t & LDS_SLOW) != 0;        /* the trap row keeps the flag */
             }
             if (exact) {
                 settle();
                 slow_run<MODE>(w, gp, g_end, warm_round, seed);
             } else {
                 if (MODE == SRE_HIP_PIKE_COUNT && cnt) note_span(gp, 16, w.st, cnt, warm_round);
-                w.st = ((t & 0xffffu) - fast_lds) / SRE_FAST_ROW_BYTES;
+                w.st = ((t & 0xffffu) - fast_lds) / SRE_FAST_ROW_BYTES;     /* ordinary rows only on this path */
             }
         }
         if (r + 1 == WARM / TILE) {
             /* end of the warm-up: what this lane assumes about its entry */
             s_in = w.st;
             w.cur_sp = -1;                  /* search starts seen in the warm-up are not verified */
-            if (w.st == 0) w.finished = true;
+            if (w.st == 0) w.fl |= F_FINISHED;
             if (MODE == SRE_HIP_PIKE_COUNT) {
-                in_pending = w.has_ev;      /* ... nor is the pending match: the chain check compares it */
+                w.set(F_IN_PENDING, w.f(F_HAS_EV));      /* ... nor is the pending match: the chain check compares it */
                 in_pe_pos = w.ev_pos;
                 in_pe_state = w.ev_state;
                 in_pe_sym = w.ev_sym;
@@ -772,7 +870,7 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
     if (!active) return;
 
     /* the lane that owns the end of the stream performs the EOF step(s) */
-    if (last_seg && !w.finished) {
+    if (last_seg && !w.f(F_FINISHED)) {
         settle();
         w.anchor_pos = -1;
         slow_run<MODE>(w, w.n, w.n + 1, false, 0);
@@ -781,18 +879,25 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
     settle();
 
     sre_seg_summary_t out;
-    out.s_in = w.unresolved ? 0xffffffffu : s_in;
-    out.s_out = w.st | (MODE == SRE_HIP_PIKE_COUNT && w.skip_next ? SRE_STATE_SKIP : 0u);
+    {
+        const uint32_t seg_len = (uint32_t) (seg_b - seg_a);
+        if (MODE == SRE_HIP_PIKE_COUNT || (w.f(F_FINISHED) && su == SU_UNSET)) su = 0;
+        out.stable_until = su == SU_UNSET ? seg_len : su;
+        out.stable_from = (MODE != SRE_HIP_PIKE_COUNT && w.f(F_SHADOW)) ? run_off : seg_len;
+    }
+    out.s_in = w.f(F_UNRESOLVED) ? 0xffffffffu : s_in;
+    out.s_out = w.st | (MODE == SRE_HIP_PIKE_COUNT && w.f(F_SKIP_NEXT) ? SRE_STATE_SKIP : 0u);
     out.flags = 0;
     out.pad = 0;
     out.count = w.count;
     out.term_pos = w.term_pos;
     out.cur_sp = w.cur_sp;
-    if (w.finished && w.term_pos >= 0) out.flags |= SRE_SUM_TERM;
-    if (w.error) out.flags |= SRE_SUM_ERROR;
-    if (w.has_ev) out.flags |= SRE_SUM_PENDING;
-    if (w.lm_valid) out.flags |= SRE_SUM_LASTEV;
-    if (MODE == SRE_HIP_PIKE_COUNT && in_pending) out.flags |= SRE_SUM_IN_PENDING;
+    if (w.f(F_FINISHED) && w.term_pos >= 0) out.flags |= SRE_SUM_TERM;
+    if (w.f(F_ERROR)) out.flags |= SRE_SUM_ERROR;
+    if (w.f(F_HAS_EV)) out.flags |= SRE_SUM_PENDING;
+    if (w.f(F_LM_VALID)) out.flags |= SRE_SUM_LASTEV;
+    if (MODE == SRE_HIP_PIKE_COUNT && w.f(F_IN_PENDING)) out.flags |= SRE_SUM_IN_PENDING;
+    if (MODE != SRE_HIP_PIKE_COUNT && out.stable_until == G.seg_bytes && !last_seg) out.flags |= SRE_SUM_STABLE;
     out.in_pe_pos = in_pe_pos;
     out.in_pe_state = in_pe_state;
     out.in_pe_sym = in_pe_sym;
@@ -824,6 +929,7 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
 struct VerifyAcc {
     unsigned long long bad, end;        /* init ~0 */
     unsigned long long count, evseg, spseg;     /* init 0 */
+    unsigned long long unst;                    /* init 0: 1 + last segment in front of evseg that is not stable */
 };
 
 __global__ __launch_bounds__(256) void
@@ -867,6 +973,9 @@ sre_k_verify_b(sre_scan_geom_t G, const sre_seg_summary_t *__restrict__ sum, Ver
         sh_sp = 0;
     }
     __syncthreads();
+    /* whole block inside one stream (the usual case): reduce in the wave first — a
+     * shared-memory atomic per lane serialises 256 ways when every segment counts */
+    unsigned long long my_count = 0, my_ev = 0, my_sp = 0;
     if (g < G.nsegs) {
         const uint32_t s = uniform ? s_first : stream_of(G, g);
         const uint64_t k = g - G.seg_first[s];
@@ -878,17 +987,27 @@ sre_k_verify_b(sre_scan_geom_t G, const sre_seg_summary_t *__restrict__ sum, Ver
         if (k < limit) {
             const sre_seg_summary_t &c = sum[g];
             if (uniform) {
-                if (c.count) atomicAdd(&sh_count, (unsigned long long) c.count);
-                if (c.flags & SRE_SUM_LASTEV) atomicMax(&sh_ev, (unsigned long long) k + 1);
+                my_count = (unsigned long long) c.count;
+                if (c.flags & SRE_SUM_LASTEV) my_ev = (unsigned long long) k + 1;
+                if (c.cur_sp >= 0) my_sp = (unsigned long long) k + 1;     /* latest segment at whose end a search start is known */
             } else {
                 if (c.count) atomicAdd(&acc[s].count, (unsigned long long) c.count);
                 if (c.flags & SRE_SUM_LASTEV) atomicMax(&acc[s].evseg, (unsigned long long) k + 1);
+                if (c.cur_sp >= 0) atomicMax(&acc[s].spseg, (unsigned long long) k + 1);
             }
-            /* latest segment at whose end a search start is known */
-            if (c.cur_sp >= 0) {
-                if (uniform) atomicMax(&sh_sp, (unsigned long long) k + 1);
-                else atomicMax(&acc[s].spseg, (unsigned long long) k + 1);
-            }
+        }
+    }
+    if (uniform) {
+        for (int d = 32; d >= 1; d >>= 1) {
+            my_count += __shfl_down(my_count, d, 64);
+            const unsigned long long e2 = __shfl_down(my_ev, d, 64), s2 = __shfl_down(my_sp, d, 64);
+            my_ev = e2 > my_ev ? e2 : my_ev;
+            my_sp = s2 > my_sp ? s2 : my_sp;
+        }
+        if ((threadIdx.x & 63u) == 0) {
+            if (my_count) atomicAdd(&sh_count, my_count);
+            if (my_ev) atomicMax(&sh_ev, my_ev);
+            if (my_sp) atomicMax(&sh_sp, my_sp);
         }
     }
     __syncthreads();
@@ -896,6 +1015,36 @@ sre_k_verify_b(sre_scan_geom_t G, const sre_seg_summary_t *__restrict__ sum, Ver
         if (sh_count) atomicAdd(&acc[s_first].count, sh_count);
         if (sh_ev) atomicMax(&acc[s_first].evseg, sh_ev);
         if (sh_sp) atomicMax(&acc[s_first].spseg, sh_sp);
+    }
+}
+
+/* FIRST: the last segment in front of the event's that is not SRE_SUM_STABLE — between
+ * the two the automaton sat in one state whose neutral threads looped in place, and the
+ * capture walker crosses all of them in one jump */
+__global__ __launch_bounds__(256) void
+sre_k_verify_b2(sre_scan_geom_t G, const sre_seg_summary_t *__restrict__ sum, VerifyAcc *__restrict__ acc)
+{
+    const uint64_t g = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long mine = 0;
+    uint32_t           s = 0;
+    if (g < G.nsegs) {
+        s = stream_of(G, g);
+        const uint64_t k = g - G.seg_first[s];
+        const uint64_t evseg = acc[s].evseg;        /* 1 + the event's segment, 0 none */
+        if (evseg != 0 && k + 1 < evseg && !(sum[g].flags & SRE_SUM_STABLE)) mine = k + 1;
+    }
+    /* one atomic per wave and stream: lanes of a wave that share the stream of its first
+     * lane are reduced first (on a stream of unstable segments every lane has a value) */
+    const uint32_t s0 = __shfl(s, 0, 64);
+    unsigned long long red = (s == s0) ? mine : 0;
+    for (int d = 32; d >= 1; d >>= 1) {
+        const unsigned long long o = __shfl_down(red, d, 64);
+        red = o > red ? o : red;
+    }
+    if ((threadIdx.x & 63u) == 0) {
+        if (red) atomicMax(&acc[s0].unst, red);
+    } else if (s != s0 && mine) {
+        atomicMax(&acc[s].unst, mine);
     }
 }
 
@@ -908,7 +1057,7 @@ sre_k_verify_c(sre_scan_tables_t T, sre_scan_geom_t G, const sre_seg_summary_t *
     /* take this stream's accumulator and leave it reset for the next pass */
     const VerifyAcc acc = accs[s];
     accs[s].bad = accs[s].end = ~0ull;
-    accs[s].count = accs[s].evseg = accs[s].spseg = 0;
+    accs[s].count = accs[s].evseg = accs[s].spseg = accs[s].unst = 0;
     const uint64_t first = G.seg_first[s], nseg = G.seg_first[s + 1] - first;
     uint64_t       bad = acc.bad, end = acc.end;
     if (bad > nseg) bad = nseg;
@@ -932,6 +1081,7 @@ sre_k_verify_c(sre_scan_tables_t T, sre_scan_geom_t G, const sre_seg_summary_t *
     st.ev_astate = 0;
     st.valid_from = 0;
     st.ev_seg = -1;
+    st.unst_seg = acc.unst ? (int64_t) acc.unst - 1 : -1;
     if (done && evseg > 0) {
         const sre_seg_summary_t &c = sum[first + evseg - 1];
         st.ev_apos = c.lm_apos;
@@ -1007,6 +1157,7 @@ struct Tracer {
     int64_t                  seg_lo, seg_hi;    /* loaded segment: [seg_lo, seg_hi], -1 none */
     int64_t                  blk_lo, blk_hi;
     int64_t                  valid_from;        /* see entry_state */
+    bool                     use_stable;        /* the summaries' stable stretches may be used (FIRST) */
     uint32_t                 seg_entry;         /* state before seg_lo */
 
     __device__ inline uint32_t step(uint32_t st, int64_t q) const
@@ -1072,6 +1223,12 @@ struct Tracer {
             cur = init_state;
         } else {
             cur = entry_state(kq);
+            if (use_stable && kq >= valid_from) {
+                /* the state does not move over the stable prefix: replay from its end */
+                int64_t skip = (int64_t) (sum[kq].stable_until & ~63u);
+                if (skip > upto - lo) skip = (upto - lo) & ~(int64_t) 63;
+                if (skip > 0 && lo + skip < hi) lo += skip;
+            }
         }
         seg_lo = lo;
         seg_hi = hi;
@@ -1101,6 +1258,13 @@ struct Tracer {
     __device__ uint32_t state_before(int64_t q)
     {
         if (q == sp) return init_state;
+        if (use_stable && q > sp) {
+            /* inside the stable prefix of its segment the state is the entry state */
+            const int64_t kq = (q - 1) / seg_bytes, sbase = kq * (int64_t) seg_bytes;
+            if (sbase >= sp && kq >= valid_from && q - sbase <= (int64_t) sum[kq].stable_until) {
+                return sum[kq].s_in & ~SRE_STATE_SKIP;
+            }
+        }
         if ((q < blk_lo || q > blk_hi) && apos >= 0 && q > apos && q <= apos + 64) {
             /* the block right behind the anchor: no segment replay needed */
             int64_t  hi = apos + 64 < n ? apos + 64 : n;
@@ -1383,6 +1547,7 @@ sre_k_captures(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
     tr.blk_hi = 0;
     tr.seg_entry = 0;
     tr.valid_from = first_valid_segment(tr.sum, tr.sp, (int64_t) G.seg_bytes, st.ev_seg);
+    tr.use_stable = (T.mode == 1 && T.nshadow != 0);
     status[s].valid_from = (uint32_t) tr.valid_from;
 
     int64_t  vec[64];
@@ -1414,8 +1579,40 @@ sre_k_captures(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
     const bool     can_jump = use_maps && T.max_threads <= 16;
     int64_t        budget = SRE_WALK_BUDGET;
 
+    /* stable stretches (sre_hip_scan.h SRE_FAST_STABLE): one search from offset 0 */
+    const uint16_t *const neutral = (T.mode == 1 && T.nshadow) ? tabp->neutral : nullptr;
+
     /* thread j lives in the list at position p */
     for (int64_t p = st.ev_pos; unresolved; p--) {
+        if (neutral != nullptr) {
+            /* cross, in O(1), every stretch in which the automaton sat in one state and
+             * thread j descended from itself without saving: the stable prefix of the
+             * segment in front of p, whole runs of stable segments, a stable suffix */
+            for (;;) {
+                if (p <= tr.sp) break;
+                const int64_t kq = (p - 1) / seg, sbase = kq * seg;
+                const sre_seg_summary_t &S = tr.sum[kq];
+                if (p == sbase + seg && kq < st.ev_seg && kq > st.unst_seg && (S.flags & SRE_SUM_STABLE)) {
+                    /* a whole run of stable segments, all in one state */
+                    if (!((neutral[S.s_in & ~SRE_STATE_SKIP] >> j) & 1u)) break;
+                    p = (st.unst_seg + 1) * seg;
+                    if (p < tr.sp) p = tr.sp;
+                    continue;
+                }
+                if (p - sbase <= (int64_t) S.stable_until) {
+                    if (!((neutral[S.s_in & ~SRE_STATE_SKIP] >> j) & 1u)) break;
+                    p = sbase > tr.sp ? sbase : tr.sp;
+                    continue;
+                }
+                if (p == sbase + seg && (int64_t) S.stable_from < seg) {
+                    if (!((neutral[S.s_out & ~SRE_STATE_SKIP] >> j) & 1u)) break;
+                    p = sbase + S.stable_from;
+                    if (p < tr.sp) p = tr.sp;
+                    continue;
+                }
+                break;
+            }
+        }
         if (can_jump && p > tr.sp && p % seg == 0 && p < st.ev_pos) {
             /* at a segment start: jump over the segments (blocks) in front of it
              * in which this lineage neither saved nor restarted */
@@ -1513,11 +1710,12 @@ scan_kernel(const sre_scan_tables_t *h_tab)
 extern "C" size_t
 sre_scan_lds_bytes(const sre_scan_tables_t *h_tab)
 {
-    const size_t tr = (size_t) h_tab->nstates * (h_tab->ncls + 1) * sizeof(sre_dev_trans_t);
+    const size_t tr = ((size_t) h_tab->nstates * (h_tab->ncls + 1) * 2 + 15) & ~(size_t) 15;
     /* index tile row: the two halves of a line as raw bytes (8 class bits) or
      * 16-bit scaled indices, plus the pad */
     const size_t half = (size_t) SRE_SCAN_ROUND * h_tab->class_bits / 8 * (h_tab->class_bits <= 2 ? 2 : 1);
-    return (size_t) h_tab->fast_bytes + 256 + tr + ((h_tab->nstates + 15u) & ~15u) + 16
+    /* [fast rows][class map][transitions][state flags][tile] */
+    return (size_t) h_tab->fast_rows * SRE_FAST_ROW_BYTES + 256 + tr + ((h_tab->nstates + 15u) & ~15u) + 16
            + (size_t) SRE_SCAN_BLOCK * (2 * half + 16);
 }
 
@@ -1573,7 +1771,7 @@ sre_scan_verify_acc_init(void *d_acc, uint32_t nstreams, hipStream_t stream)
                                     nstreams, stream);
     if (e != hipSuccess) return e;
     return hipMemset2DAsync(static_cast<char *>(d_acc) + 2 * sizeof(unsigned long long),
-                            sizeof(VerifyAcc), 0, 3 * sizeof(unsigned long long), nstreams, stream);
+                            sizeof(VerifyAcc), 0, 4 * sizeof(unsigned long long), nstreams, stream);
 }
 
 extern "C" hipError_t
@@ -1587,6 +1785,9 @@ sre_launch_verify(sre_scan_tables_t h_tab, sre_scan_geom_t geom, const sre_seg_s
     const uint32_t gseg = (uint32_t) ((geom.nsegs + 255) / 256);
     hipLaunchKernelGGL(sre_k_verify_a, dim3(gseg), dim3(256), 0, stream, geom, d_sum, acc, (int) h_tab.mode);
     hipLaunchKernelGGL(sre_k_verify_b, dim3(gseg), dim3(256), 0, stream, geom, d_sum, acc);
+    if (h_tab.mode == 1 /* SRE_HIP_PIKE_FIRST */ && h_tab.nshadow) {
+        hipLaunchKernelGGL(sre_k_verify_b2, dim3(gseg), dim3(256), 0, stream, geom, d_sum, acc);
+    }
     hipLaunchKernelGGL(sre_k_verify_c, dim3((geom.nstreams + 63) / 64), dim3(64), 0, stream, h_tab,
                        geom, d_sum, acc, d_status);
     return hipGetLastError();

@@ -106,8 +106,10 @@ tile_store(const uint4 (&regs)[4], uint8_t *tile, const uint16_t (*clsx)[256], u
                 }
                 if (k % PERW) out[k / PERW] |= v << ((k % PERW) * (32 / PERW)); else out[k / PERW] = v;
             }
+            constexpr int NW = NIDX / PERW;
             if (PIECEB == 4) *reinterpret_cast<uint32_t *>(dst) = out[0];
-            else *reinterpret_cast<uint2 *>(dst) = make_uint2(out[0], out[1 % (NIDX / PERW)]);
+            else if (PIECEB == 8) *reinterpret_cast<uint2 *>(dst) = make_uint2(out[0], out[1 % NW]);
+            else *reinterpret_cast<uint4 *>(dst) = make_uint4(out[0], out[1 % NW], out[2 % NW], out[3 % NW]);
         }
     }
 }

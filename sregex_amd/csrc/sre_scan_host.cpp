@@ -136,6 +136,62 @@ sre_scan_tables_build(const sre_program_t *prog, const sre_dfa_t *d, int mode, c
     std::vector<uint32_t> fast = build_fast(mode);
     std::vector<uint32_t> fast_plain = mode == SRE_HIP_PIKE_COUNT ? build_fast(SRE_HIP_PIKE_FIRST) : fast;
 
+    /* STABLE steps (sre_hip_scan.h).  Per state s and byte class k: the step is a
+     * self-loop without an event, and nm1 = the threads that descend from themselves in
+     * it, saving nothing and not being the ".*?" restart.  The state's neutral set is the
+     * largest nm1; a class is stable for s when its nm1 covers that set, and a fast-table
+     * entry is STABLE when every byte of it is a stable class of s — so inside a stable
+     * stretch the state is s at EVERY byte, not just at entry boundaries. */
+    std::vector<uint16_t> neutral(d->nstates, 0);
+    std::vector<uint32_t> nstable(d->nstates, 0);
+    for (uint32_t s0 = 1; s0 < d->nstates; s0++) {
+        const uint32_t n = d->nthreads[s0];
+        if (n == 0 || n > 16) continue;
+        std::vector<uint16_t> nm1(d->ncls, 0);
+        for (uint32_t k = 0; k < d->ncls; k++) {
+            const sre_dfa_trans_t &tr = d->t(s0, k);
+            if (tr.next != s0 || tr.ev_kind != SRE_DFA_EV_NONE || tr.skipped || tr.lin_n != n) continue;
+            uint16_t m = 0;
+            for (uint32_t j = 0; j < n; j++) {
+                const bool saves = (d->lin_saves[tr.lin_off + j] | d->lin_early[tr.lin_off + j]) != 0;
+                const bool restart = d->list_pcs[d->list_off[s0] + j] == 1;
+                if (d->lin_parent[tr.lin_off + j] == j && !saves && !restart) m |= (uint16_t) (1u << j);
+            }
+            nm1[k] = m;
+            if (__builtin_popcount(m) > __builtin_popcount(neutral[s0])) neutral[s0] = m;
+        }
+        if (neutral[s0] == 0) continue;
+        for (unsigned idx = 0; idx < 256; idx++) {
+            const uint32_t e = fast_plain[(size_t) s0 * 256 + idx];
+            if (e & SRE_FAST_SLOW) continue;
+            bool ok = true;
+            for (uint32_t sub = 0; sub < stride && ok; sub++) {
+                const uint32_t k = bits == 8 ? d->cls_map[idx] : ((idx >> (sub * bits)) & ((1u << bits) - 1));
+                ok = k < d->ncls && (nm1[k] & neutral[s0]) == neutral[s0];
+            }
+            if (!ok) continue;
+            fast_plain[(size_t) s0 * 256 + idx] |= SRE_FAST_STABLE;
+            if (mode != SRE_HIP_PIKE_COUNT) fast[(size_t) s0 * 256 + idx] |= SRE_FAST_STABLE;
+            nstable[s0]++;
+        }
+    }
+    /* shadow rows for the states with the most STABLE entries, as LDS allows */
+    h.nshadow = 0;
+    if (mode != SRE_HIP_PIKE_COUNT) {
+        const uint32_t room = SRE_SCAN_MAX_ROWS - d->nstates - 1;
+        while (h.nshadow < SRE_SCAN_MAX_SHADOWS && h.nshadow < room) {
+            uint32_t best = 0;
+            for (uint32_t s0 = 1; s0 < d->nstates; s0++) {
+                bool taken = false;
+                for (uint32_t q = 0; q < h.nshadow; q++) taken |= h.shadow_state[q] == s0;
+                if (!taken && nstable[s0] > nstable[best]) best = s0;
+            }
+            if (best == 0) break;
+            h.shadow_state[h.nshadow++] = (uint8_t) best;
+        }
+    }
+    h.fast_rows = d->nstates + 1 + h.nshadow;       /* rows of the scan kernel's LDS copy */
+
     std::vector<sre_dev_trans_t> trans(d->trans.size());
     for (size_t i = 0; i < d->trans.size(); i++) {
         const sre_dfa_trans_t &a = d->trans[i];
@@ -151,6 +207,8 @@ sre_scan_tables_build(const sre_program_t *prog, const sre_dfa_t *d, int mode, c
         b.saves = a.ev_saves;
         b.early = a.ev_early;
     }
+    std::vector<uint16_t> trans2((size_t) d->nstates * nsym);
+    for (size_t i = 0; i < trans2.size(); i++) trans2[i] = (uint16_t) (trans[i].next | ((uint32_t) trans[i].kind << 8));
     std::vector<uint8_t> cls(d->cls_map, d->cls_map + 256);
     std::vector<uint8_t> flags(d->nstates);
     for (uint32_t s = 0; s < d->nstates; s++) {
@@ -227,7 +285,7 @@ sre_scan_tables_build(const sre_program_t *prog, const sre_dfa_t *d, int mode, c
          * program. */
         const size_t tr = ((size_t) d->nstates * nsym + 3) * sizeof(sre_dev_trans_t);
         const size_t scan_lds = sre_scan_lds_bytes(&h);
-        const size_t fast_end = (size_t) h.fast_bytes + 4096 + 4096 + 512;
+        const size_t fast_end = (size_t) h.fast_rows * SRE_FAST_ROW_BYTES + 4096 + 4096 + 512;
         const size_t cap_lds = (size_t) h.fast_bytes + 256 + tr + (size_t) h.lin_total * 9
                                + ((size_t) d->nstates + 1 + h.list_total) * 4 + 16 + 512;
         const size_t lin_lds = 256 + (size_t) d->nstates * nsym * sizeof(sre_dev_trans_t)
@@ -246,6 +304,7 @@ sre_scan_tables_build(const sre_program_t *prog, const sre_dfa_t *d, int mode, c
         || (e = upload(fast_plain, &h.fast_plain, t->owned)) != hipSuccess
         || (e = upload(cls, &h.cls, t->owned)) != hipSuccess
         || (e = upload(trans, &h.trans, t->owned)) != hipSuccess
+        || (e = upload(trans2, &h.trans2, t->owned)) != hipSuccess
         || (e = upload(lin_parent, &h.lin_parent, t->owned)) != hipSuccess
         || (e = upload(lin_saves, &h.lin_saves, t->owned)) != hipSuccess
         || (d->has_lookahead && (e = upload(lin_early, &h.lin_early, t->owned)) != hipSuccess)
@@ -254,6 +313,7 @@ sre_scan_tables_build(const sre_program_t *prog, const sre_dfa_t *d, int mode, c
         || (e = upload(d->list_off, &h.list_off, t->owned)) != hipSuccess
         || (e = upload(d->list_pcs, &h.list_pcs, t->owned)) != hipSuccess
         || (e = upload(ncaps, &h.multi_ncaps, t->owned)) != hipSuccess
+        || (e = upload(neutral, &h.neutral, t->owned)) != hipSuccess
         || (e = hipMalloc(reinterpret_cast<void **>(&t->d_tab), sizeof(h))) != hipSuccess
         || (e = hipMemcpy(t->d_tab, &h, sizeof(h), hipMemcpyHostToDevice)) != hipSuccess)
     {

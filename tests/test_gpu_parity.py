@@ -70,6 +70,10 @@ def _expect(ora, prog, ncaps, data):
 def test_batched_scan_gen_data_goldens(gpu, engine):
     """Device-resident batched API on gen-data streams vs reference results."""
     recs = harness.load_jsonl("gen_data.jsonl")
+    if engine == S.ENGINE_VM:
+        # the exact VM walks one stream per lane at MB/s: the small sizes pin it, the
+        # 5 MiB + 8 (bench/gen-data.pl:9) and 16 MiB rows are for the throughput engines
+        recs = [r for r in recs if r["n"] <= (1 << 20) + 8]
     by_cfg = {}
     for r in recs:
         by_cfg.setdefault(tuple(r["re"]), []).append(r)
@@ -274,8 +278,9 @@ def test_scanner_count_long_pending_match_converges_quickly(gpu):
 def test_scanner_long_lineage_uses_ancestor_maps(gpu, seg):
     """A match that starts at offset 0 and ends at the far end of the stream:
     its captures cannot be found by walking a few segments back.  The scanner
-    must fall back to the parallel per-segment ancestor maps (and their
-    256-segment compositions) and still be bit-exact."""
+    either crosses the stream in O(1) jumps over stable stretches (the thread list
+    loops in place) or falls back to the parallel per-segment ancestor maps (and
+    their 256-segment compositions) — bit-exact either way."""
     ora = harness.OracleEngine()
     cases = [
         ([rb"[a-z]+@[a-z]+\.[a-z]+"], S.gen_data_host(300000, b"@abc.cc ")),
@@ -283,6 +288,7 @@ def test_scanner_long_lineage_uses_ancestor_maps(gpu, seg):
         ([rb"(a|b|c)+(@)(x)?"], S.gen_data_host(50003, b"@")),
         ([rb"x(.*)y(.*)z"], b"..x" + b"ab" * 20000 + b"y" + b"cd" * 9000 + b"z.."),
     ]
+    passes = []
     for pats, data in cases:
         with S.Pool() as pool:
             re = S.parse(pool, pats)
@@ -295,12 +301,16 @@ def test_scanner_long_lineage_uses_ancestor_maps(gpu, seg):
             other = S.DeviceBuffer.from_bytes(b"zz a@b.c zz")
             recs = sc.scan([other.ptr, buf.ptr, buf.ptr], [11, len(data), len(data)])
             assert recs[1] == first and recs[2] == first, (pats, seg, recs[1], first)
-            assert sc.last_lineage_passes == 1, (pats, seg)
+            passes.append(sc.last_lineage_passes)
             sc2 = S.Scanner(pool, prog, S.HIP_PIKE_COUNT, S.ENGINE_SCAN)
             sc2.set_segment_bytes(seg)
             assert sc2.scan([buf.ptr], [len(data)])[0] == cnt, (pats, seg)
             buf.free()
             other.free()
+    # a thread list that loops in place over the whole stream ([a-z]+ over letters) is crossed
+    # by the stable-stretch jumps and needs no maps; the list of the third case changes
+    # with every byte: it must take the ancestor maps
+    assert passes[0] == 0 and passes[2] == 1, passes
 
 
 def test_compat_api_large_buffers_take_the_scanner(gpu):
