@@ -73,6 +73,11 @@ SRE_API int sre_hip_scanner_set_segment_bytes(sre_hip_scanner_t *sc, size_t byte
  * entry state was right) */
 SRE_API int sre_hip_scanner_last_fixups(sre_hip_scanner_t *sc);
 
+/* diagnostics: 1 when the last scan's speculative fix-up rounds did not settle and the
+ * exact entry state of every remaining segment was computed by composing the
+ * segments' transition functions (FIRST / Thompson; an automaton that never forgets) */
+SRE_API int sre_hip_scanner_last_exact_passes(sre_hip_scanner_t *sc);
+
 /* diagnostics: 1 when the last scan had to build per-segment ancestor maps to
  * reconstruct the captures of a match spanning many segments */
 SRE_API int sre_hip_scanner_last_lineage_passes(sre_hip_scanner_t *sc);

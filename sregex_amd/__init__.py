@@ -26,7 +26,7 @@ HIP_THOMPSON, HIP_PIKE_FIRST, HIP_PIKE_COUNT = 0, 1, 2
 ENGINE_AUTO, ENGINE_VM, ENGINE_SCAN, ENGINE_NFA = 0, 1, 2, 3
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsregex.so")
+LIB_PATH = os.environ.get("SREGEX_AMD_LIB") or os.path.join(_HERE, "lib", "libsregex.so")
 
 _vp, _sz, _ssz = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_ssize_t
 _pssz = ctypes.POINTER(ctypes.c_ssize_t)
@@ -60,6 +60,7 @@ API = {
     "sre_hip_scanner_set_segment_bytes": (ctypes.c_int, [_vp, _sz]),
     "sre_hip_scanner_last_fixups": (ctypes.c_int, [_vp]),
     "sre_hip_scanner_last_lineage_passes": (ctypes.c_int, [_vp]),
+    "sre_hip_scanner_last_exact_passes": (ctypes.c_int, [_vp]),
     "sre_hip_scanner_class_bits": (ctypes.c_int, [_vp]),
     "sre_hip_scanner_kernel_name": (ctypes.c_char_p, [_vp]),
     "sre_hip_scanner_last_kernel_ms": (ctypes.c_double, [_vp]),
@@ -289,6 +290,10 @@ class Scanner:
     def kernel_name(self):
         """the dominant kernel of a scan, as rocprofv3 names it"""
         return self.lib.sre_hip_scanner_kernel_name(self.h).decode()
+
+    @property
+    def last_exact_passes(self):
+        return self.lib.sre_hip_scanner_last_exact_passes(self.h)
 
     @property
     def last_lineage_passes(self):

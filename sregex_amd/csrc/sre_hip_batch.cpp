@@ -21,6 +21,9 @@
 #include <string.h>
 #include <vector>
 
+/* speculative fix-up rounds before a FIRST / Thompson scan computes exact entry states */
+#define SRE_SPECULATIVE_FIXUPS 2
+
 struct sre_hip_scanner_s {
     sre_program_t     *prog;
     sre_hip_program_s *dp;
@@ -53,6 +56,9 @@ struct sre_hip_scanner_s {
     size_t                    scratch_cap;
     sre_seg_lineage_t        *d_maps, *d_blocks;
     size_t                    maps_cap;
+    uint8_t                  *d_fn;             /* segment transition functions + compositions + entry states */
+    size_t                    fn_cap;
+    int                       exact_passes;     /* of the last scan (diagnostics) */
     int                       lineage_passes;   /* of the last scan (diagnostics) */
     uint32_t                  next_init_variant;    /* compat path: a re-armed context's search */
     int                       blocks_per_cu;
@@ -94,6 +100,7 @@ scanner_release(void *data)
     if (sc->d_lo) (void) hipFree(sc->d_lo);
     if (sc->h_lo) (void) hipHostFree(sc->h_lo);
     if (sc->d_scratch) (void) hipFree(sc->d_scratch);
+    if (sc->d_fn) (void) hipFree(sc->d_fn);
     if (sc->d_maps) (void) hipFree(sc->d_maps);
     if (sc->d_blocks) (void) hipFree(sc->d_blocks);
     if (sc->ev0) (void) hipEventDestroy(sc->ev0);
@@ -234,6 +241,12 @@ extern "C" SRE_API int
 sre_hip_scanner_last_fixups(sre_hip_scanner_t *sc)
 {
     return sc->fixup_rounds;
+}
+
+extern "C" SRE_API int
+sre_hip_scanner_last_exact_passes(sre_hip_scanner_t *sc)
+{
+    return sc->exact_passes;
 }
 
 extern "C" SRE_API int
@@ -443,10 +456,10 @@ nfa_finish(sre_hip_scanner_t *sc, const int64_t *d_lo, hipStream_t stream)
     SRE_HIP_TRY(sre_launch_nfa_verify(sc->mode, sc->geom, sc->d_nsum, sc->d_nacc, sc->d_nstatus,
                                       sc->d_belief, sc->d_bvalid, sc->d_records, sc->ovec_slots, d_lo, stream));
     if (sc->mode != SRE_HIP_THOMPSON) {
-        if (d_lo == NULL) SRE_HIP_TRY(hipMemsetAsync(sc->d_ctx, 0, (size_t) n * sc->ctx_stride, stream));
+        /* (the window kernel zero-fills the context it uses) */
         SRE_HIP_TRY(sre_launch_pike_window(sc->dp->d_blob, sc->d_ptrs, sc->d_lens, n, sc->d_ctx, sc->ctx_stride,
                                            sc->d_records, sc->ovec_slots,
-                                           reinterpret_cast<const sre_nfa_window_t *>(sc->d_nstatus), d_lo, stream));
+                                           reinterpret_cast<sre_nfa_window_t *>(sc->d_nstatus), d_lo, stream));
     }
     return 0;
 hip_failed:
@@ -459,6 +472,7 @@ sre_hip_scan_enqueue(sre_hip_scanner_t *sc, const void *const *d_streams, const 
 {
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     sc->fixup_rounds = 0;
+    sc->exact_passes = 0;
     sc->lineage_passes = 0;
     sc->ev_valid = 0;
     sc->geom.init_variant = sc->next_init_variant;
@@ -505,7 +519,7 @@ sre_hip_scan_enqueue(sre_hip_scanner_t *sc, const void *const *d_streams, const 
             SRE_HIP_TRY(hipEventCreate(&sc->ev1));
         }
         SRE_HIP_TRY(hipEventRecord(sc->ev0, stream));
-        SRE_HIP_TRY(sre_launch_scan(sc->tab->d_tab, sc->tab->h, sc->geom, sc->d_sum, NULL, stream));
+        SRE_HIP_TRY(sre_launch_scan(sc->tab->d_tab, sc->tab->h, sc->geom, sc->d_sum, NULL, NULL, stream));
         SRE_HIP_TRY(hipEventRecord(sc->ev1, stream));
         sc->ev_valid = 1;
         SRE_HIP_TRY(sre_launch_verify(sc->tab->h, sc->geom, sc->d_sum, sc->d_acc, sc->d_status, stream));
@@ -596,7 +610,29 @@ sre_hip_scan_results(sre_hip_scanner_t *sc, sre_int_t *results)
                 return -1;
             }
             SRE_HIP_TRY(hipMemcpyAsync(sc->d_lo, sc->h_lo, n * sizeof(int64_t), hipMemcpyHostToDevice, stream));
-            SRE_HIP_TRY(sre_launch_scan(sc->tab->d_tab, sc->tab->h, sc->geom, sc->d_sum, sc->d_lo, stream));
+            const uint8_t *d_entry = NULL;
+            if (sc->mode != SRE_HIP_PIKE_COUNT && sc->fixup_rounds > SRE_SPECULATIVE_FIXUPS) {
+                /* speculation does not settle this stream (an automaton that never
+                 * forgets): compose the segments' transition functions instead — after
+                 * this pass every lane enters with the exact state */
+                if (sc->geom.nsegs > sc->fn_cap) {
+                    if (sc->d_fn) (void) hipFree(sc->d_fn);
+                    sc->d_fn = NULL;
+                    sc->fn_cap = 0;
+                    const size_t nchunks = sc->geom.nsegs / 256 + 1;
+                    SRE_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&sc->d_fn),
+                                          sc->geom.nsegs * 64 + nchunks * 64 + nchunks + sc->geom.nsegs + 64));
+                    sc->fn_cap = sc->geom.nsegs;
+                }
+                const size_t nchunks = sc->geom.nsegs / 256 + 1;
+                uint8_t *d_comp = sc->d_fn + sc->geom.nsegs * 64, *d_chunk = d_comp + nchunks * 64;
+                uint8_t *d_ent = d_chunk + nchunks;
+                SRE_HIP_TRY(sre_launch_exact_entries(sc->tab->d_tab, sc->tab->h, sc->geom, sc->d_sum, sc->d_status,
+                                                     sc->d_fn, d_comp, d_chunk, d_ent, stream));
+                d_entry = d_ent;
+                sc->exact_passes++;
+            }
+            SRE_HIP_TRY(sre_launch_scan(sc->tab->d_tab, sc->tab->h, sc->geom, sc->d_sum, sc->d_lo, d_entry, stream));
             SRE_HIP_TRY(sre_launch_verify(sc->tab->h, sc->geom, sc->d_sum, sc->d_acc, sc->d_status, stream));
             SRE_HIP_TRY(sre_launch_captures(sc->tab->d_tab, sc->tab->h, sc->geom, sc->d_sum,
                                             sc->d_status, sc->d_scratch, sc->d_records,
@@ -655,6 +691,10 @@ sre_hip_scan_results(sre_hip_scanner_t *sc, sre_int_t *results)
     }
     if (!settled) {
         SRE_HIP_TRY(hipMemcpyAsync(sc->h_records, sc->d_records, bytes, hipMemcpyDeviceToHost, stream));
+        if (sc->engine == SRE_HIP_ENGINE_NFA) {
+            SRE_HIP_TRY(hipMemcpyAsync(sc->h_nstatus, sc->d_nstatus, n * sizeof(sre_nfa_status_t),
+                                       hipMemcpyDeviceToHost, stream));
+        }
         SRE_HIP_TRY(hipStreamSynchronize(stream));
     }
     memcpy(results, sc->h_records, bytes);
@@ -684,7 +724,10 @@ sre_hip_scan_one(sre_hip_scanner_t *sc, const void *d_buf, size_t len, int init_
     sc->next_init_variant = (uint32_t) init_variant;
     if (sre_hip_scan_enqueue(sc, ptrs, lens, 1, stream) != 0) return -1;
     if (sre_hip_scan_results(sc, rec) != 0) return -1;
-    if (poisoned) *poisoned = sc->engine == SRE_HIP_ENGINE_SCAN ? sc->h_status[0].error : 0;
+    if (poisoned) {
+        *poisoned = sc->engine == SRE_HIP_ENGINE_SCAN ? sc->h_status[0].error
+                  : sc->engine == SRE_HIP_ENGINE_NFA ? (sc->h_nstatus[0].clean_mode & SRE_NFA_WINDOW_POISONED) != 0 : 0;
+    }
     return 0;
 }
 

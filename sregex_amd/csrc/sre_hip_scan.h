@@ -202,8 +202,13 @@ int sre_scan_blocks_per_cu(const sre_scan_tables_t *h_tab);
 
 /* control pass over segments [lo[s], nseg_s) of every stream; lo == NULL: all.
  * carry[s] (with lo) = exact entry of segment lo[s] taken from summaries[lo[s]-1]. */
+/* d_entry (optional, with lo): exact entry state per segment, 0xff = none (sre_launch_exact_entries) */
 hipError_t sre_launch_scan(const sre_scan_tables_t *d_tab, sre_scan_tables_t h_tab,
-    sre_scan_geom_t geom, sre_seg_summary_t *d_sum, const int64_t *d_lo, hipStream_t stream);
+    sre_scan_geom_t geom, sre_seg_summary_t *d_sum, const int64_t *d_lo, const uint8_t *d_entry,
+    hipStream_t stream);
+hipError_t sre_launch_exact_entries(const sre_scan_tables_t *d_tab, sre_scan_tables_t h_tab,
+    sre_scan_geom_t geom, const sre_seg_summary_t *d_sum, const sre_stream_status_t *d_status,
+    uint8_t *d_fn, uint8_t *d_comp, uint8_t *d_chunk_entry, uint8_t *d_entry, hipStream_t stream);
 size_t sre_scan_verify_acc_bytes(uint32_t nstreams);
 hipError_t sre_scan_verify_acc_init(void *d_acc, uint32_t nstreams, hipStream_t stream);
 hipError_t sre_launch_verify(sre_scan_tables_t h_tab, sre_scan_geom_t geom,

@@ -28,6 +28,7 @@
  * further after an empty match (:179-196, :624-628).
  */
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include "sre_hip_scan.h"
 #include "sre_hip_tile.h"
 
@@ -460,12 +461,13 @@ byte_x4(uint32_t v, uint32_t sh)
 template <int MODE, int BITS>
 __global__ __launch_bounds__(SRE_SCAN_BLOCK, MODE == SRE_HIP_PIKE_COUNT ? 3 : 4) void
 sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
-           sre_seg_summary_t *__restrict__ sum, const int64_t *__restrict__ lo)
+           sre_seg_summary_t *__restrict__ sum, const int64_t *__restrict__ lo,
+           const uint8_t *__restrict__ entry)
 {
     constexpr int      TILE = SRE_SCAN_ROUND;
     constexpr int      WARM = SRE_SCAN_LINE;         /* warm-up bytes in front of a segment */
     constexpr int      STRIDE = 8 / BITS;
-    constexpr bool     WIDE = (BITS <= 2);           /* 16-bit pre-scaled indices (see tile_store) */
+    constexpr bool     WIDE = SRE_TILE_WIDE(BITS);   /* 16-bit pre-scaled indices (see tile_store) */
     constexpr uint32_t ROWRAW = TILE / STRIDE * (WIDE ? 2 : 1);  /* index bytes per round */
     constexpr uint32_t ROWB = 2 * ROWRAW + 16;       /* see tile_store */
     constexpr int      GIDX = 16 / STRIDE;           /* indices per 16 input bytes */
@@ -617,6 +619,11 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
                     in_pe_sym = c.pe_sym;
                 }
             }
+        } else if (entry != nullptr && entry[g] != 0xffu) {
+            /* exact: the segments' transition functions were composed up to here
+             * (sre_k_seg_functions; FIRST / Thompson after fix-up rounds that did
+             * not converge) */
+            w.st = entry[g];
         } else {
             /* speculative: assume the state reached by a warm-up over the WARM
              * bytes in front of the segment.  In a fix-up round the warm-up
@@ -914,6 +921,146 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
     out.pe_apos = w.ev_apos;
     out.pe_astate = w.ev_astate;
     sum[g] = out;
+}
+
+/* ============================================================ exact entry states */
+
+/*
+ * A stream whose automaton never "forgets" (a state that rotates with the input:
+ * x(?:[^y]{3})*y behind an x) defeats speculation: a fix-up round is only sure to
+ * repair ONE segment, so the rounds would go on for as many segments as the stream
+ * has.  After two rounds that did not settle a FIRST / Thompson scan, the entry
+ * state of every remaining segment is computed exactly instead:
+ *   sre_k_seg_functions  one WAVE per segment, lane l = entry state l: all 64 lanes
+ *                        read the same bytes and walk the LDS fast table from their
+ *                        own state — the segment's whole transition function
+ *                        (64 bytes) at the cost of one lane's walk;
+ *   sre_k_fn_chunks      composes 256 consecutive functions (again lane = state);
+ *   sre_k_fn_resolve     per stream: from the verified prefix's exit state through
+ *                        partial chunks and chunk compositions;
+ *   sre_k_fn_fill        per chunk: the entry state of each of its segments.
+ * One more scan pass with these entry states is exact in every lane.  (COUNT keeps
+ * the speculative rounds: where its searches restart depends on match ends, which
+ * is not a function of the state alone.)
+ */
+#define SRE_FN_CHUNK 256u
+
+template <int BITS>
+__global__ __launch_bounds__(256) void
+sre_k_seg_functions(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
+                    const sre_stream_status_t *__restrict__ status, uint8_t *__restrict__ fn)
+{
+    constexpr int STRIDE = 8 / BITS;
+    constexpr int GIDX = 16 / STRIDE;
+    typedef const __attribute__((address_space(3))) uint32_t *lds_u32_t;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    __shared__ uint16_t clsx[BITS == 8 ? 1 : 8 / BITS][256];
+    const uint32_t tid = threadIdx.x, nst = tabp->nstates, nsym = tabp->ncls + 1;
+    /* LDS: [fast rows + trap][class map][transitions, 2 B each] */
+    uint32_t *fast = reinterpret_cast<uint32_t *>(lds);
+    uint8_t  *clsl = lds + (nst + 1) * SRE_FAST_ROW_BYTES;
+    uint16_t *tr2 = reinterpret_cast<uint16_t *>(clsl + 256);
+    constexpr uint32_t LDS_SLOW = 1u << 16;
+    const uint32_t fast_lds = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) uint8_t *) lds;
+    const uint32_t trap_lds = fast_lds + nst * SRE_FAST_ROW_BYTES;
+    for (uint32_t i = tid; i < nst * 256; i += 256) {
+        const uint32_t gl = tabp->fast[i];
+        fast[i] = (gl & SRE_FAST_SLOW) ? (trap_lds | LDS_SLOW) : fast_lds + (gl & ~(SRE_FAST_ROW_BYTES - 1));
+    }
+    fast[nst * 256 + tid] = trap_lds | LDS_SLOW;
+    clsl[tid] = tabp->cls[tid];
+    for (uint32_t i = tid; i < nst * nsym; i += 256) tr2[i] = tabp->trans2[i];
+    if (BITS != 8) {
+#pragma unroll
+        for (int u = 0; u < 8 / BITS; u++) clsx[u][tid] = (uint16_t) ((uint32_t) tabp->cls[tid] << (BITS * u + 2));
+    }
+    __syncthreads();
+
+    const uint32_t lane = tid & 63u;
+    const uint64_t g = (uint64_t) blockIdx.x * 4 + (tid >> 6);
+    if (g >= G.nsegs) return;
+    const uint32_t s = stream_of(G, g);
+    const uint64_t k = g - G.seg_first[s];
+    if (status[s].done || (int64_t) k < status[s].first_bad) return;
+    if (lane >= nst) {
+        fn[g * 64 + lane] = 0;
+        return;
+    }
+    const uint8_t *data = G.streams[s];
+    const int64_t  n = (int64_t) G.lens[s];
+    int64_t        p = (int64_t) k * G.seg_bytes, seg_b = p + G.seg_bytes;
+    if (seg_b > n) seg_b = n;
+    uint32_t cur = lane;
+    auto exact = [&](int64_t from, int64_t to) {
+        for (int64_t q = from; q < to; q++) cur = tr2[cur * nsym + clsl[data[q]]] & 0xffu;
+    };
+    for (; p + 16 <= seg_b; p += 16) {
+        const sre_u32x4 v = *reinterpret_cast<const __attribute__((address_space(1))) sre_u32x4_unaligned *>(
+            reinterpret_cast<uintptr_t>(data + p));
+        const uint32_t words[4] = {v.x, v.y, v.z, v.w};
+        uint32_t       t = fast_lds + cur * SRE_FAST_ROW_BYTES;
+#pragma unroll
+        for (int j = 0; j < GIDX; j++) {
+            uint32_t ix = 0;
+#pragma unroll
+            for (int u = 0; u < STRIDE; u++) {
+                const int      b = j * STRIDE + u;
+                const uint32_t c = (words[b >> 2] >> ((b & 3) * 8)) & 0xffu;
+                ix |= BITS == 8 ? c << 2 : (uint32_t) clsx[u][c];
+            }
+            t = *(lds_u32_t) (uintptr_t) ((t & 0xffffu) + ix);
+        }
+        if (t & LDS_SLOW) exact(p, p + 16);
+        else cur = ((t & 0xffffu) - fast_lds) / SRE_FAST_ROW_BYTES;
+    }
+    exact(p, seg_b);
+    fn[g * 64 + lane] = (uint8_t) cur;
+}
+
+__global__ __launch_bounds__(64) void
+sre_k_fn_chunks(uint64_t nsegs, const uint8_t *__restrict__ fn, uint8_t *__restrict__ comp)
+{
+    const uint64_t c = blockIdx.x;
+    uint32_t       v = threadIdx.x;
+    const uint64_t g0 = c * SRE_FN_CHUNK, g1 = g0 + SRE_FN_CHUNK <= nsegs ? g0 + SRE_FN_CHUNK : nsegs;
+    for (uint64_t g = g0; g < g1; g++) v = fn[g * 64 + (v & 63u)];
+    comp[c * 64 + threadIdx.x] = (uint8_t) v;
+}
+
+__global__ void
+sre_k_fn_resolve(sre_scan_geom_t G, const sre_seg_summary_t *__restrict__ sum,
+                 const sre_stream_status_t *__restrict__ status, const uint8_t *__restrict__ fn,
+                 const uint8_t *__restrict__ comp, uint8_t *__restrict__ entry, uint8_t *__restrict__ chunk_entry)
+{
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= G.nstreams || status[s].done || status[s].first_bad < 1) return;
+    const uint64_t first = G.seg_first[s], g_hi = G.seg_first[s + 1];
+    uint64_t       g = first + (uint64_t) status[s].first_bad;
+    uint32_t       v = sum[g - 1].s_out & 63u;          /* the verified prefix's exit state */
+    while (g < g_hi) {
+        if (g % SRE_FN_CHUNK == 0 && g + SRE_FN_CHUNK <= g_hi) {
+            chunk_entry[g / SRE_FN_CHUNK] = (uint8_t) v;
+            v = comp[(g / SRE_FN_CHUNK) * 64 + v];
+            g += SRE_FN_CHUNK;
+        } else {
+            entry[g] = (uint8_t) v;
+            v = fn[g * 64 + v];
+            g++;
+        }
+    }
+}
+
+__global__ void
+sre_k_fn_fill(uint64_t nsegs, const uint8_t *__restrict__ fn, const uint8_t *__restrict__ chunk_entry,
+              uint8_t *__restrict__ entry)
+{
+    const uint64_t c = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (c * SRE_FN_CHUNK >= nsegs || chunk_entry[c] == 0xffu) return;
+    uint32_t v = chunk_entry[c];
+    for (uint64_t g = c * SRE_FN_CHUNK; g < (c + 1) * SRE_FN_CHUNK && g < nsegs; g++) {
+        entry[g] = (uint8_t) v;
+        v = fn[g * 64 + (v & 63u)];
+    }
 }
 
 /* ===================================================================== verify */
@@ -1685,7 +1832,7 @@ sre_k_captures(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
 }  // namespace
 
 typedef void (*sre_scan_kernel_t)(const sre_scan_tables_t *, sre_scan_geom_t, sre_seg_summary_t *,
-                                  const int64_t *);
+                                  const int64_t *, const uint8_t *);
 
 template <int MODE>
 static sre_scan_kernel_t
@@ -1713,10 +1860,18 @@ sre_scan_lds_bytes(const sre_scan_tables_t *h_tab)
     const size_t tr = ((size_t) h_tab->nstates * (h_tab->ncls + 1) * 2 + 15) & ~(size_t) 15;
     /* index tile row: the two halves of a line as raw bytes (8 class bits) or
      * 16-bit scaled indices, plus the pad */
-    const size_t half = (size_t) SRE_SCAN_ROUND * h_tab->class_bits / 8 * (h_tab->class_bits <= 2 ? 2 : 1);
+    const size_t half = (size_t) SRE_SCAN_ROUND * h_tab->class_bits / 8 * (SRE_TILE_WIDE(h_tab->class_bits) ? 2 : 1);
     /* [fast rows][class map][transitions][state flags][tile] */
-    return (size_t) h_tab->fast_rows * SRE_FAST_ROW_BYTES + 256 + tr + ((h_tab->nstates + 15u) & ~15u) + 16
-           + (size_t) SRE_SCAN_BLOCK * (2 * half + 16);
+    static const char *pad_env = getenv("SRE_HIP_LDS_PAD");      /* experiment knob: fewer workgroups per CU */
+    const size_t pad = pad_env ? (size_t) atoi(pad_env) : 0;
+    size_t       need = pad + (size_t) h_tab->fast_rows * SRE_FAST_ROW_BYTES + 256 + tr + ((h_tab->nstates + 15u) & ~15u)
+                        + 16 + (size_t) SRE_SCAN_BLOCK * (2 * half + 16);
+    /* COUNT: two workgroups per CU, not the three its registers allow — measured on one
+     * box, configs[2] stream: 3 per CU 1.65 ms, 2 per CU 1.37 ms, 1 per CU 2.46 ms
+     * (profiles/r02_experiments.txt).  The request is padded past a third of the CU's
+     * 160 KiB (the kernel has at least 4.7 KiB of static LDS on top). */
+    if (h_tab->mode == SRE_HIP_PIKE_COUNT && pad_env == NULL && need < 50 * 1024) need = 50 * 1024;
+    return need;
 }
 
 /* workgroups of the scan kernel one CU can hold (registers and LDS), for the
@@ -1735,7 +1890,7 @@ sre_scan_blocks_per_cu(const sre_scan_tables_t *h_tab)
 
 extern "C" hipError_t
 sre_launch_scan(const sre_scan_tables_t *d_tab, sre_scan_tables_t h_tab, sre_scan_geom_t geom,
-                sre_seg_summary_t *d_sum, const int64_t *d_lo, hipStream_t stream)
+                sre_seg_summary_t *d_sum, const int64_t *d_lo, const uint8_t *d_entry, hipStream_t stream)
 {
     if (geom.nsegs == 0) return hipSuccess;
     const uint32_t grid = (uint32_t) ((geom.nsegs + SRE_SCAN_BLOCK - 1) / SRE_SCAN_BLOCK);
@@ -1753,7 +1908,7 @@ sre_launch_scan(const sre_scan_tables_t *d_tab, sre_scan_tables_t h_tab, sre_sca
         }
     }
     hipLaunchKernelGGL(scan_kernel(&h_tab), dim3(grid), dim3(SRE_SCAN_BLOCK), shmem, stream,
-                       d_tab, geom, d_sum, d_lo);
+                       d_tab, geom, d_sum, d_lo, d_entry);
     return hipGetLastError();
 }
 
@@ -1847,5 +2002,40 @@ sre_launch_lineage(const sre_scan_tables_t *d_tab, sre_scan_tables_t h_tab, sre_
         hipLaunchKernelGGL(sre_k_lineage_blocks, dim3((uint32_t) ((nblocks * 16 + 255) / 256)), dim3(256), 0,
                            stream, geom.nsegs, d_maps, d_blocks);
     }
+    return hipGetLastError();
+}
+
+/* FIRST / Thompson: exact entry states of every segment behind each unsettled stream's
+ * verified prefix (see sre_k_seg_functions).  d_fn: nsegs * 64 bytes, d_comp:
+ * (nsegs / 256 + 1) * 64, d_chunk_entry: nsegs / 256 + 1, d_entry: nsegs (out; 0xff =
+ * not computed). */
+extern "C" hipError_t
+sre_launch_exact_entries(const sre_scan_tables_t *d_tab, sre_scan_tables_t h_tab, sre_scan_geom_t geom,
+                         const sre_seg_summary_t *d_sum, const sre_stream_status_t *d_status,
+                         uint8_t *d_fn, uint8_t *d_comp, uint8_t *d_chunk_entry, uint8_t *d_entry,
+                         hipStream_t stream)
+{
+    if (geom.nsegs == 0) return hipSuccess;
+    const uint64_t nchunks = (geom.nsegs + SRE_FN_CHUNK - 1) / SRE_FN_CHUNK;
+    hipError_t     e;
+    if ((e = hipMemsetAsync(d_entry, 0xff, geom.nsegs, stream)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(d_chunk_entry, 0xff, nchunks, stream)) != hipSuccess) return e;
+    const size_t shmem = (size_t) (h_tab.nstates + 1) * SRE_FAST_ROW_BYTES + 256
+                         + (((size_t) h_tab.nstates * (h_tab.ncls + 1) * 2 + 15) & ~(size_t) 15);
+    const uint32_t grid = (uint32_t) ((geom.nsegs + 3) / 4);
+    void (*kern)(const sre_scan_tables_t *, sre_scan_geom_t, const sre_stream_status_t *, uint8_t *) =
+        h_tab.class_bits == 1 ? sre_k_seg_functions<1> : h_tab.class_bits == 2 ? sre_k_seg_functions<2>
+        : h_tab.class_bits == 4 ? sre_k_seg_functions<4> : sre_k_seg_functions<8>;
+    if (shmem > 48 * 1024) {
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int) shmem);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), shmem, stream, d_tab, geom, d_status, d_fn);
+    hipLaunchKernelGGL(sre_k_fn_chunks, dim3((uint32_t) nchunks), dim3(64), 0, stream, geom.nsegs, d_fn, d_comp);
+    hipLaunchKernelGGL(sre_k_fn_resolve, dim3((geom.nstreams + 63) / 64), dim3(64), 0, stream, geom, d_sum,
+                       d_status, d_fn, d_comp, d_entry, d_chunk_entry);
+    hipLaunchKernelGGL(sre_k_fn_fill, dim3((uint32_t) ((nchunks + 63) / 64)), dim3(64), 0, stream, geom.nsegs,
+                       d_fn, d_chunk_entry, d_entry);
     return hipGetLastError();
 }

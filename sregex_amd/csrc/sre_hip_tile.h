@@ -13,6 +13,13 @@
 #include <hip/hip_runtime.h>
 #include "sre_hip_scan.h"
 
+/* class widths whose tile holds 16-bit indices already scaled to a byte offset into a
+ * fast-table row (one SDWA add per lookup in the consumer) instead of 8-bit ones */
+#ifndef SRE_TILE_WIDE_MAX_BITS
+#define SRE_TILE_WIDE_MAX_BITS 2
+#endif
+#define SRE_TILE_WIDE(bits) ((bits) <= SRE_TILE_WIDE_MAX_BITS)
+
 namespace {
 
 /* one row of a workgroup's staging: where the lane's segment (with its warm-up
@@ -74,7 +81,7 @@ __device__ inline void
 tile_store(const uint4 (&regs)[4], uint8_t *tile, const uint16_t (*clsx)[256], uint32_t tid, uint32_t stage)
 {
     constexpr int      STRIDE = 8 / BITS;                       /* input bytes per index */
-    constexpr bool     WIDE = (BITS <= 2);                      /* 16-bit pre-scaled indices */
+    constexpr bool     WIDE = SRE_TILE_WIDE(BITS);              /* 16-bit pre-scaled indices */
     constexpr uint32_t HALFB = SRE_SCAN_ROUND / STRIDE * (WIDE ? 2 : 1);
     constexpr uint32_t ROWB = 2 * HALFB + 16;
     constexpr uint32_t PIECEB = HALFB / 4;                      /* index bytes per 16 input bytes */

@@ -35,20 +35,23 @@ typedef struct {
     int64_t ev_pos;         /* first MATCH event, -1 none: no window */
     int64_t clean_pos;      /* the VM starts here */
     int32_t done;
-    int32_t clean_mode;     /* 1: the reference reaches clean_pos as a leading-byte skip target */
+    int32_t clean_mode;     /* bit 0: the reference reaches clean_pos as a leading-byte skip target;
+                               SRE_NFA_WINDOW_POISONED: set by the window kernel (see there) */
 } sre_nfa_window_t;
+#define SRE_NFA_WINDOW_POISONED 0x100
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 hipError_t sre_launch_pike_window(const void *blob, const void *const *d_streams,
     const uint64_t *d_lens, uint32_t nstreams, void *d_ctx, uint64_t ctx_stride,
-    int64_t *d_records, uint32_t ovec_slots, const sre_nfa_window_t *d_win, const int64_t *d_lo,
+    int64_t *d_records, uint32_t ovec_slots, sre_nfa_window_t *d_win, const int64_t *d_lo,
     hipStream_t stream);
+/* ctx_bytes: size of one stream context (copied into LDS for the call when it fits) */
 hipError_t sre_launch_pike_exec(const void *blob, const sre_dev_req_t *d_reqs,
-    uint32_t nreqs, hipStream_t stream);
+    uint32_t nreqs, size_t ctx_bytes, hipStream_t stream);
 hipError_t sre_launch_thompson_exec(const void *blob, const sre_dev_req_t *d_reqs,
-    uint32_t nreqs, hipStream_t stream);
+    uint32_t nreqs, size_t ctx_bytes, hipStream_t stream);
 /* whole-stream scan, one lane per stream; mode = SRE_HIP_THOMPSON / PIKE_FIRST / PIKE_COUNT */
 hipError_t sre_launch_vm_scan(const void *blob, int mode, const void *const *d_streams,
     const uint64_t *d_lens, uint32_t nstreams, void *d_ctx, uint64_t ctx_stride,

@@ -754,61 +754,99 @@ struct Thompson {
 
 }  // namespace
 
-/* One lane per request: lane i of the grid serves reqs[i]. */
+/*
+ * One WORKGROUP per request.  The stream context (a few KiB: thread lists, tags,
+ * capture vectors) is copied into LDS by the whole wave, lane 0 runs the VM on it
+ * there, and the wave copies it back: the VM touches its context several times per
+ * byte and thread, and from HBM every one of those is a ~1 us round trip.  A context
+ * too large for LDS (thousands of instructions) is worked on in place.
+ */
+__device__ inline void
+ctx_copy(uint8_t *dst, const uint8_t *src, size_t bytes)
+{
+    for (size_t i = (size_t) threadIdx.x * 16; i < bytes; i += (size_t) blockDim.x * 16) {
+        *reinterpret_cast<uint4 *>(dst + i) = *reinterpret_cast<const uint4 *>(src + i);
+    }
+}
+
 extern "C" __global__ void
 sre_k_pike_exec(const uint8_t *__restrict__ blob, const sre_dev_req_t *__restrict__ reqs,
-                uint32_t nreqs)
+                uint32_t nreqs, uint32_t use_lds)
 {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) uint8_t ctx_lds[];
+    const uint32_t i = blockIdx.x;
     if (i >= nreqs) return;
     const sre_dev_req_t rq = reqs[i];
 
     Pike vm;
     vm.P = prog_view(blob);
     const sre_pike_layout_t L = sre_pike_layout(vm.P.h->len, vm.P.h->nthreads, vm.P.h->nslots);
-    uint8_t *base = static_cast<uint8_t *>(rq.ctx);
-    vm.h = reinterpret_cast<PikeHdr *>(base);
-    vm.tags = reinterpret_cast<uint32_t *>(base + L.tags);
-    vm.initial = reinterpret_cast<uint32_t *>(base + L.initial);
-    vm.nodes[0] = base + L.nodes[0];
-    vm.nodes[1] = base + L.nodes[1];
-    vm.matched = reinterpret_cast<int64_t *>(base + L.matched);
-    vm.work = reinterpret_cast<int64_t *>(base + L.work);
-    vm.stack = reinterpret_cast<StackRec *>(base + L.stack);
-    vm.node_bytes = L.node_bytes;
-    vm.nslots = vm.P.h->nslots;
-    vm.in.p = rq.input;
-    vm.in.inl = rq.inline_bytes;
+    uint8_t *home = static_cast<uint8_t *>(rq.ctx);
+    uint8_t *base = use_lds ? ctx_lds : home;
+    if (use_lds) {
+        ctx_copy(ctx_lds, home, L.total);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        vm.h = reinterpret_cast<PikeHdr *>(base);
+        vm.tags = reinterpret_cast<uint32_t *>(base + L.tags);
+        vm.initial = reinterpret_cast<uint32_t *>(base + L.initial);
+        vm.nodes[0] = base + L.nodes[0];
+        vm.nodes[1] = base + L.nodes[1];
+        vm.matched = reinterpret_cast<int64_t *>(base + L.matched);
+        vm.work = reinterpret_cast<int64_t *>(base + L.work);
+        vm.stack = reinterpret_cast<StackRec *>(base + L.stack);
+        vm.node_bytes = L.node_bytes;
+        vm.nslots = vm.P.h->nslots;
+        vm.in.p = rq.input;
+        vm.in.inl = rq.inline_bytes;
 
-    sre_dev_result_t *res = static_cast<sre_dev_result_t *>(rq.result);
-    int64_t          *ov = reinterpret_cast<int64_t *>(res + 1);
-    res->rc = vm.exec(rq.size, rq.eof, rq.want_pending != 0, res, ov, rq.ovec_slots, &rq);
+        sre_dev_result_t *res = static_cast<sre_dev_result_t *>(rq.result);
+        int64_t          *ov = reinterpret_cast<int64_t *>(res + 1);
+        res->rc = vm.exec(rq.size, rq.eof, rq.want_pending != 0, res, ov, rq.ovec_slots, &rq);
+    }
+    if (use_lds) {
+        __syncthreads();
+        ctx_copy(home, ctx_lds, L.total);
+    }
 }
 
 extern "C" __global__ void
 sre_k_thompson_exec(const uint8_t *__restrict__ blob, const sre_dev_req_t *__restrict__ reqs,
-                    uint32_t nreqs)
+                    uint32_t nreqs, uint32_t use_lds)
 {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    extern __shared__ __attribute__((aligned(16))) uint8_t ctx_lds[];
+    const uint32_t i = blockIdx.x;
     if (i >= nreqs) return;
     const sre_dev_req_t rq = reqs[i];
 
     Thompson vm;
     vm.P = prog_view(blob);
     const sre_thompson_layout_t L = sre_thompson_layout(vm.P.h->len);
-    uint8_t *base = static_cast<uint8_t *>(rq.ctx);
-    vm.h = reinterpret_cast<ThompsonHdr *>(base);
-    vm.tags = reinterpret_cast<uint32_t *>(base + L.tags);
-    vm.list[0] = reinterpret_cast<uint32_t *>(base + L.list[0]);
-    vm.list[1] = reinterpret_cast<uint32_t *>(base + L.list[1]);
-    vm.stack = reinterpret_cast<uint32_t *>(base + L.stack);
-    vm.in.p = rq.input;
-    vm.in.inl = rq.inline_bytes;
+    uint8_t *home = static_cast<uint8_t *>(rq.ctx);
+    uint8_t *base = use_lds ? ctx_lds : home;
+    if (use_lds) {
+        ctx_copy(ctx_lds, home, L.total);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        vm.h = reinterpret_cast<ThompsonHdr *>(base);
+        vm.tags = reinterpret_cast<uint32_t *>(base + L.tags);
+        vm.list[0] = reinterpret_cast<uint32_t *>(base + L.list[0]);
+        vm.list[1] = reinterpret_cast<uint32_t *>(base + L.list[1]);
+        vm.stack = reinterpret_cast<uint32_t *>(base + L.stack);
+        vm.in.p = rq.input;
+        vm.in.inl = rq.inline_bytes;
 
-    sre_dev_result_t *res = static_cast<sre_dev_result_t *>(rq.result);
-    res->has_pending = 0;
-    res->consumed = 0;
-    res->rc = vm.exec(rq.size, rq.eof, res);
+        sre_dev_result_t *res = static_cast<sre_dev_result_t *>(rq.result);
+        res->has_pending = 0;
+        res->consumed = 0;
+        res->rc = vm.exec(rq.size, rq.eof, res);
+    }
+    if (use_lds) {
+        __syncthreads();
+        ctx_copy(home, ctx_lds, L.total);
+    }
 }
 
 /*
@@ -877,9 +915,12 @@ extern "C" __global__ void
 sre_k_pike_window(const uint8_t *__restrict__ blob, const uint8_t *const *__restrict__ streams,
                   const uint64_t *__restrict__ lens, uint32_t nstreams, uint8_t *ctx_base,
                   uint64_t ctx_stride, int64_t *__restrict__ records, uint32_t ovec_slots,
-                  const sre_nfa_window_t *__restrict__ win, const int64_t *__restrict__ lo)
+                  sre_nfa_window_t *__restrict__ win, const int64_t *__restrict__ lo, uint32_t use_lds)
 {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    /* one workgroup per stream; the (fresh) context lives in LDS when it fits, see
+     * sre_k_pike_exec */
+    extern __shared__ __attribute__((aligned(16))) uint8_t ctx_lds[];
+    const uint32_t i = blockIdx.x;
     if (i >= nstreams) return;
     if (lo != nullptr && lo[i] < 0) return;     /* settled in an earlier round */
     if (!win[i].done || win[i].ev_pos < 0) return;
@@ -887,7 +928,13 @@ sre_k_pike_window(const uint8_t *__restrict__ blob, const uint8_t *const *__rest
     Pike vm;
     vm.P = prog_view(blob);
     const sre_pike_layout_t L = sre_pike_layout(vm.P.h->len, vm.P.h->nthreads, vm.P.h->nslots);
-    uint8_t *base = ctx_base + (size_t) i * ctx_stride;
+    uint8_t *base = use_lds ? ctx_lds : ctx_base + (size_t) i * ctx_stride;
+    /* zero-filled == fresh */
+    for (size_t b = (size_t) threadIdx.x * 16; b < L.total; b += (size_t) blockDim.x * 16) {
+        *reinterpret_cast<uint4 *>(base + b) = make_uint4(0, 0, 0, 0);
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
     vm.h = reinterpret_cast<PikeHdr *>(base);
     vm.tags = reinterpret_cast<uint32_t *>(base + L.tags);
     vm.initial = reinterpret_cast<uint32_t *>(base + L.initial);
@@ -899,28 +946,40 @@ sre_k_pike_window(const uint8_t *__restrict__ blob, const uint8_t *const *__rest
     vm.node_bytes = L.node_bytes;
     vm.nslots = vm.P.h->nslots;
     vm.in.inl = 0;
-    vm.in.p = streams[i];       /* the context is zero-filled (fresh) by the caller */
+    vm.in.p = streams[i];
 
     int64_t         *rec = records + (size_t) i * (2 + ovec_slots);
     sre_dev_result_t res;
     for (uint32_t k = 0; k < ovec_slots; k++) rec[2 + k] = -1;
     const int64_t rc = vm.exec(lens[i], 1u, false, &res, rec + 2, ovec_slots, nullptr, win[i].clean_pos,
-                               win[i].clean_mode != 0);
+                               (win[i].clean_mode & 1) != 0);
     rec[0] = rc;
     rec[1] = rc >= 0 ? 1 : 0;
+    /* a match returned with threads still listed at end of input: the context is
+     * poisoned, its next exec fails (sre_vm_pike.c:616-622) — the compat API asks */
+    if (rc >= 0 && vm.h->eof) win[i].clean_mode |= SRE_NFA_WINDOW_POISONED;
 }
+
+/* dynamic LDS a one-request VM kernel may take for the context copy */
+#define SRE_VM_CTX_LDS_LIMIT (96u * 1024u)
 
 extern "C" hipError_t
 sre_launch_pike_window(const void *blob, const void *const *d_streams, const uint64_t *d_lens,
                        uint32_t nstreams, void *d_ctx, uint64_t ctx_stride, int64_t *d_records,
-                       uint32_t ovec_slots, const sre_nfa_window_t *d_win, const int64_t *d_lo,
+                       uint32_t ovec_slots, sre_nfa_window_t *d_win, const int64_t *d_lo,
                        hipStream_t stream)
 {
-    uint32_t block = 64, grid = (nstreams + block - 1) / block;
-    hipLaunchKernelGGL(sre_k_pike_window, dim3(grid), dim3(block), 0, stream,
+    const size_t   bytes = ((size_t) ctx_stride + 15) & ~(size_t) 15;
+    const uint32_t use_lds = bytes <= SRE_VM_CTX_LDS_LIMIT ? 1u : 0u;
+    if (use_lds && bytes > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sre_k_pike_window),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, SRE_VM_CTX_LDS_LIMIT);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(sre_k_pike_window, dim3(nstreams), dim3(64), use_lds ? bytes : 0, stream,
                        static_cast<const uint8_t *>(blob),
                        reinterpret_cast<const uint8_t *const *>(d_streams), d_lens, nstreams,
-                       static_cast<uint8_t *>(d_ctx), ctx_stride, d_records, ovec_slots, d_win, d_lo);
+                       static_cast<uint8_t *>(d_ctx), ctx_stride, d_records, ovec_slots, d_win, d_lo, use_lds);
     return hipGetLastError();
 }
 
@@ -972,22 +1031,33 @@ sre_launch_vm_scan(const void *blob, int mode, const void *const *d_streams,
     return hipGetLastError();
 }
 
-extern "C" hipError_t
-sre_launch_pike_exec(const void *blob, const sre_dev_req_t *d_reqs, uint32_t nreqs,
-                     hipStream_t stream)
+template <typename K>
+static hipError_t
+vm_exec_launch(K kernel, const void *blob, const sre_dev_req_t *d_reqs, uint32_t nreqs, size_t ctx_bytes,
+               hipStream_t stream)
 {
-    uint32_t block = 64, grid = (nreqs + block - 1) / block;
-    hipLaunchKernelGGL(sre_k_pike_exec, dim3(grid), dim3(block), 0, stream,
-                       static_cast<const uint8_t *>(blob), d_reqs, nreqs);
+    const size_t   bytes = (ctx_bytes + 15) & ~(size_t) 15;
+    const uint32_t use_lds = bytes <= SRE_VM_CTX_LDS_LIMIT ? 1u : 0u;
+    if (use_lds && bytes > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, SRE_VM_CTX_LDS_LIMIT);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kernel, dim3(nreqs), dim3(64), use_lds ? bytes : 0, stream,
+                       static_cast<const uint8_t *>(blob), d_reqs, nreqs, use_lds);
     return hipGetLastError();
 }
 
 extern "C" hipError_t
-sre_launch_thompson_exec(const void *blob, const sre_dev_req_t *d_reqs, uint32_t nreqs,
+sre_launch_pike_exec(const void *blob, const sre_dev_req_t *d_reqs, uint32_t nreqs, size_t ctx_bytes,
+                     hipStream_t stream)
+{
+    return vm_exec_launch(sre_k_pike_exec, blob, d_reqs, nreqs, ctx_bytes, stream);
+}
+
+extern "C" hipError_t
+sre_launch_thompson_exec(const void *blob, const sre_dev_req_t *d_reqs, uint32_t nreqs, size_t ctx_bytes,
                          hipStream_t stream)
 {
-    uint32_t block = 64, grid = (nreqs + block - 1) / block;
-    hipLaunchKernelGGL(sre_k_thompson_exec, dim3(grid), dim3(block), 0, stream,
-                       static_cast<const uint8_t *>(blob), d_reqs, nreqs);
-    return hipGetLastError();
+    return vm_exec_launch(sre_k_thompson_exec, blob, d_reqs, nreqs, ctx_bytes, stream);
 }

@@ -177,7 +177,7 @@ sre_scan_tables_build(const sre_program_t *prog, const sre_dfa_t *d, int mode, c
     }
     /* shadow rows for the states with the most STABLE entries, as LDS allows */
     h.nshadow = 0;
-    if (mode != SRE_HIP_PIKE_COUNT) {
+    if (mode != SRE_HIP_PIKE_COUNT && getenv("SRE_HIP_NO_SHADOW") == NULL) {      /* (experiment knob) */
         const uint32_t room = SRE_SCAN_MAX_ROWS - d->nstates - 1;
         while (h.nshadow < SRE_SCAN_MAX_SHADOWS && h.nshadow < room) {
             uint32_t best = 0;

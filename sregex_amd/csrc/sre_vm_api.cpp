@@ -26,9 +26,11 @@
 extern "C" int sre_hip_scan_one(sre_hip_scanner_t *sc, const void *d_buf, size_t len,
     int init_variant, sre_int_t *rec, int *poisoned, hipStream_t stream);
 
-/* whole-buffer calls at least this long go through the table-driven scanner
- * when the program admits one; shorter ones are cheaper on the VM kernel */
-#define SRE_COMPAT_SCAN_MIN_BYTES  (32u * 1024u)
+/* whole-buffer calls at least this long go through a throughput engine (the
+ * table-driven scanner, else the NFA tier) when the program admits one: below it
+ * the exact VM's ~1 us per byte is cheaper than the scanners' fixed launch cost
+ * (profiles/r02_crossover.json) */
+#define SRE_COMPAT_SCAN_MIN_BYTES  16u
 
 namespace {
 
@@ -41,8 +43,9 @@ struct HostBlock {
 
 struct DeviceStream {
     sre_hip_program_s *dp;
+    int                device;
     void              *d_ctx;       /* VM state, zero-filled == fresh */
-    size_t             ctx_bytes;
+    size_t             ctx_bytes, ctx_cap, blk_cap;
     void              *d_in;        /* staging for chunks > 8 bytes */
     size_t             in_cap;
     HostBlock         *h_blk;       /* pinned + mapped */
@@ -54,10 +57,22 @@ struct DeviceStream {
     int64_t            preset_processed;
 };
 
+/*
+ * Contexts come and go with the caller's pools (the reference's clients make one
+ * per subject, src/sre_cli.c:298-660; a filter makes one per request), and a HIP
+ * stream + two device allocations + a pinned block cost milliseconds to create.
+ * Released device streams are therefore parked in a process-wide free list and
+ * handed to the next context that fits (same device, large enough), with the VM
+ * state zero-filled again.  The list is bounded; the API is single-threaded by
+ * contract, so no lock.
+ */
+#define SRE_STREAM_CACHE_MAX 32
+DeviceStream *g_parked[SRE_STREAM_CACHE_MAX];
+int           g_nparked = 0;
+
 void
-device_stream_release(void *data)
+device_stream_destroy(DeviceStream *ds)
 {
-    DeviceStream *ds = static_cast<DeviceStream *>(data);
     if (ds->d_ctx) (void) hipFree(ds->d_ctx);
     if (ds->d_in) (void) hipFree(ds->d_in);
     if (ds->h_blk) (void) hipHostFree(ds->h_blk);
@@ -65,29 +80,66 @@ device_stream_release(void *data)
     free(ds);
 }
 
+void
+device_stream_release(void *data)
+{
+    DeviceStream *ds = static_cast<DeviceStream *>(data);
+    if (!ds->failed && g_nparked < SRE_STREAM_CACHE_MAX) {
+        ds->dp = NULL;                      /* the program may be gone before the next use */
+        g_parked[g_nparked++] = ds;
+        return;
+    }
+    device_stream_destroy(ds);
+}
+
 DeviceStream *
 device_stream_open(sre_pool_t *pool, sre_program_t *prog, size_t ctx_bytes, size_t ovec_slots)
 {
     sre_hip_program_s *dp = sre_hip_program_get(prog);
     if (dp == NULL) return NULL;
+    const size_t blk = sizeof(HostBlock) + ovec_slots * sizeof(int64_t);
 
-    DeviceStream *ds = static_cast<DeviceStream *>(calloc(1, sizeof(DeviceStream)));
+    DeviceStream *ds = NULL;
+    for (int i = 0; i < g_nparked; i++) {
+        DeviceStream *c = g_parked[i];
+        if (c->device == dp->device && c->ctx_cap >= ctx_bytes && c->blk_cap >= blk) {
+            ds = c;
+            g_parked[i] = g_parked[--g_nparked];
+            break;
+        }
+    }
+    if (ds != NULL) {
+        ds->dp = dp;
+        ds->ctx_bytes = ctx_bytes;
+        ds->failed = 0;
+        ds->preset_valid = ds->preset_flags = 0;
+        ds->preset_processed = 0;
+        memset(ds->h_blk, 0, blk);
+        SRE_HIP_TRY(hipMemsetAsync(ds->d_ctx, 0, ctx_bytes, ds->stream));
+        if (sre_pool_add_cleanup(pool, device_stream_release, ds) != SRE_OK) goto hip_failed;
+        return ds;
+    }
+
+    ds = static_cast<DeviceStream *>(calloc(1, sizeof(DeviceStream)));
     if (ds == NULL) return NULL;
     ds->dp = dp;
+    ds->device = dp->device;
     ds->ctx_bytes = ctx_bytes;
-    size_t blk = sizeof(HostBlock) + ovec_slots * sizeof(int64_t);
+    /* room to be reused by the next program too */
+    ds->ctx_cap = ctx_bytes < 64 * 1024 ? 64 * 1024 : ctx_bytes;
+    ds->blk_cap = blk < 1024 ? 1024 : blk;
 
     SRE_HIP_TRY(hipStreamCreateWithFlags(&ds->stream, hipStreamNonBlocking));
-    SRE_HIP_TRY(hipMalloc(&ds->d_ctx, ctx_bytes));
+    SRE_HIP_TRY(hipMalloc(&ds->d_ctx, ds->ctx_cap));
     SRE_HIP_TRY(hipMemsetAsync(ds->d_ctx, 0, ctx_bytes, ds->stream));
-    SRE_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&ds->h_blk), blk, hipHostMallocMapped));
+    SRE_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&ds->h_blk), ds->blk_cap, hipHostMallocMapped));
     SRE_HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&ds->d_blk), ds->h_blk, 0));
-    memset(ds->h_blk, 0, blk);
+    memset(ds->h_blk, 0, ds->blk_cap);
     if (sre_pool_add_cleanup(pool, device_stream_release, ds) != SRE_OK) goto hip_failed;
     return ds;
 
 hip_failed:
-    device_stream_release(ds);
+    device_stream_destroy(ds);
     return NULL;
 }
 
@@ -95,7 +147,7 @@ hip_failed:
 int
 device_stream_exec(DeviceStream *ds, const sre_char *input, size_t len, unsigned eof,
                    unsigned want_pending, size_t ovec_slots,
-                   hipError_t (*launch)(const void *, const sre_dev_req_t *, uint32_t, hipStream_t))
+                   hipError_t (*launch)(const void *, const sre_dev_req_t *, uint32_t, size_t, hipStream_t))
 {
     sre_dev_req_t *rq = &ds->h_blk->req;
 
@@ -126,7 +178,7 @@ device_stream_exec(DeviceStream *ds, const sre_char *input, size_t len, unsigned
     }
     ds->h_blk->res.rc = SRE_ERROR;
 
-    SRE_HIP_TRY(launch(ds->dp->d_blob, &ds->d_blk->req, 1, ds->stream));
+    SRE_HIP_TRY(launch(ds->dp->d_blob, &ds->d_blk->req, 1, ds->ctx_bytes, ds->stream));
     SRE_HIP_TRY(hipStreamSynchronize(ds->stream));
     return 0;
 
@@ -157,6 +209,25 @@ struct sre_vm_pike_ctx_s {
     sre_int_t     *rec;
 };
 
+/* The throughput scanner of a program for the compat path: built once per program
+ * and mode (automaton + device tables cost milliseconds), owned by the PROGRAM's
+ * pool, shared by every context of the program — exec() is synchronous, so one call
+ * is in flight at a time.  NULL when only the exact VM takes the program. */
+static sre_hip_scanner_t *
+compat_scanner(sre_program_t *prog, int mode)
+{
+    sre_hip_program_s *dp = sre_hip_program_get(prog);
+    if (dp == NULL) return NULL;
+    const int slot = mode == SRE_HIP_THOMPSON ? 0 : 1;
+    if (!dp->compat_tried[slot]) {
+        dp->compat_tried[slot] = 1;
+        sre_hip_scanner_t *sc = sre_hip_scanner_create(prog->pool, prog, mode, SRE_HIP_ENGINE_AUTO);
+        if (sc && sre_hip_scanner_engine(sc) == SRE_HIP_ENGINE_VM) sc = NULL;
+        dp->compat_scanner[slot] = sc;
+    }
+    return dp->compat_scanner[slot];
+}
+
 static int
 pike_scan_route(sre_vm_pike_ctx_t *ctx, sre_char *input, size_t len, sre_int_t *prc)
 {
@@ -168,8 +239,7 @@ pike_scan_route(sre_vm_pike_ctx_t *ctx, sre_char *input, size_t len, sre_int_t *
     }
     if (!ctx->scanner_tried) {
         ctx->scanner_tried = 1;
-        ctx->scanner = sre_hip_scanner_create(ctx->pool, ctx->prog, SRE_HIP_PIKE_FIRST, SRE_HIP_ENGINE_AUTO);
-        if (ctx->scanner && sre_hip_scanner_engine(ctx->scanner) != SRE_HIP_ENGINE_SCAN) ctx->scanner = NULL;
+        ctx->scanner = compat_scanner(ctx->prog, SRE_HIP_PIKE_FIRST);
         if (ctx->scanner) {
             ctx->rec = static_cast<sre_int_t *>(
                 sre_palloc(ctx->pool, sre_hip_scanner_result_slots(ctx->scanner) * sizeof(sre_int_t)));
@@ -180,6 +250,12 @@ pike_scan_route(sre_vm_pike_ctx_t *ctx, sre_char *input, size_t len, sre_int_t *
     /* look-ahead assertions: the automaton models a FRESH context only (a
      * re-armed search needs seen_word, sre_vm_pike.c:472-473, 594) */
     if (ctx->prog->lookahead_asserts && (ctx->empty_capture || ctx->processed_bytes != 0)) return 0;
+    /* the NFA tier's exact window runs a FRESH context from a clean position */
+    if (sre_hip_scanner_engine(ctx->scanner) == SRE_HIP_ENGINE_NFA
+        && (ctx->empty_capture || ctx->processed_bytes != 0))
+    {
+        return 0;
+    }
 
     size_t skip = 0;
     int    variant;
@@ -355,8 +431,7 @@ sre_vm_thompson_exec(sre_vm_thompson_ctx_t *ctx, sre_char *input, size_t len, un
         /* first and only chunk of a large stream: match / no match from the scanner */
         if (!ctx->scanner_tried) {
             ctx->scanner_tried = 1;
-            ctx->scanner = sre_hip_scanner_create(ctx->pool, ctx->prog, SRE_HIP_THOMPSON, SRE_HIP_ENGINE_AUTO);
-            if (ctx->scanner && sre_hip_scanner_engine(ctx->scanner) != SRE_HIP_ENGINE_SCAN) ctx->scanner = NULL;
+            ctx->scanner = compat_scanner(ctx->prog, SRE_HIP_THOMPSON);
         }
         DeviceStream *ds = ctx->ds;
         if (ctx->scanner) {

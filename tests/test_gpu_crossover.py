@@ -1,0 +1,87 @@
+"""Small-input behaviour of the unchanged C API: one
+sre_vm_pike_exec / sre_vm_thompson_exec call on a host buffer of 64 B .. 1 MiB,
+this library against the real reference (oracle/_ref/libsregex_ref.so) on the same
+box.  Writes the measured table to gpurun_out/crossover.json (copied to profiles/)
+and checks that at no size the library is slower than the reference's single core
+by more than a launch + sync latency budget."""
+import ctypes
+import json
+import os
+import sys
+import time
+
+import pytest
+
+import sregex_amd as S
+import harness
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [64, 1024, 32 * 1024, 1 << 20]
+LATENCY_BUDGET_US = 150.0       # one H2D copy + kernel launches + one stream sync of a synchronous exec()
+
+
+def _ref():
+    sys.path.insert(0, os.path.join(harness.HERE, "golden"))
+    import make_goldens
+    if not os.path.exists(os.path.join(make_goldens.REFDIR, "libsregex_ref.so")):
+        pytest.skip("oracle/_ref not built")
+    return make_goldens.RefLib()
+
+
+def _time(fn, reps):
+    fn()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    return (time.perf_counter() - t0) / reps
+
+
+def test_small_input_crossover_vs_reference(lib):
+    assert lib.sre_hip_device_count() >= 1
+    ref = _ref()
+    rows = []
+    cases = [("cfg2 no match", [rb"[a-z]+@[a-z]+\.[a-z]+"], b"aaabbccb"),
+             ("cfg2 match at the end", [rb"[a-z]+@[a-z]+\.[a-z]+"], b" a@abc.cc "),
+             ("leak-free bench pattern", [rb"(?:a|b)aa(?:aa|bb)cc(?:a|b)"], b"aaabbccb")]
+    for name, pats, tail in cases:
+        rpool, rprog, rncaps = ref.compile(pats)
+        with S.Pool() as pool:
+            re = S.parse(pool, pats)
+            prog = S.compile(pool, re)
+            for n in SIZES:
+                data = S.gen_data_host(n, tail)
+                reps = 200 if n <= 1024 else 40 if n <= 32768 else 5
+                want = ref.pike_first(rprog, rncaps, data)
+
+                def ours():
+                    with S.Pool() as ep:
+                        p = S.PikeCtx(ep, prog, re.ncaps)
+                        rc = p.exec(data, True, want_pending=False)
+                        return rc, list(p.ovector)
+
+                rc, ov = ours()
+                assert rc == want[0] and (rc < 0 or ov == want[1]), (name, n, rc, ov, want)
+                t_ours = _time(ours, reps)
+                t_ref = _time(lambda: ref.pike_first(rprog, rncaps, data), max(2, reps // 4))
+                def ours_th():
+                    with S.Pool() as ep:
+                        return S.ThompsonCtx(ep, prog).exec(data, True)
+
+                assert ours_th() == ref.thompson(rprog, data)
+                t_ours_th = _time(ours_th, reps)
+                t_ref_th = _time(lambda: ref.thompson(rprog, data), max(2, reps // 4))
+                rows.append({"case": name, "bytes": len(data),
+                             "pike_us": t_ours * 1e6, "ref_pike_us": t_ref * 1e6,
+                             "thompson_us": t_ours_th * 1e6, "ref_thompson_us": t_ref_th * 1e6,
+                             "pike_MBps": len(data) / t_ours / 1e6, "ref_pike_MBps": len(data) / t_ref / 1e6})
+        ref.L.sre_destroy_pool(rpool)
+    out = os.path.join(harness.ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "crossover.json"), "w") as f:
+        json.dump({"latency_budget_us": LATENCY_BUDGET_US, "rows": rows}, f, indent=1)
+    for r in rows:
+        print(r)
+    slow = [r for r in rows if r["pike_us"] > r["ref_pike_us"] + LATENCY_BUDGET_US
+            or r["thompson_us"] > r["ref_thompson_us"] + LATENCY_BUDGET_US]
+    assert not slow, slow

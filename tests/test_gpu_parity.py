@@ -274,6 +274,36 @@ def test_scanner_count_long_pending_match_converges_quickly(gpu):
             assert sc.last_fixups <= 4, (pat, sc.last_fixups)
 
 
+def test_scanner_automaton_that_never_forgets_gets_exact_entry_states(gpu):
+    """x(?:[^y]{3})*y behind an 'x': the state rotates with the input (period 3, which
+    does not divide the segment size), so every speculative lane behind the x is wrong
+    and a fix-up round is only sure to repair one segment.  After two rounds the
+    scanner composes the segments' transition functions on the device and finishes in
+    ONE exact pass (round-1 advisor finding: the rounds used to be linear in the
+    number of segments, each with a host round trip)."""
+    ora = harness.OracleEngine()
+    cases = [([rb"x(?:[^y]{3})*y"], b"ab" * 50 + b"x" + b"abc" * 20000 + b"ab" + b"y" + b"zz"),
+             ([rb"x(?:[^y]{3})*y"], b"x" + b"abc" * 20000 + b"y" + b"zz"),
+             ([rb"(a)(?:[bc]{2})*(d)"], b"q" * 777 + b"a" + b"bc" * 30001 + b"bd" + b"bc" * 5000)]
+    for seg in (256, 1280):
+        for pats, data in cases:
+            with S.Pool() as pool:
+                re = S.parse(pool, pats)
+                prog = S.compile(pool, re)
+                first, cnt = _expect(ora, prog, re.ncaps, data)
+                buf = S.DeviceBuffer.from_bytes(data)
+                for mode, want in ((S.HIP_PIKE_FIRST, first), (S.HIP_THOMPSON, None)):
+                    sc = S.Scanner(pool, prog, mode, S.ENGINE_SCAN)
+                    sc.set_segment_bytes(seg)
+                    rec = sc.scan([buf.ptr], [len(data)])[0]
+                    if want is None:
+                        assert rec[0] == (0 if first[0] >= 0 else S.SRE_DECLINED), (pats, seg, rec)
+                    else:
+                        assert rec == want, (pats, seg, rec, want)
+                    assert sc.last_fixups <= 4, (pats, seg, mode, sc.last_fixups)
+                buf.free()
+
+
 @pytest.mark.parametrize("seg", [64, 4096])
 def test_scanner_long_lineage_uses_ancestor_maps(gpu, seg):
     """A match that starts at offset 0 and ends at the far end of the stream:
