@@ -14,6 +14,9 @@ Workload (BASELINE.json):
           the only collective is one RCCL all-reduce of the per-rank match counts.
 A step = one complete scan of the rank's resident input through the public
 batched C ABI (sre_hip_scan_enqueue + sre_hip_scan_results), results included.
+roofline.frac is the WHOLE step against the HBM peak (all kernels, copies and gaps
+of a step: bytes / wall time per step); roofline.kernel_frac is the dominant scan
+kernel alone (hipEvents around its launch).
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -160,6 +163,12 @@ class Resident:
 
     def __init__(self, torch, lib, hstream):
         self.torch, self.lib, self.hstream, self.bufs = torch, lib, hstream, []
+        self._side = None
+
+    def side_stream(self):
+        if self._side is None:
+            self._side = self.torch.cuda.Stream()
+        return self._side
 
     def fill(self, lens, tails):
         need = [max(n, 16) for n in lens]
@@ -179,20 +188,30 @@ def measure(spec, S, torch, res, hstream, stream, steps, warmup, barrier):
     lens = spec["lens"]
     pool = S.Pool()
     prog = S.compile(pool, S.parse(pool, spec["pats"]))
-    # two scanners take turns: step i is queued before the results of step i-1
-    # are collected (they travel to pinned memory as part of the queued work),
-    # so the GPU goes from one pass straight into the next
+    # two scanners take turns, each on its own HIP stream: step i is queued before the
+    # results of step i-1 are collected (they travel to pinned memory as part of the
+    # queued work), and the small kernels behind a scan (chain check, captures, the copy
+    # of the records) overlap with the next scan instead of sitting between two of them
     scs = [S.Scanner(pool, prog, spec["mode"], S.ENGINE_AUTO) for _ in range(2)]
     sc = scs[0]
     if sc.engine == S.ENGINE_VM and sum(lens) > (64 << 20):
         pool.destroy()
         raise RuntimeError("no throughput engine admits this program: the exact VM runs at MB/s, not benchmarked at this size")
+    side = res.side_stream()
+    hs = [hstream, ctypes.c_void_p(side.cuda_stream)]
+    if len(lens) > 1 or os.environ.get("SRE_BENCH_ONE_STREAM"):
+        # many streams per call: the tail kernels (one capture walker per stream) are heavy
+        # enough to slow the overlapped scan down by more than they hide (measured on one
+        # box, 128 x 64 MiB: 1.79 ms per step on two streams, 1.69 on one) — one stream
+        hs[1] = hstream
 
     def run(nsteps):
         recs, kms, inflight = None, [], None
         for i in range(nsteps):
             cur = scs[i % 2]
-            cur.enqueue(ptrs, lens, hstream)
+            if inflight is not None:
+                inflight.order_after_scan(hs[i % 2])    # scan kernels one after the other, tails overlapped
+            cur.enqueue(ptrs, lens, hs[i % 2])
             if inflight is not None:
                 recs = inflight.results()
                 kms.append(inflight.last_kernel_ms)
@@ -202,20 +221,20 @@ def measure(spec, S, torch, res, hstream, stream, steps, warmup, barrier):
             kms.append(inflight.last_kernel_ms)
         return recs, kms
 
+    torch.cuda.synchronize()            # the input was generated on the main stream
     recs, _ = run(max(warmup, 2))       # both scanners allocate their buffers outside the timed region
     spec["check"](recs)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     barrier()
     t0 = time.perf_counter()
-    ev0.record(stream)
     recs, kernel_ms = run(steps)
-    ev1.record(stream)
     barrier()
     dt = time.perf_counter() - t0
     spec["check"](recs)
     total = sum(lens)
     kms = sum(kernel_ms) / len(kernel_ms)
-    step_gpu_ms = ev0.elapsed_time(ev1) / steps     # every kernel and copy of a step, and the gaps between them
+    # whole step: every kernel and copy of a step and whatever idles between them — the
+    # wall clock over the K steps (two streams: no single stream sees all of it)
+    step_gpu_ms = dt / steps * 1e3
     out = dict(dt=dt, total=total, recs=recs, kernel_ms=kms, step_gpu_ms=step_gpu_ms,
                matches=sum(1 for r in recs if r[0] >= 0),
                segment_bytes=sc.last_segment_bytes, fixup_rounds=sc.last_fixups,
@@ -230,7 +249,7 @@ def roofline(m):
     scan = m["total"] / (m["kernel_ms"] * 1e-3) / 1e9 if m["kernel_ms"] > 0 else None
     return {"bound": "hbm", "achieved": whole, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": whole / HBM_PEAK_GBS, "traffic": None,
-            "step_gpu_ms": m["step_gpu_ms"], "kernel": m["kernel"], "kernel_ms": m["kernel_ms"],
+            "step_ms": m["step_gpu_ms"], "kernel": m["kernel"], "kernel_ms": m["kernel_ms"],
             "kernel_achieved": scan, "kernel_frac": scan / HBM_PEAK_GBS if scan else None,
             "algorithmic_bytes_per_launch": m["total"]}
 
@@ -324,7 +343,7 @@ def main():
             # MI355X_MICROARCH.md HBM section) + WRITE_SIZE, KB -> bytes.  A stored
             # measurement (PMC counters cannot be read from inside the run): source named.
             pj = json.load(open(prof))
-            pm = {(r["counter"], "sre_k_scan<1, 2>" in r["kernel"]): r["mean_value_KB"] for r in pj["counters"]}
+            pm = {(r["counter"], "sre_k_scan<1, 2" in r["kernel"]): r["mean_value_KB"] for r in pj["counters"]}
             if ("FETCH_SIZE", True) in pm:
                 line["roofline"]["traffic"] = (2 * pm[("FETCH_SIZE", True)] + pm[("WRITE_SIZE", True)]) * 1024
                 line["roofline"]["traffic_source"] = "profiles/r02_pmc_hbm.json (commit %s, %s)" % (
@@ -363,7 +382,7 @@ def main():
                     vm = measure(vs, S, torch, res, hstream, stream, min(args.steps, 6), 2, barrier)
                     r = roofline(vm)
                     variants[name] = {"workload": vs["text"], "ms_per_step": vm["dt"] / min(args.steps, 6) * 1e3,
-                                      "step_gpu_ms": vm["step_gpu_ms"], "GBps": r["achieved"], "frac": r["frac"],
+                                      "GBps": r["achieved"], "frac": r["frac"],
                                       "kernel": vm["kernel"], "kernel_ms": vm["kernel_ms"],
                                       "kernel_frac": r["kernel_frac"], "engine": vm["engine"],
                                       "matches": vm["matches"], "fixup_rounds": vm["fixup_rounds"],

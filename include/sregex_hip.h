@@ -96,6 +96,16 @@ SRE_API const char *sre_hip_scanner_kernel_name(sre_hip_scanner_t *sc);
  * -1 when the exact VM engine ran.  Waits for the kernel. */
 SRE_API double sre_hip_scanner_last_kernel_ms(sre_hip_scanner_t *sc);
 
+/*
+ * Make `hip_stream` wait until the dominant (segment-scan) kernel of sc's last enqueued
+ * scan has finished — not for the small kernels and copies behind it.  A driver that
+ * alternates two scanners on two streams calls this on the OTHER scanner before each
+ * enqueue: the big kernels then run one after the other (neither is slowed down by
+ * sharing the GPU), while the chain check, the capture walk and the copy of the
+ * records of one step overlap with the scan of the next.  No-op before the first scan.
+ */
+SRE_API int sre_hip_scanner_order_after_scan(sre_hip_scanner_t *sc, void *hip_stream);
+
 /* segment size the last scan used (0 for the VM engine) */
 SRE_API size_t sre_hip_scanner_last_segment_bytes(sre_hip_scanner_t *sc);
 

@@ -65,6 +65,7 @@ API = {
     "sre_hip_scanner_kernel_name": (ctypes.c_char_p, [_vp]),
     "sre_hip_scanner_last_kernel_ms": (ctypes.c_double, [_vp]),
     "sre_hip_scanner_last_segment_bytes": (_sz, [_vp]),
+    "sre_hip_scanner_order_after_scan": (ctypes.c_int, [_vp, _vp]),
     "sre_hip_scan_enqueue": (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_sz), _sz, _vp]),
     "sre_hip_scan_results": (ctypes.c_int, [_vp, _pssz]),
     "sre_hip_scan_batch": (ctypes.c_int, [_vp, ctypes.POINTER(_vp), ctypes.POINTER(_sz), _sz, _pssz, _vp]),
@@ -95,6 +96,8 @@ def load_library(path=None):
             "(or __graft_entry__.build()); there is no pure-Python matcher" % p)
     lib = ctypes.CDLL(p)
     for name, (res, args) in API.items():
+        if os.environ.get("SREGEX_AMD_LIB") and not hasattr(lib, name):
+            continue                 # an older build given for an A/B run (tools/exp_knobs.sh)
         fn = getattr(lib, name)      # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args
@@ -314,6 +317,11 @@ class Scanner:
     @property
     def last_fixups(self):
         return self.lib.sre_hip_scanner_last_fixups(self.h)
+
+    def order_after_scan(self, hip_stream):
+        """make hip_stream wait for this scanner's last scan kernel (see sregex_hip.h)"""
+        if self.lib.sre_hip_scanner_order_after_scan(self.h, hip_stream) != 0:
+            raise RuntimeError("sre_hip_scanner_order_after_scan failed")
 
     def enqueue(self, d_ptrs, lens, hip_stream=None):
         n = len(d_ptrs)

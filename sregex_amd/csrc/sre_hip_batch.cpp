@@ -260,8 +260,9 @@ sre_hip_scanner_kernel_name(sre_hip_scanner_t *sc)
 {
     if (sc->kernel_name[0] == 0) {
         if (sc->engine == SRE_HIP_ENGINE_SCAN) {
-            snprintf(sc->kernel_name, sizeof(sc->kernel_name), "sre_k_scan<%d, %d>",
-                     sc->mode == SRE_HIP_PIKE_COUNT ? 2 : 1, (int) sc->tab->h.class_bits);
+            snprintf(sc->kernel_name, sizeof(sc->kernel_name), "sre_k_scan<%d, %d, %s>",
+                     sc->mode == SRE_HIP_PIKE_COUNT ? 2 : 1, (int) sc->tab->h.class_bits,
+                     sc->tab->h.wide ? "true" : "false");
         } else if (sc->engine == SRE_HIP_ENGINE_NFA) {
             sre_nfa_kernel_name(sc->mode, sc->ntab.nslices, sc->kernel_name, sizeof(sc->kernel_name));
         } else {
@@ -286,6 +287,14 @@ sre_hip_scanner_last_kernel_ms(sre_hip_scanner_t *sc)
     if (hipEventSynchronize(sc->ev1) != hipSuccess) return -1.0;
     if (hipEventElapsedTime(&ms, sc->ev0, sc->ev1) != hipSuccess) return -1.0;
     return (double) ms;
+}
+
+extern "C" SRE_API int
+sre_hip_scanner_order_after_scan(sre_hip_scanner_t *sc, void *hip_stream)
+{
+    if (!sc->ev_valid) return 0;
+    hipError_t e = hipStreamWaitEvent(static_cast<hipStream_t>(hip_stream), sc->ev1, 0);
+    return e == hipSuccess ? 0 : sre_hip_fail("hipStreamWaitEvent", e);
 }
 
 extern "C" SRE_API size_t
@@ -457,7 +466,7 @@ nfa_finish(sre_hip_scanner_t *sc, const int64_t *d_lo, hipStream_t stream)
                                       sc->d_belief, sc->d_bvalid, sc->d_records, sc->ovec_slots, d_lo, stream));
     if (sc->mode != SRE_HIP_THOMPSON) {
         /* (the window kernel zero-fills the context it uses) */
-        SRE_HIP_TRY(sre_launch_pike_window(sc->dp->d_blob, sc->d_ptrs, sc->d_lens, n, sc->d_ctx, sc->ctx_stride,
+        SRE_HIP_TRY(sre_launch_pike_window(sc->dp->d_blob, sc->dp->blob_bytes, sc->d_ptrs, sc->d_lens, n, sc->d_ctx, sc->ctx_stride,
                                            sc->d_records, sc->ovec_slots,
                                            reinterpret_cast<sre_nfa_window_t *>(sc->d_nstatus), d_lo, stream));
     }

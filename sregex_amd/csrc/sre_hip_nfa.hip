@@ -198,7 +198,7 @@ sre_k_nfa(sre_nfa_tables_t T, sre_scan_geom_t G, sre_nfa_summary_t *__restrict__
     for (uint32_t s = 0; s <= nrounds; s++) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        tile_store<8>(regs, tile, nullptr, tid, s);
+        tile_store<8, false>(regs, tile, nullptr, tid, s);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         if (s < nrounds) tile_fetch(regs, rows, tid, s + 1);
@@ -328,14 +328,23 @@ sre_k_nfa_verify_a(sre_scan_geom_t G, const sre_nfa_summary_t *__restrict__ sum,
     if (sum[g].first_ev >= 0) atomicMin(&acc[s].end, (unsigned long long) k);
 }
 
-__global__ __launch_bounds__(256) void
+__global__ __launch_bounds__(1024) void
 sre_k_nfa_verify_b(sre_scan_geom_t G, const sre_nfa_summary_t *__restrict__ sum, NfaAcc *__restrict__ acc)
 {
-    const uint64_t g = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    /* nearly every segment has a clean position, and they all go to one address per
+     * stream: reduce in the wave, then in the workgroup (1024 segments), then one atomic */
+    __shared__ unsigned long long sh_max;
+    const uint64_t g0 = (uint64_t) blockIdx.x * blockDim.x;
+    const uint64_t g = g0 + threadIdx.x;
+    const uint64_t glast = (g0 + blockDim.x - 1 < G.nsegs) ? g0 + blockDim.x - 1 : G.nsegs - 1;
+    const uint32_t s_first = nfa_stream_of(G, g0), s_last = nfa_stream_of(G, glast);
+    const bool     uniform = (s_first == s_last);
+    if (threadIdx.x == 0) sh_max = 0;
+    __syncthreads();
     unsigned long long mine = 0;
-    uint32_t           s = 0;
+    uint32_t           s = s_first;
     if (g < G.nsegs) {
-        s = nfa_stream_of(G, g);
+        if (!uniform) s = nfa_stream_of(G, g);
         const uint64_t k = g - G.seg_first[s];
         const uint64_t nseg = G.seg_first[s + 1] - G.seg_first[s];
         uint64_t       bad = acc[s].bad, end = acc[s].end;
@@ -344,16 +353,15 @@ sre_k_nfa_verify_b(sre_scan_geom_t G, const sre_nfa_summary_t *__restrict__ sum,
         const uint64_t limit = end < bad ? end + 1 : bad;
         if (k < limit && sum[g].last_clean >= 0) mine = (unsigned long long) sum[g].last_clean + 1;    /* position * 2 + mode */
     }
-    /* one atomic per wave and stream (nearly every segment has a clean position) */
-    const uint32_t     s0 = __shfl(s, 0, 64);
-    unsigned long long red = (s == s0) ? mine : 0;
-    for (int d = 32; d >= 1; d >>= 1) {
-        const unsigned long long o = __shfl_down(red, d, 64);
-        red = o > red ? o : red;
-    }
-    if ((threadIdx.x & 63u) == 0) {
-        if (red) atomicMax(&acc[s0].clean, red);
-    } else if (s != s0 && mine) {
+    if (uniform) {
+        for (int d = 32; d >= 1; d >>= 1) {
+            const unsigned long long o = __shfl_down(mine, d, 64);
+            mine = o > mine ? o : mine;
+        }
+        if ((threadIdx.x & 63u) == 0 && mine) atomicMax(&sh_max, mine);
+        __syncthreads();
+        if (threadIdx.x == 0 && sh_max) atomicMax(&acc[s_first].clean, sh_max);
+    } else if (mine) {
         atomicMax(&acc[s].clean, mine);
     }
 }
@@ -496,7 +504,8 @@ sre_launch_nfa_verify(int mode, sre_scan_geom_t geom, const sre_nfa_summary_t *d
     NfaAcc        *acc = static_cast<NfaAcc *>(d_acc);
     const uint32_t gseg = (uint32_t) ((geom.nsegs + 255) / 256);
     hipLaunchKernelGGL(sre_k_nfa_verify_a, dim3(gseg), dim3(256), 0, stream, geom, d_sum, acc, d_belief, d_bvalid);
-    hipLaunchKernelGGL(sre_k_nfa_verify_b, dim3(gseg), dim3(256), 0, stream, geom, d_sum, acc);
+    hipLaunchKernelGGL(sre_k_nfa_verify_b, dim3((uint32_t) ((geom.nsegs + 1023) / 1024)), dim3(1024), 0, stream,
+                       geom, d_sum, acc);
     hipLaunchKernelGGL(sre_k_nfa_verify_c, dim3((geom.nstreams + 63) / 64), dim3(64), 0, stream, mode, geom,
                        d_sum, acc, d_status, d_records, ovec_slots, d_lo);
     return hipGetLastError();

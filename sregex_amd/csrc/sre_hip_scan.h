@@ -92,7 +92,9 @@ typedef struct {
     const uint32_t        *multi_ncaps; /* [nregexes] */
     uint32_t nregexes;
     uint32_t nshadow;                   /* shadow rows in the LDS fast table (FIRST / Thompson tables) */
-    uint32_t fast_rows, pad4;           /* rows of the scan kernel's LDS copy: nstates + 1 (trap) + nshadow */
+    uint32_t fast_rows;                 /* rows of the scan kernel's LDS copy: nstates + 1 (trap) + nshadow */
+    uint32_t wide;                      /* the staging tile holds 16-bit pre-scaled indices (sre_hip_tile.h): always with
+                                           <= 2 class bits; with 4 in COUNT mode when two workgroups per CU still fit */
     uint8_t  shadow_state[SRE_SCAN_MAX_SHADOWS];    /* the state each of them copies */
     const uint16_t        *neutral;     /* [nstates] bit j: thread j of the state's list descends from itself,
                                            without a save, in every STABLE step of the state (0: none) */

@@ -458,7 +458,7 @@ byte_x4(uint32_t v, uint32_t sh)
  * warm-up: the 128 bytes (one line) in front of the segment, walked with the
  * same fast loop, nothing recorded.
  */
-template <int MODE, int BITS>
+template <int MODE, int BITS, bool WIDE>
 __global__ __launch_bounds__(SRE_SCAN_BLOCK, MODE == SRE_HIP_PIKE_COUNT ? 3 : 4) void
 sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
            sre_seg_summary_t *__restrict__ sum, const int64_t *__restrict__ lo,
@@ -467,7 +467,6 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
     constexpr int      TILE = SRE_SCAN_ROUND;
     constexpr int      WARM = SRE_SCAN_LINE;         /* warm-up bytes in front of a segment */
     constexpr int      STRIDE = 8 / BITS;
-    constexpr bool     WIDE = SRE_TILE_WIDE(BITS);   /* 16-bit pre-scaled indices (see tile_store) */
     constexpr uint32_t ROWRAW = TILE / STRIDE * (WIDE ? 2 : 1);  /* index bytes per round */
     constexpr uint32_t ROWB = 2 * ROWRAW + 16;       /* see tile_store */
     constexpr int      GIDX = 16 / STRIDE;           /* indices per 16 input bytes */
@@ -730,7 +729,7 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
          * compiler from moving tile reads across the stores */
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        tile_store<BITS>(regs, tile, clsx, tid, s);
+        tile_store<BITS, WIDE>(regs, tile, clsx, tid, s);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         /* the next stage's HBM loads fly while this round is consumed from LDS */
@@ -1105,7 +1104,7 @@ sre_k_verify_a(sre_scan_geom_t G, const sre_seg_summary_t *__restrict__ sum, Ver
     if (sum[g].flags & SRE_SUM_TERM) atomicMin(&acc[s].end, (unsigned long long) k);
 }
 
-__global__ __launch_bounds__(256) void
+__global__ __launch_bounds__(1024) void
 sre_k_verify_b(sre_scan_geom_t G, const sre_seg_summary_t *__restrict__ sum, VerifyAcc *__restrict__ acc)
 {
     __shared__ unsigned long long sh_count, sh_ev, sh_sp;
@@ -1168,29 +1167,34 @@ sre_k_verify_b(sre_scan_geom_t G, const sre_seg_summary_t *__restrict__ sum, Ver
 /* FIRST: the last segment in front of the event's that is not SRE_SUM_STABLE — between
  * the two the automaton sat in one state whose neutral threads looped in place, and the
  * capture walker crosses all of them in one jump */
-__global__ __launch_bounds__(256) void
+__global__ __launch_bounds__(1024) void
 sre_k_verify_b2(sre_scan_geom_t G, const sre_seg_summary_t *__restrict__ sum, VerifyAcc *__restrict__ acc)
 {
-    const uint64_t g = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ unsigned long long sh_max;
+    const uint64_t g0 = (uint64_t) blockIdx.x * blockDim.x;
+    const uint64_t g = g0 + threadIdx.x;
+    const uint64_t glast = (g0 + blockDim.x - 1 < G.nsegs) ? g0 + blockDim.x - 1 : G.nsegs - 1;
+    const uint32_t s_first = stream_of(G, g0), s_last = stream_of(G, glast);
+    const bool     uniform = (s_first == s_last);       /* whole block inside one stream */
+    if (threadIdx.x == 0) sh_max = 0;
+    __syncthreads();
     unsigned long long mine = 0;
-    uint32_t           s = 0;
+    uint32_t           s = s_first;
     if (g < G.nsegs) {
-        s = stream_of(G, g);
+        if (!uniform) s = stream_of(G, g);
         const uint64_t k = g - G.seg_first[s];
         const uint64_t evseg = acc[s].evseg;        /* 1 + the event's segment, 0 none */
         if (evseg != 0 && k + 1 < evseg && !(sum[g].flags & SRE_SUM_STABLE)) mine = k + 1;
     }
-    /* one atomic per wave and stream: lanes of a wave that share the stream of its first
-     * lane are reduced first (on a stream of unstable segments every lane has a value) */
-    const uint32_t s0 = __shfl(s, 0, 64);
-    unsigned long long red = (s == s0) ? mine : 0;
-    for (int d = 32; d >= 1; d >>= 1) {
-        const unsigned long long o = __shfl_down(red, d, 64);
-        red = o > red ? o : red;
-    }
-    if ((threadIdx.x & 63u) == 0) {
-        if (red) atomicMax(&acc[s0].unst, red);
-    } else if (s != s0 && mine) {
+    if (uniform) {
+        for (int d = 32; d >= 1; d >>= 1) {
+            const unsigned long long o = __shfl_down(mine, d, 64);
+            mine = o > mine ? o : mine;
+        }
+        if ((threadIdx.x & 63u) == 0 && mine) atomicMax(&sh_max, mine);
+        __syncthreads();
+        if (threadIdx.x == 0 && sh_max) atomicMax(&acc[s_first].unst, sh_max);
+    } else if (mine) {
         atomicMax(&acc[s].unst, mine);
     }
 }
@@ -1836,22 +1840,23 @@ typedef void (*sre_scan_kernel_t)(const sre_scan_tables_t *, sre_scan_geom_t, sr
 
 template <int MODE>
 static sre_scan_kernel_t
-scan_kernel_bits(uint32_t bits)
+scan_kernel_bits(uint32_t bits, bool wide4)
 {
     switch (bits) {
-    case 1: return sre_k_scan<MODE, 1>;
-    case 2: return sre_k_scan<MODE, 2>;
-    case 4: return sre_k_scan<MODE, 4>;
-    default: return sre_k_scan<MODE, 8>;
+    case 1: return sre_k_scan<MODE, 1, true>;
+    case 2: return sre_k_scan<MODE, 2, true>;
+    case 4: return (MODE == SRE_HIP_PIKE_COUNT && wide4) ? sre_k_scan<MODE, 4, (MODE == SRE_HIP_PIKE_COUNT)>
+                                                         : sre_k_scan<MODE, 4, false>;
+    default: return sre_k_scan<MODE, 8, false>;
     }
 }
 
-/* the variant that runs for these tables: [mode][class bits] */
+/* the variant that runs for these tables: [mode][class bits][tile index width] */
 static sre_scan_kernel_t
 scan_kernel(const sre_scan_tables_t *h_tab)
 {
-    return h_tab->mode == SRE_HIP_PIKE_COUNT ? scan_kernel_bits<SRE_HIP_PIKE_COUNT>(h_tab->class_bits)
-                                             : scan_kernel_bits<1>(h_tab->class_bits);
+    return h_tab->mode == SRE_HIP_PIKE_COUNT ? scan_kernel_bits<SRE_HIP_PIKE_COUNT>(h_tab->class_bits, h_tab->wide != 0)
+                                             : scan_kernel_bits<1>(h_tab->class_bits, false);
 }
 
 extern "C" size_t
@@ -1860,7 +1865,7 @@ sre_scan_lds_bytes(const sre_scan_tables_t *h_tab)
     const size_t tr = ((size_t) h_tab->nstates * (h_tab->ncls + 1) * 2 + 15) & ~(size_t) 15;
     /* index tile row: the two halves of a line as raw bytes (8 class bits) or
      * 16-bit scaled indices, plus the pad */
-    const size_t half = (size_t) SRE_SCAN_ROUND * h_tab->class_bits / 8 * (SRE_TILE_WIDE(h_tab->class_bits) ? 2 : 1);
+    const size_t half = (size_t) SRE_SCAN_ROUND * h_tab->class_bits / 8 * (h_tab->wide ? 2 : 1);
     /* [fast rows][class map][transitions][state flags][tile] */
     static const char *pad_env = getenv("SRE_HIP_LDS_PAD");      /* experiment knob: fewer workgroups per CU */
     const size_t pad = pad_env ? (size_t) atoi(pad_env) : 0;
@@ -1897,8 +1902,8 @@ sre_launch_scan(const sre_scan_tables_t *d_tab, sre_scan_tables_t h_tab, sre_sca
     const size_t   shmem = sre_scan_lds_bytes(&h_tab);
     if (shmem > 48 * 1024) {
         /* more than the default dynamic LDS limit: opt in (once per variant) */
-        static bool raised[2][9];
-        bool       &done = raised[h_tab.mode == SRE_HIP_PIKE_COUNT][h_tab.class_bits & 8 ? 8 : h_tab.class_bits];
+        static bool raised[2][9][2];
+        bool       &done = raised[h_tab.mode == SRE_HIP_PIKE_COUNT][h_tab.class_bits & 8 ? 8 : h_tab.class_bits][h_tab.wide != 0];
         if (!done) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(scan_kernel(&h_tab)),
                                                hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1939,9 +1944,12 @@ sre_launch_verify(sre_scan_tables_t h_tab, sre_scan_geom_t geom, const sre_seg_s
     VerifyAcc *acc = static_cast<VerifyAcc *>(d_acc);
     const uint32_t gseg = (uint32_t) ((geom.nsegs + 255) / 256);
     hipLaunchKernelGGL(sre_k_verify_a, dim3(gseg), dim3(256), 0, stream, geom, d_sum, acc, (int) h_tab.mode);
-    hipLaunchKernelGGL(sre_k_verify_b, dim3(gseg), dim3(256), 0, stream, geom, d_sum, acc);
+    /* 1024 segments per workgroup: one global atomic per workgroup and stream, and these
+     * all land on one address (a 4 GiB stream is 258K segments) */
+    const uint32_t gseg4 = (uint32_t) ((geom.nsegs + 1023) / 1024);
+    hipLaunchKernelGGL(sre_k_verify_b, dim3(gseg4), dim3(1024), 0, stream, geom, d_sum, acc);
     if (h_tab.mode == 1 /* SRE_HIP_PIKE_FIRST */ && h_tab.nshadow) {
-        hipLaunchKernelGGL(sre_k_verify_b2, dim3(gseg), dim3(256), 0, stream, geom, d_sum, acc);
+        hipLaunchKernelGGL(sre_k_verify_b2, dim3(gseg4), dim3(1024), 0, stream, geom, d_sum, acc);
     }
     hipLaunchKernelGGL(sre_k_verify_c, dim3((geom.nstreams + 63) / 64), dim3(64), 0, stream, h_tab,
                        geom, d_sum, acc, d_status);

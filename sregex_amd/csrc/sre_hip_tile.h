@@ -13,13 +13,9 @@
 #include <hip/hip_runtime.h>
 #include "sre_hip_scan.h"
 
-/* class widths whose tile holds 16-bit indices already scaled to a byte offset into a
- * fast-table row (one SDWA add per lookup in the consumer) instead of 8-bit ones */
-#ifndef SRE_TILE_WIDE_MAX_BITS
-#define SRE_TILE_WIDE_MAX_BITS 2
-#endif
-#define SRE_TILE_WIDE(bits) ((bits) <= SRE_TILE_WIDE_MAX_BITS)
-
+/* tile_store<BITS, WIDE>: WIDE = the tile holds 16-bit indices already scaled to a byte
+ * offset into a fast-table row (one SDWA add per lookup in the consumer) instead of 8-bit
+ * ones; chosen per scanner (sre_scan_tables_t.wide) */
 namespace {
 
 /* one row of a workgroup's staging: where the lane's segment (with its warm-up
@@ -76,12 +72,11 @@ tile_fetch(uint4 (&regs)[4], const RowDesc *rows, uint32_t tid, uint32_t stage)
  * lane's dependent chain is table lookups only.  A tile row holds the two
  * 64-byte halves of the row's current line back to back plus a 16-byte pad,
  * which makes the consumer's 16-byte reads bank-conflict free. */
-template <int BITS>
+template <int BITS, bool WIDE>
 __device__ inline void
 tile_store(const uint4 (&regs)[4], uint8_t *tile, const uint16_t (*clsx)[256], uint32_t tid, uint32_t stage)
 {
     constexpr int      STRIDE = 8 / BITS;                       /* input bytes per index */
-    constexpr bool     WIDE = SRE_TILE_WIDE(BITS);              /* 16-bit pre-scaled indices */
     constexpr uint32_t HALFB = SRE_SCAN_ROUND / STRIDE * (WIDE ? 2 : 1);
     constexpr uint32_t ROWB = 2 * HALFB + 16;
     constexpr uint32_t PIECEB = HALFB / 4;                      /* index bytes per 16 input bytes */

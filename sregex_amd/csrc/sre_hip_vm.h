@@ -43,14 +43,14 @@ typedef struct {
 #ifdef __cplusplus
 extern "C" {
 #endif
-hipError_t sre_launch_pike_window(const void *blob, const void *const *d_streams,
+hipError_t sre_launch_pike_window(const void *blob, size_t blob_bytes, const void *const *d_streams,
     const uint64_t *d_lens, uint32_t nstreams, void *d_ctx, uint64_t ctx_stride,
     int64_t *d_records, uint32_t ovec_slots, sre_nfa_window_t *d_win, const int64_t *d_lo,
     hipStream_t stream);
 /* ctx_bytes: size of one stream context (copied into LDS for the call when it fits) */
-hipError_t sre_launch_pike_exec(const void *blob, const sre_dev_req_t *d_reqs,
+hipError_t sre_launch_pike_exec(const void *blob, size_t blob_bytes, const sre_dev_req_t *d_reqs,
     uint32_t nreqs, size_t ctx_bytes, hipStream_t stream);
-hipError_t sre_launch_thompson_exec(const void *blob, const sre_dev_req_t *d_reqs,
+hipError_t sre_launch_thompson_exec(const void *blob, size_t blob_bytes, const sre_dev_req_t *d_reqs,
     uint32_t nreqs, size_t ctx_bytes, hipStream_t stream);
 /* whole-stream scan, one lane per stream; mode = SRE_HIP_THOMPSON / PIKE_FIRST / PIKE_COUNT */
 hipError_t sre_launch_vm_scan(const void *blob, int mode, const void *const *d_streams,

@@ -761,6 +761,18 @@ struct Thompson {
  * byte and thread, and from HBM every one of those is a ~1 us round trip.  A context
  * too large for LDS (thousands of instructions) is worked on in place.
  */
+/* copy the program image into LDS (blob_lds_bytes > 0) and return where to read it */
+__device__ inline const uint8_t *
+stage_blob(const uint8_t *blob, uint8_t *lds, uint32_t blob_lds_bytes)
+{
+    if (blob_lds_bytes == 0) return blob;
+    for (uint32_t i = threadIdx.x * 16; i < blob_lds_bytes; i += blockDim.x * 16) {
+        *reinterpret_cast<uint4 *>(lds + i) = *reinterpret_cast<const uint4 *>(blob + i);
+    }
+    __syncthreads();
+    return lds;
+}
+
 __device__ inline void
 ctx_copy(uint8_t *dst, const uint8_t *src, size_t bytes)
 {
@@ -771,20 +783,22 @@ ctx_copy(uint8_t *dst, const uint8_t *src, size_t bytes)
 
 extern "C" __global__ void
 sre_k_pike_exec(const uint8_t *__restrict__ blob, const sre_dev_req_t *__restrict__ reqs,
-                uint32_t nreqs, uint32_t use_lds)
+                uint32_t nreqs, uint32_t use_lds, uint32_t blob_lds_bytes)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t ctx_lds[];
     const uint32_t i = blockIdx.x;
     if (i >= nreqs) return;
     const sre_dev_req_t rq = reqs[i];
+    /* the program image too: the VM fetches an instruction per thread and step */
+    blob = stage_blob(blob, ctx_lds, blob_lds_bytes);
 
     Pike vm;
     vm.P = prog_view(blob);
     const sre_pike_layout_t L = sre_pike_layout(vm.P.h->len, vm.P.h->nthreads, vm.P.h->nslots);
     uint8_t *home = static_cast<uint8_t *>(rq.ctx);
-    uint8_t *base = use_lds ? ctx_lds : home;
+    uint8_t *base = use_lds ? ctx_lds + blob_lds_bytes : home;
     if (use_lds) {
-        ctx_copy(ctx_lds, home, L.total);
+        ctx_copy(base, home, L.total);
         __syncthreads();
     }
     if (threadIdx.x == 0) {
@@ -807,26 +821,28 @@ sre_k_pike_exec(const uint8_t *__restrict__ blob, const sre_dev_req_t *__restric
     }
     if (use_lds) {
         __syncthreads();
-        ctx_copy(home, ctx_lds, L.total);
+        ctx_copy(home, base, L.total);
     }
 }
 
 extern "C" __global__ void
 sre_k_thompson_exec(const uint8_t *__restrict__ blob, const sre_dev_req_t *__restrict__ reqs,
-                    uint32_t nreqs, uint32_t use_lds)
+                    uint32_t nreqs, uint32_t use_lds, uint32_t blob_lds_bytes)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t ctx_lds[];
     const uint32_t i = blockIdx.x;
     if (i >= nreqs) return;
     const sre_dev_req_t rq = reqs[i];
+    /* the program image too: the VM fetches an instruction per thread and step */
+    blob = stage_blob(blob, ctx_lds, blob_lds_bytes);
 
     Thompson vm;
     vm.P = prog_view(blob);
     const sre_thompson_layout_t L = sre_thompson_layout(vm.P.h->len);
     uint8_t *home = static_cast<uint8_t *>(rq.ctx);
-    uint8_t *base = use_lds ? ctx_lds : home;
+    uint8_t *base = use_lds ? ctx_lds + blob_lds_bytes : home;
     if (use_lds) {
-        ctx_copy(ctx_lds, home, L.total);
+        ctx_copy(base, home, L.total);
         __syncthreads();
     }
     if (threadIdx.x == 0) {
@@ -845,7 +861,7 @@ sre_k_thompson_exec(const uint8_t *__restrict__ blob, const sre_dev_req_t *__res
     }
     if (use_lds) {
         __syncthreads();
-        ctx_copy(home, ctx_lds, L.total);
+        ctx_copy(home, base, L.total);
     }
 }
 
@@ -915,7 +931,8 @@ extern "C" __global__ void
 sre_k_pike_window(const uint8_t *__restrict__ blob, const uint8_t *const *__restrict__ streams,
                   const uint64_t *__restrict__ lens, uint32_t nstreams, uint8_t *ctx_base,
                   uint64_t ctx_stride, int64_t *__restrict__ records, uint32_t ovec_slots,
-                  sre_nfa_window_t *__restrict__ win, const int64_t *__restrict__ lo, uint32_t use_lds)
+                  sre_nfa_window_t *__restrict__ win, const int64_t *__restrict__ lo, uint32_t use_lds,
+                  uint32_t blob_lds_bytes)
 {
     /* one workgroup per stream; the (fresh) context lives in LDS when it fits, see
      * sre_k_pike_exec */
@@ -924,11 +941,12 @@ sre_k_pike_window(const uint8_t *__restrict__ blob, const uint8_t *const *__rest
     if (i >= nstreams) return;
     if (lo != nullptr && lo[i] < 0) return;     /* settled in an earlier round */
     if (!win[i].done || win[i].ev_pos < 0) return;
+    blob = stage_blob(blob, ctx_lds, blob_lds_bytes);
 
     Pike vm;
     vm.P = prog_view(blob);
     const sre_pike_layout_t L = sre_pike_layout(vm.P.h->len, vm.P.h->nthreads, vm.P.h->nslots);
-    uint8_t *base = use_lds ? ctx_lds : ctx_base + (size_t) i * ctx_stride;
+    uint8_t *base = use_lds ? ctx_lds + blob_lds_bytes : ctx_base + (size_t) i * ctx_stride;
     /* zero-filled == fresh */
     for (size_t b = (size_t) threadIdx.x * 16; b < L.total; b += (size_t) blockDim.x * 16) {
         *reinterpret_cast<uint4 *>(base + b) = make_uint4(0, 0, 0, 0);
@@ -960,16 +978,25 @@ sre_k_pike_window(const uint8_t *__restrict__ blob, const uint8_t *const *__rest
     if (rc >= 0 && vm.h->eof) win[i].clean_mode |= SRE_NFA_WINDOW_POISONED;
 }
 
-/* dynamic LDS a one-request VM kernel may take for the context copy */
+/* dynamic LDS a one-request VM kernel may take for the context (and program) copy */
 #define SRE_VM_CTX_LDS_LIMIT (96u * 1024u)
 
+/* bytes of LDS for the program image, 0 when it does not fit next to the context */
+static uint32_t
+vm_blob_lds(size_t blob_bytes, size_t ctx_bytes)
+{
+    const size_t b = (blob_bytes + 15) & ~(size_t) 15, c = (ctx_bytes + 15) & ~(size_t) 15;
+    return (b <= 32 * 1024 && b + c <= SRE_VM_CTX_LDS_LIMIT) ? (uint32_t) b : 0u;
+}
+
 extern "C" hipError_t
-sre_launch_pike_window(const void *blob, const void *const *d_streams, const uint64_t *d_lens,
+sre_launch_pike_window(const void *blob, size_t blob_bytes, const void *const *d_streams, const uint64_t *d_lens,
                        uint32_t nstreams, void *d_ctx, uint64_t ctx_stride, int64_t *d_records,
                        uint32_t ovec_slots, sre_nfa_window_t *d_win, const int64_t *d_lo,
                        hipStream_t stream)
 {
-    const size_t   bytes = ((size_t) ctx_stride + 15) & ~(size_t) 15;
+    const uint32_t blob_lds = vm_blob_lds(blob_bytes, ctx_stride);
+    const size_t   bytes = (((size_t) ctx_stride + 15) & ~(size_t) 15) + blob_lds;
     const uint32_t use_lds = bytes <= SRE_VM_CTX_LDS_LIMIT ? 1u : 0u;
     if (use_lds && bytes > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sre_k_pike_window),
@@ -979,7 +1006,8 @@ sre_launch_pike_window(const void *blob, const void *const *d_streams, const uin
     hipLaunchKernelGGL(sre_k_pike_window, dim3(nstreams), dim3(64), use_lds ? bytes : 0, stream,
                        static_cast<const uint8_t *>(blob),
                        reinterpret_cast<const uint8_t *const *>(d_streams), d_lens, nstreams,
-                       static_cast<uint8_t *>(d_ctx), ctx_stride, d_records, ovec_slots, d_win, d_lo, use_lds);
+                       static_cast<uint8_t *>(d_ctx), ctx_stride, d_records, ovec_slots, d_win, d_lo, use_lds,
+                       use_lds ? blob_lds : 0u);
     return hipGetLastError();
 }
 
@@ -1033,10 +1061,11 @@ sre_launch_vm_scan(const void *blob, int mode, const void *const *d_streams,
 
 template <typename K>
 static hipError_t
-vm_exec_launch(K kernel, const void *blob, const sre_dev_req_t *d_reqs, uint32_t nreqs, size_t ctx_bytes,
-               hipStream_t stream)
+vm_exec_launch(K kernel, const void *blob, size_t blob_bytes, const sre_dev_req_t *d_reqs, uint32_t nreqs,
+               size_t ctx_bytes, hipStream_t stream)
 {
-    const size_t   bytes = (ctx_bytes + 15) & ~(size_t) 15;
+    const uint32_t blob_lds = vm_blob_lds(blob_bytes, ctx_bytes);
+    const size_t   bytes = ((ctx_bytes + 15) & ~(size_t) 15) + blob_lds;
     const uint32_t use_lds = bytes <= SRE_VM_CTX_LDS_LIMIT ? 1u : 0u;
     if (use_lds && bytes > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel),
@@ -1044,20 +1073,20 @@ vm_exec_launch(K kernel, const void *blob, const sre_dev_req_t *d_reqs, uint32_t
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(kernel, dim3(nreqs), dim3(64), use_lds ? bytes : 0, stream,
-                       static_cast<const uint8_t *>(blob), d_reqs, nreqs, use_lds);
+                       static_cast<const uint8_t *>(blob), d_reqs, nreqs, use_lds, use_lds ? blob_lds : 0u);
     return hipGetLastError();
 }
 
 extern "C" hipError_t
-sre_launch_pike_exec(const void *blob, const sre_dev_req_t *d_reqs, uint32_t nreqs, size_t ctx_bytes,
-                     hipStream_t stream)
+sre_launch_pike_exec(const void *blob, size_t blob_bytes, const sre_dev_req_t *d_reqs, uint32_t nreqs,
+                     size_t ctx_bytes, hipStream_t stream)
 {
-    return vm_exec_launch(sre_k_pike_exec, blob, d_reqs, nreqs, ctx_bytes, stream);
+    return vm_exec_launch(sre_k_pike_exec, blob, blob_bytes, d_reqs, nreqs, ctx_bytes, stream);
 }
 
 extern "C" hipError_t
-sre_launch_thompson_exec(const void *blob, const sre_dev_req_t *d_reqs, uint32_t nreqs, size_t ctx_bytes,
-                         hipStream_t stream)
+sre_launch_thompson_exec(const void *blob, size_t blob_bytes, const sre_dev_req_t *d_reqs, uint32_t nreqs,
+                         size_t ctx_bytes, hipStream_t stream)
 {
-    return vm_exec_launch(sre_k_thompson_exec, blob, d_reqs, nreqs, ctx_bytes, stream);
+    return vm_exec_launch(sre_k_thompson_exec, blob, blob_bytes, d_reqs, nreqs, ctx_bytes, stream);
 }

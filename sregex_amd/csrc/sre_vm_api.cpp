@@ -147,7 +147,7 @@ hip_failed:
 int
 device_stream_exec(DeviceStream *ds, const sre_char *input, size_t len, unsigned eof,
                    unsigned want_pending, size_t ovec_slots,
-                   hipError_t (*launch)(const void *, const sre_dev_req_t *, uint32_t, size_t, hipStream_t))
+                   hipError_t (*launch)(const void *, size_t, const sre_dev_req_t *, uint32_t, size_t, hipStream_t))
 {
     sre_dev_req_t *rq = &ds->h_blk->req;
 
@@ -178,7 +178,7 @@ device_stream_exec(DeviceStream *ds, const sre_char *input, size_t len, unsigned
     }
     ds->h_blk->res.rc = SRE_ERROR;
 
-    SRE_HIP_TRY(launch(ds->dp->d_blob, &ds->d_blk->req, 1, ds->ctx_bytes, ds->stream));
+    SRE_HIP_TRY(launch(ds->dp->d_blob, ds->dp->blob_bytes, &ds->d_blk->req, 1, ds->ctx_bytes, ds->stream));
     SRE_HIP_TRY(hipStreamSynchronize(ds->stream));
     return 0;
 
