@@ -45,6 +45,7 @@ struct sre_hip_scanner_s {
     sre_dfa_t                *dfa;
     sre_scan_device_tables_t *tab;
     uint32_t                  seg_override;     /* 0 = automatic */
+    uint64_t                  seg_cap_env;
     sre_scan_geom_t           geom;
     uint64_t                 *d_seg_first, *h_seg_first;
     sre_seg_summary_t        *d_sum;
@@ -385,21 +386,33 @@ scan_geometry(sre_hip_scanner_t *sc, size_t nstreams)
     for (size_t i = 0; i < nstreams; i++) total += sc->h_lens[i];
     uint64_t seg = sc->seg_override;
     {
-        const char *e = getenv("SRE_HIP_SEG_BYTES");        /* experiment knob */
+        const char *e = getenv("SRE_HIP_SEG_BYTES");        /* experiment knobs */
         if (seg == 0 && e && atoi(e) > 0 && atoi(e) % 256 == 0) seg = (uint64_t) atoi(e);
+        e = getenv("SRE_HIP_SEG_CAP");
+        sc->seg_cap_env = e && atoi(e) > 0 ? (uint64_t) atoi(e) : 0;
     }
     if (seg == 0) {
-        /* as few rounds of resident workgroups as keep a segment <= ~16 KiB:
-         * longer segments mean fewer summaries to verify, shorter ones keep
-         * every CU busy; measured flat between 5.5 and 16 KiB on MI355X */
+        /* as few rounds of resident workgroups as keep a segment <= ~40 KiB: longer
+         * segments mean fewer summaries to verify and a smaller share of warm-up,
+         * shorter ones keep every CU busy on small batches */
         if (sc->blocks_per_cu == 0) {
             sc->blocks_per_cu = sc->engine == SRE_HIP_ENGINE_NFA ? sre_nfa_blocks_per_cu(sc->mode, sc->ntab.nslices)
                                                                  : sre_scan_blocks_per_cu(&sc->tab->h);
         }
         const uint64_t resident = 256ull * (uint64_t) sc->blocks_per_cu * SRE_SCAN_BLOCK;
-        uint64_t       rounds = (total + resident * 16384 - 1) / (resident * 16384);
+        /* (measured, one box, 4 GiB: the COUNT kernel at two workgroups per CU takes 1.33 ms
+         * with 16 640-byte segments = two rounds of resident workgroups, 1.25 ms with 33 280 =
+         * one round, and 1.67 ms with 21 760 = one and a half: a whole number of rounds
+         * matters, and one long round beats two short ones; profiles/r02_experiments.txt) */
+        const uint64_t seg_cap = sc->seg_cap_env ? sc->seg_cap_env : 40960;
+        uint64_t       rounds = (total + resident * seg_cap - 1) / (resident * seg_cap);
         if (rounds < 1) rounds = 1;
-        seg = (total / (resident * rounds) + SRE_SCAN_SEG_ALIGN - 1) / SRE_SCAN_SEG_ALIGN * SRE_SCAN_SEG_ALIGN;
+        /* ... and a few workgroup slots are left spare: a grid that needs EVERY slot of its
+         * last round waits a whole extra round for the stragglers when anything else (the
+         * tail kernels of the previous call) holds a slot at launch — 509 workgroups on 512
+         * slots ran 30 % slower than 505 */
+        const uint64_t lanes = resident * rounds - (resident * rounds >> 6);
+        seg = (total / lanes + SRE_SCAN_SEG_ALIGN) / SRE_SCAN_SEG_ALIGN * SRE_SCAN_SEG_ALIGN;
         if (seg < 1024) seg = 1024;
         /* rows that are a multiple of 4 KiB apart land on the same HBM channels */
         if (seg % 4096 == 0) seg += SRE_SCAN_SEG_ALIGN;

@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B runs on ONE box (boxes differ by several percent): experiment knobs.
 #   SRE_HIP_LDS_PAD      extra dynamic LDS per workgroup (fewer workgroups per CU)
-#   SRE_HIP_SEG_BYTES    segment size
+#   SRE_HIP_SEG_BYTES    segment size;  SRE_HIP_SEG_CAP  largest segment the automatic choice makes
 #   SRE_HIP_NO_SHADOW    no shadow rows (stable-stretch tracking off)
 #   SRE_BENCH_ONE_STREAM bench.py: both scanners on one HIP stream
 #   SREGEX_AMD_LIB       another build of the library (an older commit, another tile layout)
@@ -14,7 +14,9 @@ d=json.loads(sys.stdin.read()); r=d['roofline']
 print('step_ms %.4f kernel_ms %.4f frac %.4f kfrac %.4f seg %s' % (r['step_ms'], r['kernel_ms'], r['frac'], r['kernel_frac'], d['config']['segment_bytes']))")
   echo "$CFG $EXTRA | $name | $out"
 }
+for CFG in cfg3 nfa cfg4 cfg2 cfg1; do
+EXTRA=
+one "cap 40960 (default)" A=1; one "cap 16384 (old)" SRE_HIP_SEG_CAP=16384
+done
 CFG=cfg2 EXTRA=--many-streams
-one "two streams" A=1; one "one stream" SRE_BENCH_ONE_STREAM=1; one "two streams" A=1; one "one stream" SRE_BENCH_ONE_STREAM=1
-EXTRA="--many-streams --bytes 2147483648"
-one "two streams 2 GiB" A=1; one "one stream 2 GiB" SRE_BENCH_ONE_STREAM=1
+one "cap 40960 (default)" A=1; one "cap 16384 (old)" SRE_HIP_SEG_CAP=16384
