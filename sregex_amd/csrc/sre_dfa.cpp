@@ -294,11 +294,21 @@ sre_dfa_build(const sre_program_t *prog, uint32_t max_states, const char **why)
 
     /* ---- breadth-first exploration ---- */
     const uint32_t nsym = d->ncls + 1;
+    std::vector<uint32_t> unskip_of;
     for (uint32_t s = 0; s < b.lists.size(); s++) {
         if (b.lists.size() > max_states) {
             *why = "state cap exceeded";
             delete d;
             return NULL;
+        }
+        /* the chunk-boundary twin of a travelling skip (sre_dfa.h `unskip`): interned now so
+         * that it is explored like any other state */
+        if (unskip_of.size() <= s) unskip_of.resize(s + 1, 0);
+        unskip_of[s] = s;
+        if (prog->nleading && prog->lookahead_asserts == 0 && b.sss[s] == 2) {      /* (chunked streams of look-ahead
+                                                                                      programs stay on the exact VM) */
+            const std::vector<uint32_t> Lc = b.lists[s];
+            unskip_of[s] = b.intern(Lc, d->matched[s] != 0, 1, b.variant[s], 0);
         }
         const std::vector<uint32_t> L = b.lists[s];
         const bool                  was_matched = d->matched[s] != 0;
@@ -438,6 +448,11 @@ sre_dfa_build(const sre_program_t *prog, uint32_t max_states, const char **why)
     }
 
     d->nstates = (uint32_t) b.lists.size();
+    unskip_of.resize(d->nstates);
+    for (uint32_t s = 0; s < d->nstates; s++) {
+        if (unskip_of[s] == 0 && s != 0) unskip_of[s] = s;     /* states interned by the last explored ones */
+    }
+    d->unskip = unskip_of;
     d->seen_start = b.sss;
     d->nthreads.resize(d->nstates);
     d->list_off.resize(d->nstates + 1);

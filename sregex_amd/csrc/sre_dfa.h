@@ -78,6 +78,11 @@ struct sre_dfa_s {
     std::vector<uint16_t>        nthreads;   /* [nstates] list length */
     std::vector<uint32_t>        list_off;   /* [nstates + 1] into list_pcs */
     std::vector<uint32_t>        list_pcs;   /* the thread lists themselves (debug / tests) */
+    std::vector<uint32_t>        unskip;     /* [nstates] the state a CHUNK BOUNDARY turns this one into: a
+                                                leading-byte skip that is still travelling (seen_start == 2) ends
+                                                at the end of a chunk, and the next exec() starts with an ordinary
+                                                initial-state check (sre_vm_pike.c:304-306, then :256-273 again):
+                                                same list, seen_start == 1.  Identity elsewhere. */
 
     const sre_dfa_trans_t &t(uint32_t s, uint32_t sym) const { return trans[(size_t) s * (ncls + 1) + sym]; }
 };

@@ -498,6 +498,8 @@ sre_hip_scan_enqueue(sre_hip_scanner_t *sc, const void *const *d_streams, const 
     sc->lineage_passes = 0;
     sc->ev_valid = 0;
     sc->geom.init_variant = sc->next_init_variant;
+    sc->geom.flags = 0;
+    sc->geom.entry_state = 0;
     sc->next_init_variant = 0;
     if (nstreams == 0) {
         sc->last_n = 0;
@@ -563,51 +565,13 @@ hip_failed:
     return -1;
 }
 
-extern "C" SRE_API int
-sre_hip_scan_results(sre_hip_scanner_t *sc, sre_int_t *results)
+/* Segments behind a broken state chain are re-run from the exact carried state until
+ * every stream's verified prefix reaches its end (h_status holds the latest status on
+ * return).  with_captures: the capture kernel runs behind every round. */
+static int
+scan_settle(sre_hip_scanner_t *sc, size_t n, hipStream_t stream, bool with_captures, bool *psettled)
 {
-    if (sc->last_n == 0) return 0;
-    const size_t n = sc->last_n;
-    hipStream_t  stream = sc->last_stream;
-
-    const size_t bytes = n * (2 + (size_t) sc->ovec_slots) * sizeof(int64_t);
-    bool         settled = true;        /* the copies queued by enqueue() are the answer */
-
-    /* everything enqueue() queued for this call, result copies included */
-    SRE_HIP_TRY(hipEventSynchronize(sc->ev_done));
-    if (sc->engine == SRE_HIP_ENGINE_NFA) {
-        /* segments behind a wrong entry set are re-run: the first one from the
-         * exact carried set, the ones behind it from what their predecessor's lane
-         * ended in last round (sets only grow towards the truth, so corrections
-         * travel many segments per round) */
-        for (bool first = true;; first = false) {
-            if (!first) {
-                SRE_HIP_TRY(hipMemcpyAsync(sc->h_nstatus, sc->d_nstatus, n * sizeof(sre_nfa_status_t),
-                                           hipMemcpyDeviceToHost, stream));
-                SRE_HIP_TRY(hipStreamSynchronize(stream));
-            }
-            size_t pending = 0;
-            for (size_t i = 0; i < n; i++) {
-                if (sc->h_nstatus[i].done) {
-                    sc->h_lo[i] = -1;
-                } else {
-                    sc->h_lo[i] = sc->h_nstatus[i].first_bad;
-                    pending++;
-                }
-            }
-            if (pending == 0) break;
-            settled = false;
-            if (++sc->fixup_rounds > 1000000) {
-                fprintf(stderr, "[sregex-hip] NFA scanner fix-up did not converge\n");
-                return -1;
-            }
-            SRE_HIP_TRY(hipMemcpyAsync(sc->d_lo, sc->h_lo, n * sizeof(int64_t), hipMemcpyHostToDevice, stream));
-            SRE_HIP_TRY(sre_launch_nfa_scan(sc->mode, sc->ntab, sc->geom, sc->d_nsum, sc->d_lo, sc->d_belief,
-                                            sc->d_bvalid, stream));
-            if (nfa_finish(sc, sc->d_lo, stream) != 0) return -1;
-        }
-    }
-    if (sc->engine == SRE_HIP_ENGINE_SCAN) {
+    bool settled = true;
         /* segments behind a broken state chain are re-run from the exact carried
          * state until every stream's verified prefix reaches its end */
         for (bool first = true;; first = false) {
@@ -656,10 +620,64 @@ sre_hip_scan_results(sre_hip_scanner_t *sc, sre_int_t *results)
             }
             SRE_HIP_TRY(sre_launch_scan(sc->tab->d_tab, sc->tab->h, sc->geom, sc->d_sum, sc->d_lo, d_entry, stream));
             SRE_HIP_TRY(sre_launch_verify(sc->tab->h, sc->geom, sc->d_sum, sc->d_acc, sc->d_status, stream));
-            SRE_HIP_TRY(sre_launch_captures(sc->tab->d_tab, sc->tab->h, sc->geom, sc->d_sum,
-                                            sc->d_status, sc->d_scratch, sc->d_records,
-                                            sc->ovec_slots, NULL, NULL, 0, stream));
+            if (with_captures) {
+                SRE_HIP_TRY(sre_launch_captures(sc->tab->d_tab, sc->tab->h, sc->geom, sc->d_sum,
+                                                sc->d_status, sc->d_scratch, sc->d_records,
+                                                sc->ovec_slots, NULL, NULL, 0, stream));
+            }
         }
+    if (psettled) *psettled = settled;
+    return 0;
+hip_failed:
+    return -1;
+}
+
+extern "C" SRE_API int
+sre_hip_scan_results(sre_hip_scanner_t *sc, sre_int_t *results)
+{
+    if (sc->last_n == 0) return 0;
+    const size_t n = sc->last_n;
+    hipStream_t  stream = sc->last_stream;
+
+    const size_t bytes = n * (2 + (size_t) sc->ovec_slots) * sizeof(int64_t);
+    bool         settled = true;        /* the copies queued by enqueue() are the answer */
+
+    /* everything enqueue() queued for this call, result copies included */
+    SRE_HIP_TRY(hipEventSynchronize(sc->ev_done));
+    if (sc->engine == SRE_HIP_ENGINE_NFA) {
+        /* segments behind a wrong entry set are re-run: the first one from the
+         * exact carried set, the ones behind it from what their predecessor's lane
+         * ended in last round (sets only grow towards the truth, so corrections
+         * travel many segments per round) */
+        for (bool first = true;; first = false) {
+            if (!first) {
+                SRE_HIP_TRY(hipMemcpyAsync(sc->h_nstatus, sc->d_nstatus, n * sizeof(sre_nfa_status_t),
+                                           hipMemcpyDeviceToHost, stream));
+                SRE_HIP_TRY(hipStreamSynchronize(stream));
+            }
+            size_t pending = 0;
+            for (size_t i = 0; i < n; i++) {
+                if (sc->h_nstatus[i].done) {
+                    sc->h_lo[i] = -1;
+                } else {
+                    sc->h_lo[i] = sc->h_nstatus[i].first_bad;
+                    pending++;
+                }
+            }
+            if (pending == 0) break;
+            settled = false;
+            if (++sc->fixup_rounds > 1000000) {
+                fprintf(stderr, "[sregex-hip] NFA scanner fix-up did not converge\n");
+                return -1;
+            }
+            SRE_HIP_TRY(hipMemcpyAsync(sc->d_lo, sc->h_lo, n * sizeof(int64_t), hipMemcpyHostToDevice, stream));
+            SRE_HIP_TRY(sre_launch_nfa_scan(sc->mode, sc->ntab, sc->geom, sc->d_nsum, sc->d_lo, sc->d_belief,
+                                            sc->d_bvalid, stream));
+            if (nfa_finish(sc, sc->d_lo, stream) != 0) return -1;
+        }
+    }
+    if (sc->engine == SRE_HIP_ENGINE_SCAN) {
+        if (scan_settle(sc, n, stream, true, &settled) != 0) return -1;
         /* a match whose lineage outran the plain backward walk: build the
          * per-segment ancestor maps in parallel and walk again, jumping */
         if (sc->mode != SRE_HIP_THOMPSON) {
@@ -751,6 +769,66 @@ sre_hip_scan_one(sre_hip_scanner_t *sc, const void *d_buf, size_t len, int init_
                   : sc->engine == SRE_HIP_ENGINE_NFA ? (sc->h_nstatus[0].clean_mode & SRE_NFA_WINDOW_POISONED) != 0 : 0;
     }
     return 0;
+}
+
+/*
+ * One CHUNK of one stream through the table-driven scanner, for the chunked use of
+ * sre_vm_pike_exec (sre_vm_api.cpp): scan + chain check (+ fix-up rounds), then
+ * sre_k_stream_tail.  `continues`: the search is under way, `entry_state` is the
+ * automaton state the previous chunk ended in and *d_ctx holds its threads' capture
+ * vectors; otherwise a search starts at the chunk's first byte with `init_variant`.
+ * `base`: absolute stream offset of the chunk.  The result lands in *h_res (pinned,
+ * device-visible as d_res).  Synchronous.
+ */
+extern "C" int
+sre_hip_scan_stream_chunk(sre_hip_scanner_t *sc, const void *d_buf, size_t len, int init_variant,
+    int continues, uint32_t entry_state, int eof, int64_t base, sre_stream_ctx_t *d_ctx,
+    sre_stream_result_t *d_res, const sre_stream_result_t *h_res, uint32_t ovec_slots, hipStream_t stream)
+{
+    if (sc->engine != SRE_HIP_ENGINE_SCAN || sc->mode != SRE_HIP_PIKE_FIRST) return -1;
+    sc->fixup_rounds = 0;
+    sc->exact_passes = 0;
+    sc->lineage_passes = 0;
+    sc->ev_valid = 0;
+    if (scanner_reserve(sc, 1) != 0) return -1;
+    sc->h_ptrs[0] = d_buf;
+    sc->h_lens[0] = len;
+    sc->geom.init_variant = (uint32_t) init_variant;
+    if (scan_geometry(sc, 1) != 0) return -1;
+    sc->geom.flags = (continues ? SRE_GEOM_CONTINUES : 0u) | (eof ? 0u : SRE_GEOM_NO_EOF);
+    sc->geom.entry_state = entry_state;
+    SRE_HIP_TRY(hipMemcpyAsync(sc->d_in, sc->h_in, 4 * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
+    SRE_HIP_TRY(sre_launch_scan(sc->tab->d_tab, sc->tab->h, sc->geom, sc->d_sum, NULL, NULL, stream));
+    SRE_HIP_TRY(sre_launch_verify(sc->tab->h, sc->geom, sc->d_sum, sc->d_acc, sc->d_status, stream));
+    /* the tail runs right behind the chain check; should the speculative entry states of
+     * the chunk's lanes have been wrong (rare), it says so and the rounds are run first */
+    SRE_HIP_TRY(sre_launch_stream_tail(sc->tab->d_tab, sc->tab->h, sc->geom, sc->d_sum, sc->d_status,
+                                       sc->d_scratch, d_ctx, d_res, base, eof, ovec_slots, stream));
+    SRE_HIP_TRY(hipStreamSynchronize(stream));
+    if (h_res->rc == SRE_STREAM_UNSETTLED) {
+        SRE_HIP_TRY(hipMemcpyAsync(sc->h_status, sc->d_status, sizeof(sre_stream_status_t),
+                                   hipMemcpyDeviceToHost, stream));
+        SRE_HIP_TRY(hipStreamSynchronize(stream));
+        if (scan_settle(sc, 1, stream, false, NULL) != 0) goto hip_failed;
+        SRE_HIP_TRY(sre_launch_stream_tail(sc->tab->d_tab, sc->tab->h, sc->geom, sc->d_sum, sc->d_status,
+                                           sc->d_scratch, d_ctx, d_res, base, eof, ovec_slots, stream));
+        SRE_HIP_TRY(hipStreamSynchronize(stream));
+    }
+    sc->geom.flags = 0;
+    sc->last_n = 0;
+    return 0;
+hip_failed:
+    sc->geom.flags = 0;
+    return -1;
+}
+
+/* can chunks of a stream go through this scanner?  (the carried state has room for 16
+ * threads of 64 capture slots) */
+extern "C" int
+sre_hip_scanner_streams(sre_hip_scanner_t *sc)
+{
+    return sc->engine == SRE_HIP_ENGINE_SCAN && sc->mode == SRE_HIP_PIKE_FIRST
+           && sc->tab->h.max_threads <= SRE_STREAM_MAX_THREADS && sc->tab->h.nslots <= SRE_STREAM_MAX_SLOTS;
 }
 
 /* ------------------------------------------------------------------ helpers */

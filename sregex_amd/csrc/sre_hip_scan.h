@@ -41,8 +41,11 @@
  * lane that starts a stretch in a shadow row and is still in one at its end has seen
  * STABLE steps only. */
 #define SRE_SCAN_MAX_SHADOWS  2u
-#define SRE_SCAN_MAX_STATES   54u     /* rows (states + trap + shadows, 1 KiB each) must end below 64 KiB of LDS */
-#define SRE_SCAN_MAX_ROWS     55u
+/* rows (states + trap + shadows, 1 KiB each) must end below 64 KiB of LDS, behind the
+ * kernel's static LDS: the class-map tables (512 bytes per byte position of an index)
+ * and the table header */
+#define SRE_SCAN_MAX_ROWS(bits)   ((65536u - 768u - ((bits) == 8 ? 512u : (8u / (bits)) * 512u)) / 1024u)
+#define SRE_SCAN_MAX_STATES       62u     /* with 8 class bits; fewer with narrower classes */
 #define SRE_SCAN_BLOCK        256u    /* lanes = segments per workgroup */
 #define SRE_SCAN_LDS_LIMIT    (128u * 1024u)  /* dynamic LDS a scan workgroup may ask for (160 KiB per CU) */
 #define SRE_CAPTURE_LDS_LIMIT  (144u * 1024u)  /* ... and the capture walker / lineage kernels (one workgroup per CU then) */
@@ -96,6 +99,7 @@ typedef struct {
     uint32_t wide;                      /* the staging tile holds 16-bit pre-scaled indices (sre_hip_tile.h): always with
                                            <= 2 class bits; with 4 in COUNT mode when two workgroups per CU still fit */
     uint8_t  shadow_state[SRE_SCAN_MAX_SHADOWS];    /* the state each of them copies */
+    const uint8_t         *unskip;      /* [nstates] sre_dfa_t.unskip: what a chunk boundary makes of a state */
     const uint16_t        *neutral;     /* [nstates] bit j: thread j of the state's list descends from itself,
                                            without a save, in every STABLE step of the state (0: none) */
 } sre_scan_tables_t;
@@ -157,6 +161,37 @@ typedef struct {
 #define SRE_LINEAGE_BLOCK  256u     /* segments composed into one block map */
 #define SRE_WALK_BUDGET    256      /* positions of plain backward walk (~2 us each) before asking for the maps */
 
+/*
+ * State of ONE stream between the chunks of a streaming scan (sre_k_stream_tail): what
+ * the reference's context keeps in its thread lists (sre_vm_pike.c:47-76) — the ordered
+ * list is the automaton state, and every listed thread's capture vector is carried by
+ * value, resolved at the end of each chunk by the backward lineage walk.
+ */
+#define SRE_STREAM_MAX_THREADS 16u
+#define SRE_STREAM_MAX_SLOTS   64u
+typedef struct {
+    uint32_t state;             /* automaton state in front of the next byte; 0: no search under way */
+    uint32_t has_pending;       /* a match is pending (the list lives on) */
+    int64_t  pending_regex;
+    int64_t  pending_vec[SRE_STREAM_MAX_SLOTS];
+    int64_t  caps[SRE_STREAM_MAX_THREADS][SRE_STREAM_MAX_SLOTS];
+    int64_t  caps_next[SRE_STREAM_MAX_THREADS][SRE_STREAM_MAX_SLOTS];    /* scratch of sre_k_stream_tail */
+} sre_stream_ctx_t;
+
+/* sre_stream_result_t.rc: the chunk's lanes were not all verified; run the fix-up rounds */
+#define SRE_STREAM_UNSETTLED (-100)
+
+/* result of one streaming exec, written to host-visible memory */
+typedef struct {
+    int64_t  rc;                /* regex id, SRE_AGAIN, SRE_DECLINED, SRE_ERROR */
+    int64_t  has_pending, pending[2];
+    int64_t  ev_in_chunk;       /* a match event happened inside this chunk (sre_vm_pike.c:586-601) */
+    int64_t  poisoned;          /* match returned with threads still listed at eof (:616-622) */
+    int64_t  next_state;        /* host shadow of sre_stream_ctx_t.state */
+    int64_t  pad;
+    int64_t  ov[SRE_STREAM_MAX_SLOTS];
+} sre_stream_result_t;
+
 /* per-stream outcome of verify + reduce */
 typedef struct {
     int64_t  first_bad;     /* first segment whose assumed entry state was wrong, or nseg */
@@ -172,6 +207,7 @@ typedef struct {
     int64_t  ev_seg;        /* segment holding the event */
     int64_t  unst_seg;      /* last segment in front of ev_seg that is not SRE_SUM_STABLE, -1 none:
                                the segments between the two are stable, all in one state */
+    int64_t  unst_end;      /* ... and the last one in front of the stream's LAST segment */
     int32_t  done;          /* 1: result final, 0: needs a fix-up round from first_bad */
     int32_t  error;         /* COUNT: the iteration ended with SRE_ERROR */
     int32_t  need_maps;     /* set by sre_k_captures: lineage too long for the plain walk */
@@ -186,7 +222,12 @@ typedef struct {
     uint32_t seg_bytes;
     uint64_t nsegs;
     uint32_t init_variant;          /* SRE_DFA_INIT_* of the search that starts at offset 0 */
+    uint32_t flags;                 /* SRE_GEOM_* */
+    uint32_t entry_state;           /* SRE_GEOM_CONTINUES: the automaton state in front of offset 0 */
 } sre_scan_geom_t;
+
+#define SRE_GEOM_CONTINUES 1u       /* the buffers are chunks of streams whose search began earlier */
+#define SRE_GEOM_NO_EOF    2u       /* more chunks follow: no EOF step at the end of the buffer */
 
 #ifdef __cplusplus
 extern "C" {
@@ -211,6 +252,13 @@ hipError_t sre_launch_scan(const sre_scan_tables_t *d_tab, sre_scan_tables_t h_t
 hipError_t sre_launch_exact_entries(const sre_scan_tables_t *d_tab, sre_scan_tables_t h_tab,
     sre_scan_geom_t geom, const sre_seg_summary_t *d_sum, const sre_stream_status_t *d_status,
     uint8_t *d_fn, uint8_t *d_comp, uint8_t *d_chunk_entry, uint8_t *d_entry, hipStream_t stream);
+/* streaming: finish one chunk of ONE stream (geom.nstreams == 1) after scan + verify:
+ * the match if the search ended, else the carried state for the next chunk and the
+ * temporary / pending captures of SRE_AGAIN.  `base` = absolute offset of the chunk. */
+hipError_t sre_launch_stream_tail(const sre_scan_tables_t *d_tab, sre_scan_tables_t h_tab,
+    sre_scan_geom_t geom, const sre_seg_summary_t *d_sum, const sre_stream_status_t *d_status,
+    uint16_t *d_scratch, sre_stream_ctx_t *d_ctx, sre_stream_result_t *result, int64_t base, int eof,
+    uint32_t ovec_slots, hipStream_t stream);
 size_t sre_scan_verify_acc_bytes(uint32_t nstreams);
 hipError_t sre_scan_verify_acc_init(void *d_acc, uint32_t nstreams, hipStream_t stream);
 hipError_t sre_launch_verify(sre_scan_tables_t h_tab, sre_scan_geom_t geom,

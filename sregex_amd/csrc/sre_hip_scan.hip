@@ -472,7 +472,6 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
     constexpr int      GIDX = 16 / STRIDE;           /* indices per 16 input bytes */
     typedef const __attribute__((address_space(3))) uint32_t *lds_u32_t;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    __shared__ RowDesc rows[SRE_SCAN_BLOCK];
     /* class map pre-shifted for each byte position of an index, scaled by 4 */
     __shared__ uint16_t clsx[BITS == 8 ? 1 : 8 / BITS][256];
     __shared__ sre_scan_tables_t Ts;
@@ -487,6 +486,9 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
     const uint32_t tr_bytes = (nst * (tabp->ncls + 1) * 2u + 15u) & ~15u;      /* compact: 2 bytes a transition */
     uint8_t  *sfl = trl + tr_bytes;
     uint8_t  *tile = lds + (((size_t) (sfl - lds) + nst + 15u) & ~(size_t) 15u);
+    /* (the row descriptors live behind the tile, not in static LDS: the fast table is
+     * addressed with 16 bits and every static kilobyte in front of it costs a state) */
+    RowDesc  *rows = reinterpret_cast<RowDesc *>(tile + SRE_SCAN_BLOCK * ROWB);
     (void) nrows;
     if (tid == 0) {
         Ts = *tabp;
@@ -594,7 +596,9 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
         if (seg_b > w.n) seg_b = w.n;
 
         if (k == 0) {
-            w.st = T.init[G.init_variant];
+            /* a chunk of a stream whose search is already under way enters with the
+             * state the previous chunk ended in (sre_k_stream_tail) */
+            w.st = (G.flags & SRE_GEOM_CONTINUES) ? G.entry_state : T.init[G.init_variant];
             w.cur_sp = 0;
         } else if (lo != nullptr && (int64_t) k == lo[sidx]) {
             /* exact carry from the verified predecessor */
@@ -875,8 +879,9 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
 
     if (!active) return;
 
-    /* the lane that owns the end of the stream performs the EOF step(s) */
-    if (last_seg && !w.f(F_FINISHED)) {
+    /* the lane that owns the end of the stream performs the EOF step(s) — unless more
+     * chunks of the stream follow */
+    if (last_seg && !w.f(F_FINISHED) && !(G.flags & SRE_GEOM_NO_EOF)) {
         settle();
         w.anchor_pos = -1;
         slow_run<MODE>(w, w.n, w.n + 1, false, 0);
@@ -1076,6 +1081,7 @@ struct VerifyAcc {
     unsigned long long bad, end;        /* init ~0 */
     unsigned long long count, evseg, spseg;     /* init 0 */
     unsigned long long unst;                    /* init 0: 1 + last segment in front of evseg that is not stable */
+    unsigned long long unst_end;                /* init 0: 1 + last segment of the verified prefix that is not stable */
 };
 
 __global__ __launch_bounds__(256) void
@@ -1170,32 +1176,46 @@ sre_k_verify_b(sre_scan_geom_t G, const sre_seg_summary_t *__restrict__ sum, Ver
 __global__ __launch_bounds__(1024) void
 sre_k_verify_b2(sre_scan_geom_t G, const sre_seg_summary_t *__restrict__ sum, VerifyAcc *__restrict__ acc)
 {
-    __shared__ unsigned long long sh_max;
+    __shared__ unsigned long long sh_max, sh_max_end;
     const uint64_t g0 = (uint64_t) blockIdx.x * blockDim.x;
     const uint64_t g = g0 + threadIdx.x;
     const uint64_t glast = (g0 + blockDim.x - 1 < G.nsegs) ? g0 + blockDim.x - 1 : G.nsegs - 1;
     const uint32_t s_first = stream_of(G, g0), s_last = stream_of(G, glast);
     const bool     uniform = (s_first == s_last);       /* whole block inside one stream */
-    if (threadIdx.x == 0) sh_max = 0;
+    if (threadIdx.x == 0) sh_max = sh_max_end = 0;
     __syncthreads();
-    unsigned long long mine = 0;
+    unsigned long long mine = 0, mine_end = 0;
     uint32_t           s = s_first;
     if (g < G.nsegs) {
         if (!uniform) s = stream_of(G, g);
         const uint64_t k = g - G.seg_first[s];
         const uint64_t evseg = acc[s].evseg;        /* 1 + the event's segment, 0 none */
-        if (evseg != 0 && k + 1 < evseg && !(sum[g].flags & SRE_SUM_STABLE)) mine = k + 1;
+        const uint64_t nseg = G.seg_first[s + 1] - G.seg_first[s];
+        if (!(sum[g].flags & SRE_SUM_STABLE)) {
+            if (evseg != 0 && k + 1 < evseg) mine = k + 1;
+            /* (streaming: the walks that start at the end of a chunk; its last segment is
+             * never flagged stable and is crossed by its own stable prefix / suffix) */
+            if (k + 1 < nseg) mine_end = k + 1;
+        }
     }
     if (uniform) {
         for (int d = 32; d >= 1; d >>= 1) {
-            const unsigned long long o = __shfl_down(mine, d, 64);
+            const unsigned long long o = __shfl_down(mine, d, 64), o2 = __shfl_down(mine_end, d, 64);
             mine = o > mine ? o : mine;
+            mine_end = o2 > mine_end ? o2 : mine_end;
         }
-        if ((threadIdx.x & 63u) == 0 && mine) atomicMax(&sh_max, mine);
+        if ((threadIdx.x & 63u) == 0) {
+            if (mine) atomicMax(&sh_max, mine);
+            if (mine_end) atomicMax(&sh_max_end, mine_end);
+        }
         __syncthreads();
-        if (threadIdx.x == 0 && sh_max) atomicMax(&acc[s_first].unst, sh_max);
-    } else if (mine) {
-        atomicMax(&acc[s].unst, mine);
+        if (threadIdx.x == 0) {
+            if (sh_max) atomicMax(&acc[s_first].unst, sh_max);
+            if (sh_max_end) atomicMax(&acc[s_first].unst_end, sh_max_end);
+        }
+    } else {
+        if (mine) atomicMax(&acc[s].unst, mine);
+        if (mine_end) atomicMax(&acc[s].unst_end, mine_end);
     }
 }
 
@@ -1208,7 +1228,7 @@ sre_k_verify_c(sre_scan_tables_t T, sre_scan_geom_t G, const sre_seg_summary_t *
     /* take this stream's accumulator and leave it reset for the next pass */
     const VerifyAcc acc = accs[s];
     accs[s].bad = accs[s].end = ~0ull;
-    accs[s].count = accs[s].evseg = accs[s].spseg = accs[s].unst = 0;
+    accs[s].count = accs[s].evseg = accs[s].spseg = accs[s].unst = accs[s].unst_end = 0;
     const uint64_t first = G.seg_first[s], nseg = G.seg_first[s + 1] - first;
     uint64_t       bad = acc.bad, end = acc.end;
     if (bad > nseg) bad = nseg;
@@ -1233,6 +1253,7 @@ sre_k_verify_c(sre_scan_tables_t T, sre_scan_geom_t G, const sre_seg_summary_t *
     st.valid_from = 0;
     st.ev_seg = -1;
     st.unst_seg = acc.unst ? (int64_t) acc.unst - 1 : -1;
+    st.unst_end = acc.unst_end ? (int64_t) acc.unst_end - 1 : -1;
     if (done && evseg > 0) {
         const sre_seg_summary_t &c = sum[first + evseg - 1];
         st.ev_apos = c.lm_apos;
@@ -1611,16 +1632,160 @@ sre_k_lineage_blocks(uint64_t nsegs, const sre_seg_lineage_t *__restrict__ maps,
     }
 }
 
-__global__ __launch_bounds__(64) void
-sre_k_captures(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
-               const sre_seg_summary_t *__restrict__ sum,
-               sre_stream_status_t *__restrict__ status, uint16_t *__restrict__ scratch,
-               int64_t *__restrict__ records, uint32_t ovec_slots,
-               const sre_seg_lineage_t *__restrict__ maps,
-               const sre_seg_lineage_t *__restrict__ blocks, int use_maps)
+/*
+ * The backward lineage walk shared by the capture kernel (from the final match event)
+ * and the streaming tail kernel (from every thread still listed at the end of a chunk):
+ * thread j lives in the list at position p0; follow parent links backwards collecting
+ * the capture slots still unresolved, crossing stable stretches and (with maps) whole
+ * segments in O(1).  `carried`: the search began in FRONT of this buffer (a chunk of a
+ * stream): a lineage that reaches offset 0 takes the rest of its slots from the vector
+ * the context carries for that thread.  Values are buffer offsets + base.
+ * Returns 1 when the plain walk ran out of budget and the ancestor maps are wanted.
+ */
+struct LineageWalk {
+    const sre_scan_tables_t *T;         /* tables in LDS */
+    const sre_scan_tables_t *tabp;      /* ... and in global memory (rarely used parts) */
+    Tracer                  *tr;
+    uint32_t                 variant;
+    int64_t                  ev_seg, unst_seg;
+    int64_t                  unst_end;      /* last segment that is not stable, -1 none; a huge value: unknown */
+    uint64_t                 first;
+    const sre_seg_lineage_t *maps, *blocks;
+    bool                     use_maps;
+    const int64_t           *carried;   /* [SRE_STREAM_MAX_THREADS][SRE_STREAM_MAX_SLOTS], or null */
+    int64_t                  base;
+    int64_t                  walk_budget;   /* positions of plain walk before the maps are asked for */
+
+    __device__ int run(int64_t p0, uint32_t j, uint32_t state_at_p0, uint64_t &unresolved, int64_t *vec)
+    {
+        const sre_scan_tables_t &T = *this->T;
+        Tracer                  &tr = *this->tr;
+        const uint32_t           nsym = T.ncls + 1;
+        const uint64_t *const lin_early = tabp->lin_early;      /* global memory; rare */
+        const int64_t  seg = (int64_t) tr.seg_bytes;
+    const int64_t  k_sp = tr.sp / seg;
+    const bool     can_jump = use_maps && T.max_threads <= 16;
+    int64_t        budget = walk_budget;
+
+    /* stable stretches (sre_hip_scan.h SRE_FAST_STABLE): one search from offset 0 */
+    const uint16_t *const neutral = (T.mode == 1 && T.nshadow) ? tabp->neutral : nullptr;
+
+    /* thread j lives in the list at position p */
+    for (int64_t p = p0; unresolved; p--) {
+        if (neutral != nullptr) {
+            /* cross, in O(1), every stretch in which the automaton sat in one state and
+             * thread j descended from itself without saving: the stable prefix of the
+             * segment in front of p, whole runs of stable segments, a stable suffix */
+            for (;;) {
+                if (p <= tr.sp) break;
+                const int64_t kq = (p - 1) / seg, sbase = kq * seg;
+                const sre_seg_summary_t &S = tr.sum[kq];
+                if (p == sbase + seg && kq > unst_end && (S.flags & SRE_SUM_STABLE)) {
+                    /* ... up to the end of the buffer (walks that start there) */
+                    if (!((neutral[S.s_in & ~SRE_STATE_SKIP] >> j) & 1u)) break;
+                    p = (unst_end + 1) * seg;
+                    if (p < tr.sp) p = tr.sp;
+                    continue;
+                }
+                if (p == sbase + seg && kq < ev_seg && kq > unst_seg && (S.flags & SRE_SUM_STABLE)) {
+                    /* a whole run of stable segments, all in one state */
+                    if (!((neutral[S.s_in & ~SRE_STATE_SKIP] >> j) & 1u)) break;
+                    p = (unst_seg + 1) * seg;
+                    if (p < tr.sp) p = tr.sp;
+                    continue;
+                }
+                if (p - sbase <= (int64_t) S.stable_until) {
+                    if (!((neutral[S.s_in & ~SRE_STATE_SKIP] >> j) & 1u)) break;
+                    p = sbase > tr.sp ? sbase : tr.sp;
+                    continue;
+                }
+                if (p == sbase + seg && (int64_t) S.stable_from < seg) {
+                    if (!((neutral[S.s_out & ~SRE_STATE_SKIP] >> j) & 1u)) break;
+                    p = sbase + S.stable_from;
+                    if (p < tr.sp) p = tr.sp;
+                    continue;
+                }
+                break;
+            }
+        }
+        if (can_jump && p > tr.sp && p % seg == 0 && p < p0) {
+            /* at a segment start: jump over the segments (blocks) in front of it
+             * in which this lineage neither saved nor restarted */
+            int64_t k2 = p / seg - 1;
+            while (k2 >= k_sp) {        /* the search's own (partial) segment has a map too */
+                const uint64_t g2 = first + (uint64_t) k2;
+                if (g2 % SRE_LINEAGE_BLOCK == SRE_LINEAGE_BLOCK - 1
+                    && k2 - (int64_t) SRE_LINEAGE_BLOCK > k_sp)
+                {
+                    const sre_seg_lineage_t &bm = blocks[g2 / SRE_LINEAGE_BLOCK];
+                    if (!((bm.saved >> j) & 1u)) {
+                        j = (uint32_t) ((bm.anc >> (4 * j)) & 15ull);
+                        k2 -= SRE_LINEAGE_BLOCK;
+                        continue;
+                    }
+                }
+                const sre_seg_lineage_t &m = maps[g2];
+                if (((m.saved | m.stop) >> j) & 1u) break;
+                j = (uint32_t) ((m.anc >> (4 * j)) & 15ull);
+                k2--;
+            }
+            p = k2 < k_sp ? tr.sp : (k2 + 1) * seg;
+        }
+        if (!can_jump && --budget < 0 && T.max_threads <= 16) {
+            return 1;                       /* come back with the ancestor maps */
+        }
+        const uint32_t s_here = (p == p0) ? state_at_p0 : tr.state_before(p);
+#ifdef SRE_DEBUG_WALK
+        printf("walk p %lld s_here %u j %u pc %u unresolved %llx\n", (long long) p, s_here, j,
+               T.list_pcs[T.list_off[s_here] + j], (unsigned long long) unresolved);
+#endif
+        if (T.list_pcs[T.list_off[s_here] + j] == 1) break;      /* the ".*?" ANY thread */
+        const sre_dev_trans_t *t;
+        int64_t                val;
+        if (p == tr.sp && carried != nullptr) {
+            /* the search came in from the previous chunk: the rest is what the context
+             * carries for this thread */
+            for (uint32_t q = 0; q < T.nslots; q++) {
+                if ((unresolved >> q) & 1) vec[q] = carried[(size_t) j * SRE_STREAM_MAX_SLOTS + q];
+            }
+            unresolved = 0;
+            break;
+        }
+        if (p == tr.sp) {
+            t = &T.trans[(size_t) T.nstates * nsym + variant];   /* initial closure */
+            val = tr.sp;
+        } else {
+            t = &T.trans[(size_t) tr.state_before(p - 1) * nsym + T.cls[tr.data[p - 1]]];
+            val = p;
+        }
+        const uint64_t m = T.lin_saves[t->lin_off + j] & unresolved;
+        for (uint32_t q = 0; q < T.nslots; q++) {
+            if ((m >> q) & 1) vec[q] = val + base;
+        }
+        unresolved &= ~m;
+        if (lin_early != nullptr) {
+            /* written by a look-ahead splice before the byte was consumed */
+            const uint64_t m2 = lin_early[t->lin_off + j] & unresolved;
+            for (uint32_t q = 0; q < T.nslots; q++) {
+                if ((m2 >> q) & 1) vec[q] = val - 1 + base;
+            }
+            unresolved &= ~m2;
+        }
+        if (p == tr.sp) break;
+        j = T.lin_parent[t->lin_off + j];
+        if (j == 0xffu) break;              /* re-seeded by the leading-byte skip */
+    }
+
+        return 0;
+    }
+};
+
+/* the walkers' tables in LDS: [fast][class map][transition records][lineage saves]
+ * [list offsets][list pcs][lineage parents]; *Ts becomes a view onto them */
+__device__ inline void
+stage_walk_tables(const sre_scan_tables_t *__restrict__ tabp, uint8_t *lds, sre_scan_tables_t *Tsp)
 {
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    __shared__ sre_scan_tables_t Ts;
+    sre_scan_tables_t &Ts = *Tsp;
     {
         /* the walker's tables live in LDS:
          * [fast][class map][transition records][lineage saves][lineage parents] */
@@ -1657,6 +1822,19 @@ sre_k_captures(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
         for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) clsl[i] = tabp->cls[i];
         __syncthreads();
     }
+}
+
+__global__ __launch_bounds__(64) void
+sre_k_captures(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
+               const sre_seg_summary_t *__restrict__ sum,
+               sre_stream_status_t *__restrict__ status, uint16_t *__restrict__ scratch,
+               int64_t *__restrict__ records, uint32_t ovec_slots,
+               const sre_seg_lineage_t *__restrict__ maps,
+               const sre_seg_lineage_t *__restrict__ blocks, int use_maps)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    __shared__ sre_scan_tables_t Ts;
+    stage_walk_tables(tabp, lds, &Ts);
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= G.nstreams) return;
     if (use_maps && !status[s].need_maps) return;   /* second pass: flagged streams only */
@@ -1723,105 +1901,26 @@ sre_k_captures(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
         unresolved &= ~m;
     }
 
-    const uint64_t *const lin_early = tabp->lin_early;      /* global memory; rare */
-    const uint64_t first = G.seg_first[s];
-    const int64_t  seg = (int64_t) G.seg_bytes;
-    const int64_t  k_sp = tr.sp / seg;
-    const bool     can_jump = use_maps && T.max_threads <= 16;
-    int64_t        budget = SRE_WALK_BUDGET;
-
-    /* stable stretches (sre_hip_scan.h SRE_FAST_STABLE): one search from offset 0 */
-    const uint16_t *const neutral = (T.mode == 1 && T.nshadow) ? tabp->neutral : nullptr;
-
-    /* thread j lives in the list at position p */
-    for (int64_t p = st.ev_pos; unresolved; p--) {
-        if (neutral != nullptr) {
-            /* cross, in O(1), every stretch in which the automaton sat in one state and
-             * thread j descended from itself without saving: the stable prefix of the
-             * segment in front of p, whole runs of stable segments, a stable suffix */
-            for (;;) {
-                if (p <= tr.sp) break;
-                const int64_t kq = (p - 1) / seg, sbase = kq * seg;
-                const sre_seg_summary_t &S = tr.sum[kq];
-                if (p == sbase + seg && kq < st.ev_seg && kq > st.unst_seg && (S.flags & SRE_SUM_STABLE)) {
-                    /* a whole run of stable segments, all in one state */
-                    if (!((neutral[S.s_in & ~SRE_STATE_SKIP] >> j) & 1u)) break;
-                    p = (st.unst_seg + 1) * seg;
-                    if (p < tr.sp) p = tr.sp;
-                    continue;
-                }
-                if (p - sbase <= (int64_t) S.stable_until) {
-                    if (!((neutral[S.s_in & ~SRE_STATE_SKIP] >> j) & 1u)) break;
-                    p = sbase > tr.sp ? sbase : tr.sp;
-                    continue;
-                }
-                if (p == sbase + seg && (int64_t) S.stable_from < seg) {
-                    if (!((neutral[S.s_out & ~SRE_STATE_SKIP] >> j) & 1u)) break;
-                    p = sbase + S.stable_from;
-                    if (p < tr.sp) p = tr.sp;
-                    continue;
-                }
-                break;
-            }
-        }
-        if (can_jump && p > tr.sp && p % seg == 0 && p < st.ev_pos) {
-            /* at a segment start: jump over the segments (blocks) in front of it
-             * in which this lineage neither saved nor restarted */
-            int64_t k2 = p / seg - 1;
-            while (k2 >= k_sp) {        /* the search's own (partial) segment has a map too */
-                const uint64_t g2 = first + (uint64_t) k2;
-                if (g2 % SRE_LINEAGE_BLOCK == SRE_LINEAGE_BLOCK - 1
-                    && k2 - (int64_t) SRE_LINEAGE_BLOCK > k_sp)
-                {
-                    const sre_seg_lineage_t &bm = blocks[g2 / SRE_LINEAGE_BLOCK];
-                    if (!((bm.saved >> j) & 1u)) {
-                        j = (uint32_t) ((bm.anc >> (4 * j)) & 15ull);
-                        k2 -= SRE_LINEAGE_BLOCK;
-                        continue;
-                    }
-                }
-                const sre_seg_lineage_t &m = maps[g2];
-                if (((m.saved | m.stop) >> j) & 1u) break;
-                j = (uint32_t) ((m.anc >> (4 * j)) & 15ull);
-                k2--;
-            }
-            p = k2 < k_sp ? tr.sp : (k2 + 1) * seg;
-        }
-        if (!can_jump && --budget < 0 && T.max_threads <= 16) {
+    {
+        LineageWalk lw;
+        lw.T = &T;
+        lw.tabp = tabp;
+        lw.tr = &tr;
+        lw.variant = variant;
+        lw.ev_seg = st.ev_seg;
+        lw.unst_seg = st.unst_seg;
+        lw.unst_end = (int64_t) 1 << 62;        /* (the event's walk never starts behind its segment) */
+        lw.first = G.seg_first[s];
+        lw.maps = maps;
+        lw.blocks = blocks;
+        lw.use_maps = use_maps != 0;
+        lw.carried = nullptr;
+        lw.base = 0;
+        lw.walk_budget = SRE_WALK_BUDGET;
+        if (lw.run(st.ev_pos, j, st.ev_state, unresolved, vec)) {
             status[s].need_maps = 1;         /* come back with the ancestor maps */
             return;
         }
-        const uint32_t s_here = (p == st.ev_pos) ? st.ev_state : tr.state_before(p);
-#ifdef SRE_DEBUG_WALK
-        printf("walk p %lld s_here %u j %u pc %u unresolved %llx\n", (long long) p, s_here, j,
-               T.list_pcs[T.list_off[s_here] + j], (unsigned long long) unresolved);
-#endif
-        if (T.list_pcs[T.list_off[s_here] + j] == 1) break;      /* the ".*?" ANY thread */
-        const sre_dev_trans_t *t;
-        int64_t                val;
-        if (p == tr.sp) {
-            t = &T.trans[(size_t) T.nstates * nsym + variant];   /* initial closure */
-            val = tr.sp;
-        } else {
-            t = &T.trans[(size_t) tr.state_before(p - 1) * nsym + T.cls[tr.data[p - 1]]];
-            val = p;
-        }
-        const uint64_t m = T.lin_saves[t->lin_off + j] & unresolved;
-        for (uint32_t q = 0; q < T.nslots; q++) {
-            if ((m >> q) & 1) vec[q] = val;
-        }
-        unresolved &= ~m;
-        if (lin_early != nullptr) {
-            /* written by a look-ahead splice before the byte was consumed */
-            const uint64_t m2 = lin_early[t->lin_off + j] & unresolved;
-            for (uint32_t q = 0; q < T.nslots; q++) {
-                if ((m2 >> q) & 1) vec[q] = val - 1;
-            }
-            unresolved &= ~m2;
-        }
-        if (p == tr.sp) break;
-        j = T.lin_parent[t->lin_off + j];
-        if (j == 0xffu) break;              /* re-seeded by the leading-byte skip */
     }
 
     /* slice the winning regex's groups (sre_vm_pike.c:945-989) */
@@ -1831,6 +1930,180 @@ sre_k_captures(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
     const uint64_t ncopy = 2ull * (T.multi_ncaps[st.rc] + 1);
     for (uint64_t q = 0; q < ovec_slots; q++) rec[2 + q] = q < ncopy ? vec[ofs + q] : -1;
     rec[0] = (st.error && T.mode == SRE_HIP_PIKE_COUNT) ? RC_ERROR : st.rc;
+}
+
+
+/*
+ * Streaming (the chunked exec of the reference API, sre_vm_pike.c:148-689, on the
+ * throughput path): ONE lane finishes one chunk of one stream after the scan and the
+ * chain check.
+ *   - a match event inside the chunk: its winner's capture vector is walked out now
+ *     (lineage that reaches the chunk start continues in the vector the context
+ *     carries for that thread) and becomes the pending match (:535-553);
+ *   - the search is over (the list died, or eof): the pending match is the result
+ *     (:607-636), or SRE_DECLINED at eof (:660-666);
+ *   - otherwise SRE_AGAIN (:673-688): every thread still listed gets its capture
+ *     vector resolved — that, with the automaton state, is what the next chunk needs —
+ *     and the temporary match range is read off them (prepare_temp_captures,
+ *     :692-735, offset quirk of :711/:721 kept).
+ */
+__global__ __launch_bounds__(64) void
+sre_k_stream_tail(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
+                  const sre_seg_summary_t *__restrict__ sum, const sre_stream_status_t *__restrict__ status,
+                  uint16_t *__restrict__ scratch, sre_stream_ctx_t *__restrict__ ctx,
+                  sre_stream_result_t *__restrict__ res, int64_t base, int eof, uint32_t ovec_slots)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    __shared__ sre_scan_tables_t Ts;
+    stage_walk_tables(tabp, lds, &Ts);
+    if (threadIdx.x != 0) return;
+    const sre_scan_tables_t   &T = Ts;
+    const sre_stream_status_t  st = status[0];
+    const uint32_t             nsym = T.ncls + 1;
+    const bool                 continues = (G.flags & SRE_GEOM_CONTINUES) != 0;
+    const int64_t              n = (int64_t) G.lens[0];
+    const uint64_t             nseg = G.seg_first[1] - G.seg_first[0];
+
+    res->rc = RC_ERROR;
+    res->has_pending = 0;
+    res->ev_in_chunk = 0;
+    res->poisoned = 0;
+    res->next_state = 0;
+    if (!st.done) {
+        res->rc = SRE_STREAM_UNSETTLED;
+        return;
+    }
+
+    Tracer tr;
+    tr.T = &T;
+    tr.sum = sum;
+    tr.data = G.streams[0];
+    tr.n = n;
+    tr.sp = 0;
+    tr.seg_bytes = G.seg_bytes;
+    const uint32_t variant = G.init_variant;
+    tr.init_state = continues ? G.entry_state : T.init[variant];
+    tr.apos = st.ev_apos >= 0 ? st.ev_apos : -1;
+    tr.astate = st.ev_astate;
+    tr.ck = scratch;
+    tr.trace = tr.ck + G.seg_bytes / 64 + 4;
+    tr.seg_lo = tr.seg_hi = -1;
+    tr.blk_lo = 1;
+    tr.blk_hi = 0;
+    tr.seg_entry = 0;
+    tr.valid_from = 1;                  /* one search per chunk: every recorded entry state is its own */
+    tr.use_stable = (T.nshadow != 0);
+
+    LineageWalk lw;
+    lw.T = &T;
+    lw.tabp = tabp;
+    lw.tr = &tr;
+    lw.variant = variant;
+    lw.ev_seg = st.ev_seg >= 0 ? st.ev_seg : (int64_t) nseg;
+    lw.unst_seg = st.ev_seg >= 0 ? st.unst_seg : (int64_t) nseg;
+    lw.unst_end = T.nshadow ? st.unst_end : (int64_t) 1 << 62;
+    lw.first = 0;
+    lw.maps = lw.blocks = nullptr;
+    lw.use_maps = false;
+    lw.carried = continues ? &ctx->caps[0][0] : nullptr;
+    lw.base = base;
+    lw.walk_budget = (int64_t) 1 << 62;
+
+    const uint64_t all = T.nslots >= 64 ? ~0ull : ((1ull << T.nslots) - 1);
+    int64_t        vec[SRE_STREAM_MAX_SLOTS];
+
+    /* ---- a match event inside this chunk replaces the pending match */
+    if (st.ev_pos >= 0) {
+        uint64_t unresolved = all;
+        for (uint32_t q = 0; q < T.nslots; q++) vec[q] = -1;
+        const sre_dev_trans_t &te = T.trans[(size_t) st.ev_state * nsym + st.ev_sym];
+        if (te.kind == EV_DONE || te.kind == SRE_DEV_EV_DONE_EMPTY) {
+            const uint64_t m = te.saves & unresolved;
+            for (uint32_t q = 0; q < T.nslots; q++) {
+                if ((m >> q) & 1) vec[q] = st.ev_pos + 1 + base;
+            }
+            unresolved &= ~m;
+        }
+        if (te.early & unresolved) {
+            const uint64_t m = te.early & unresolved;
+            for (uint32_t q = 0; q < T.nslots; q++) {
+                if ((m >> q) & 1) vec[q] = st.ev_pos + base;
+            }
+            unresolved &= ~m;
+        }
+        /* carried stride: the context's rows are SRE_STREAM_MAX_SLOTS wide */
+        lw.run(st.ev_pos, te.src, st.ev_state, unresolved, vec);
+        ctx->has_pending = 1;
+        ctx->pending_regex = st.rc;
+        for (uint32_t q = 0; q < T.nslots; q++) ctx->pending_vec[q] = vec[q];
+        res->ev_in_chunk = 1;
+    }
+
+    /* ---- is the search over? */
+    const uint64_t last = (uint64_t) st.limit >= 1 ? (uint64_t) st.limit - 1 : 0;
+    const bool     died = (sum[last].flags & SRE_SUM_TERM) != 0;
+    if (died || eof) {
+        if (ctx->has_pending) {
+            const int64_t id = ctx->pending_regex;
+            uint64_t      ofs = 0;
+            for (int64_t i = 0; i < id; i++) ofs += T.multi_ncaps[i] + 1;
+            ofs *= 2;
+            const uint64_t ncopy = 2ull * (T.multi_ncaps[id] + 1);
+            for (uint64_t q = 0; q < ovec_slots && q < SRE_STREAM_MAX_SLOTS; q++) {
+                res->ov[q] = q < ncopy ? ctx->pending_vec[ofs + q] : -1;
+            }
+            res->rc = id;
+            res->poisoned = st.error ? 1 : 0;
+        } else {
+            res->rc = RC_DECLINED;
+        }
+        ctx->state = 0;
+        ctx->has_pending = 0;
+        return;
+    }
+
+    /* ---- SRE_AGAIN: carry the list (state + every thread's captures) to the next chunk */
+    const uint32_t sF = sum[nseg - 1].s_out & ~SRE_STATE_SKIP;
+    const uint32_t nth = T.list_off[sF + 1] - T.list_off[sF];
+    /* what the next chunk starts from: a leading-byte skip that is still travelling ends
+     * with the chunk (sre_dfa.h `unskip`); the list, and so the vectors, are the same */
+    const uint32_t sNext = tabp->unskip[sF];
+    int64_t        a0 = -1, a1 = -1;
+    /* the new vectors go to a second set of rows first: the walk of thread j may still
+     * read the carried vector of any thread */
+    int64_t *fresh = &ctx->caps_next[0][0];
+    for (uint32_t j = 0; j < nth && j < SRE_STREAM_MAX_THREADS; j++) {
+        uint64_t unresolved = all;
+        for (uint32_t q = 0; q < T.nslots; q++) vec[q] = -1;
+        lw.run(n, j, sF, unresolved, vec);
+        for (uint32_t q = 0; q < T.nslots; q++) fresh[(size_t) j * SRE_STREAM_MAX_SLOTS + q] = vec[q];
+        /* prepare_temp_captures (:692-735) */
+        uint64_t ofs = 0;
+        for (uint32_t r = 0; r < T.nregexes; r++) {
+            int64_t b = vec[ofs];
+            if (b != -1 && (a0 == -1 || b < a0)) a0 = b;
+            b = vec[1];
+            if (b != -1 && (a1 == -1 || b > a1)) a1 = b;
+            ofs += 2ull * (T.multi_ncaps[r] + 1);
+        }
+    }
+    for (uint32_t j = 0; j < nth && j < SRE_STREAM_MAX_THREADS; j++) {
+        for (uint32_t q = 0; q < T.nslots; q++) ctx->caps[j][q] = fresh[(size_t) j * SRE_STREAM_MAX_SLOTS + q];
+    }
+    ctx->state = sNext;
+    res->next_state = sNext;
+    res->ov[0] = a0;
+    res->ov[1] = a1;
+    res->rc = -2;                       /* SRE_AGAIN */
+    if (ctx->has_pending) {
+        const int64_t id = ctx->pending_regex;
+        uint64_t      ofs = 0;
+        for (int64_t i = 0; i < id; i++) ofs += T.multi_ncaps[i] + 1;
+        ofs *= 2;
+        res->has_pending = 1;
+        res->pending[0] = ctx->pending_vec[ofs];
+        res->pending[1] = ctx->pending_vec[ofs + 1];
+    }
 }
 
 }  // namespace
@@ -1876,7 +2149,7 @@ sre_scan_lds_bytes(const sre_scan_tables_t *h_tab)
      * (profiles/r02_experiments.txt).  The request is padded past a third of the CU's
      * 160 KiB (the kernel has at least 4.7 KiB of static LDS on top). */
     if (h_tab->mode == SRE_HIP_PIKE_COUNT && pad_env == NULL && need < 50 * 1024) need = 50 * 1024;
-    return need;
+    return need + (size_t) SRE_SCAN_BLOCK * 16;      /* row descriptors */
 }
 
 /* workgroups of the scan kernel one CU can hold (registers and LDS), for the
@@ -1931,7 +2204,7 @@ sre_scan_verify_acc_init(void *d_acc, uint32_t nstreams, hipStream_t stream)
                                     nstreams, stream);
     if (e != hipSuccess) return e;
     return hipMemset2DAsync(static_cast<char *>(d_acc) + 2 * sizeof(unsigned long long),
-                            sizeof(VerifyAcc), 0, 4 * sizeof(unsigned long long), nstreams, stream);
+                            sizeof(VerifyAcc), 0, 5 * sizeof(unsigned long long), nstreams, stream);
 }
 
 extern "C" hipError_t
@@ -2045,5 +2318,28 @@ sre_launch_exact_entries(const sre_scan_tables_t *d_tab, sre_scan_tables_t h_tab
                        d_status, d_fn, d_comp, d_entry, d_chunk_entry);
     hipLaunchKernelGGL(sre_k_fn_fill, dim3((uint32_t) ((nchunks + 63) / 64)), dim3(64), 0, stream, geom.nsegs,
                        d_fn, d_chunk_entry, d_entry);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t
+sre_launch_stream_tail(const sre_scan_tables_t *d_tab, sre_scan_tables_t h_tab, sre_scan_geom_t geom,
+                       const sre_seg_summary_t *d_sum, const sre_stream_status_t *d_status,
+                       uint16_t *d_scratch, sre_stream_ctx_t *d_ctx, sre_stream_result_t *result, int64_t base,
+                       int eof, uint32_t ovec_slots, hipStream_t stream)
+{
+    const size_t shmem = (size_t) h_tab.fast_bytes + 256
+                         + ((size_t) h_tab.nstates * (h_tab.ncls + 1) + 3) * sizeof(sre_dev_trans_t)
+                         + (size_t) h_tab.lin_total * 9 + ((size_t) h_tab.nstates + 1 + h_tab.list_total) * 4 + 16;
+    if (shmem > 48 * 1024) {
+        static bool raised = false;
+        if (!raised) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sre_k_stream_tail),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, SRE_CAPTURE_LDS_LIMIT);
+            if (e != hipSuccess) return e;
+            raised = true;
+        }
+    }
+    hipLaunchKernelGGL(sre_k_stream_tail, dim3(1), dim3(64), shmem, stream, d_tab, geom, d_sum, d_status,
+                       d_scratch, d_ctx, result, base, eof, ovec_slots);
     return hipGetLastError();
 }

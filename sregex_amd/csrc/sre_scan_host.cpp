@@ -44,9 +44,12 @@ sre_scan_tables_build(const sre_program_t *prog, const sre_dfa_t *d, int mode, c
     static const char *dummy;
     if (why == NULL) why = &dummy;
     *why = NULL;
-    if (d->nstates > SRE_SCAN_MAX_STATES) {
-        *why = "automaton has more states than the LDS fast table holds";
-        return NULL;
+    {
+        const uint32_t b = d->ncls <= 2 ? 1 : d->ncls <= 4 ? 2 : d->ncls <= 16 ? 4 : 8;
+        if (d->nstates + 1 > SRE_SCAN_MAX_ROWS(b)) {
+            *why = "automaton has more states than the LDS fast table holds";
+            return NULL;
+        }
     }
     if (d->max_threads > 254) {
         *why = "thread lists longer than 254";
@@ -178,7 +181,7 @@ sre_scan_tables_build(const sre_program_t *prog, const sre_dfa_t *d, int mode, c
     /* shadow rows for the states with the most STABLE entries, as LDS allows */
     h.nshadow = 0;
     if (mode != SRE_HIP_PIKE_COUNT && getenv("SRE_HIP_NO_SHADOW") == NULL) {      /* (experiment knob) */
-        const uint32_t room = SRE_SCAN_MAX_ROWS - d->nstates - 1;
+        const uint32_t room = SRE_SCAN_MAX_ROWS(bits) - d->nstates - 1;
         while (h.nshadow < SRE_SCAN_MAX_SHADOWS && h.nshadow < room) {
             uint32_t best = 0;
             for (uint32_t s0 = 1; s0 < d->nstates; s0++) {
@@ -222,6 +225,8 @@ sre_scan_tables_build(const sre_program_t *prog, const sre_dfa_t *d, int mode, c
         flags[s] = (uint8_t) ((d->matched[s] ? 1 : 0) | (d->seen_start[s] << 1));
     }
     std::vector<uint32_t> ncaps(prog->multi_ncaps, prog->multi_ncaps + prog->nregexes);
+    std::vector<uint8_t>  unskip(d->nstates);
+    for (uint32_t s = 0; s < d->nstates; s++) unskip[s] = (uint8_t) d->unskip[s];
     /* Lineage vectors, stored once per distinct content.  Per new thread of a
      * transition: parent index, SAVE masks, and flag bits (bit0 its closure path
      * saved a slot, bit1 it is the ".*?" ANY thread).  Equal lin_off therefore
@@ -292,7 +297,7 @@ sre_scan_tables_build(const sre_program_t *prog, const sre_dfa_t *d, int mode, c
          * program. */
         const size_t tr = ((size_t) d->nstates * nsym + 3) * sizeof(sre_dev_trans_t);
         const size_t scan_lds = sre_scan_lds_bytes(&h);
-        const size_t fast_end = (size_t) h.fast_rows * SRE_FAST_ROW_BYTES + 4096 + 4096 + 512;
+        const size_t fast_end = (size_t) h.fast_rows * SRE_FAST_ROW_BYTES + 768 + (bits == 8 ? 512 : (8 / bits) * 512);
         const size_t cap_lds = (size_t) h.fast_bytes + 256 + tr + (size_t) h.lin_total * 9
                                + ((size_t) d->nstates + 1 + h.list_total) * 4 + 16 + 512;
         const size_t lin_lds = 256 + (size_t) d->nstates * nsym * sizeof(sre_dev_trans_t)
@@ -321,6 +326,7 @@ sre_scan_tables_build(const sre_program_t *prog, const sre_dfa_t *d, int mode, c
         || (e = upload(d->list_pcs, &h.list_pcs, t->owned)) != hipSuccess
         || (e = upload(ncaps, &h.multi_ncaps, t->owned)) != hipSuccess
         || (e = upload(neutral, &h.neutral, t->owned)) != hipSuccess
+        || (e = upload(unskip, &h.unskip, t->owned)) != hipSuccess
         || (e = hipMalloc(reinterpret_cast<void **>(&t->d_tab), sizeof(h))) != hipSuccess
         || (e = hipMemcpy(t->d_tab, &h, sizeof(h), hipMemcpyHostToDevice)) != hipSuccess)
     {

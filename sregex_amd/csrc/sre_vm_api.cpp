@@ -17,7 +17,9 @@
  * returns SRE_ERROR after a diagnostic on stderr.
  */
 #include "sre_hip_runtime.h"
+#include "sre_hip_scan.h"
 #include <sregex_hip.h>
+#include <stddef.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -25,12 +27,19 @@
 /* sre_hip_batch.cpp */
 extern "C" int sre_hip_scan_one(sre_hip_scanner_t *sc, const void *d_buf, size_t len,
     int init_variant, sre_int_t *rec, int *poisoned, hipStream_t stream);
+extern "C" int sre_hip_scan_stream_chunk(sre_hip_scanner_t *sc, const void *d_buf, size_t len,
+    int init_variant, int continues, uint32_t entry_state, int eof, int64_t base, sre_stream_ctx_t *d_ctx,
+    sre_stream_result_t *d_res, const sre_stream_result_t *h_res, uint32_t ovec_slots, hipStream_t stream);
+extern "C" int sre_hip_scanner_streams(sre_hip_scanner_t *sc);
 
 /* whole-buffer calls at least this long go through a throughput engine (the
  * table-driven scanner, else the NFA tier) when the program admits one: below it
  * the exact VM's ~1 us per byte is cheaper than the scanners' fixed launch cost
  * (profiles/r02_crossover.json) */
 #define SRE_COMPAT_SCAN_MIN_BYTES  16u
+/* a chunked stream starts on the scanner when its first chunk is at least this long
+ * (byte-at-a-time feeding stays on the exact VM kernel) */
+#define SRE_COMPAT_STREAM_MIN_BYTES 4096u
 
 namespace {
 
@@ -55,6 +64,14 @@ struct DeviceStream {
     /* context state accumulated while its searches ran on the scanner */
     uint32_t           preset_valid, preset_flags;
     int64_t            preset_processed;
+    /* chunked streaming on the scanner: the carried list (device) and the result block
+     * (pinned, device-visible), allocated on first use */
+    sre_stream_ctx_t    *d_sctx;
+    sre_stream_result_t *h_sres, *d_sres;
+    /* pinned double buffer of stage_input */
+    uint8_t            *h_stage[2];
+    hipEvent_t          ev_stage[2];
+    int                 stage_busy[2];
 };
 
 /*
@@ -75,6 +92,12 @@ device_stream_destroy(DeviceStream *ds)
 {
     if (ds->d_ctx) (void) hipFree(ds->d_ctx);
     if (ds->d_in) (void) hipFree(ds->d_in);
+    for (int b = 0; b < 2; b++) {
+        if (ds->h_stage[b]) (void) hipHostFree(ds->h_stage[b]);
+        if (ds->ev_stage[b]) (void) hipEventDestroy(ds->ev_stage[b]);
+    }
+    if (ds->d_sctx) (void) hipFree(ds->d_sctx);
+    if (ds->h_sres) (void) hipHostFree(ds->h_sres);
     if (ds->h_blk) (void) hipHostFree(ds->h_blk);
     if (ds->stream) (void) hipStreamDestroy(ds->stream);
     free(ds);
@@ -207,7 +230,62 @@ struct sre_vm_pike_ctx_s {
     sre_hip_scanner_t *scanner;     /* lazily created, NULL if the program is not admitted */
     int            scanner_tried;
     sre_int_t     *rec;
+    /* a search that runs chunk by chunk on the scanner (pike_stream_route) */
+    int            stream_mode;     /* the device holds the carried list of a search under way */
+    uint32_t       stream_state;    /* host shadow of the automaton state in front of the next byte */
 };
+
+/*
+ * Host -> device staging of a chunk.  The caller's buffer is pageable memory, and a
+ * plain hipMemcpyAsync from it crawls (~1 GB/s measured here: the runtime stages it
+ * through small internal buffers, synchronously).  Large chunks therefore go through
+ * TWO pinned buffers owned by the device stream: the CPU copies piece k + 1 into one
+ * while the DMA engine moves piece k out of the other.
+ */
+#define SRE_STAGE_PIECE   (2u << 20)
+#define SRE_STAGE_MIN     (64u << 10)
+
+static int
+stage_input(DeviceStream *ds, const sre_char *input, size_t len)
+{
+    if (len > ds->in_cap) {
+        if (ds->d_in) (void) hipFree(ds->d_in);
+        ds->d_in = NULL;
+        ds->in_cap = 0;
+        if (hipMalloc(&ds->d_in, len + (len >> 2) + 4096) != hipSuccess) return -1;
+        ds->in_cap = len + (len >> 2) + 4096;
+    }
+    if (len == 0) return 0;
+    if (len < SRE_STAGE_MIN) {
+        return hipMemcpyAsync(ds->d_in, input, len, hipMemcpyHostToDevice, ds->stream) == hipSuccess ? 0 : -1;
+    }
+    if (ds->h_stage[0] == NULL) {
+        for (int b = 0; b < 2; b++) {
+            if (hipHostMalloc(reinterpret_cast<void **>(&ds->h_stage[b]), SRE_STAGE_PIECE, hipHostMallocNonCoherent) != hipSuccess
+                || hipEventCreateWithFlags(&ds->ev_stage[b], hipEventDisableTiming) != hipSuccess)
+            {
+                return -1;
+            }
+        }
+    }
+    size_t off = 0;
+    for (int b = 0; off < len; b ^= 1) {
+        const size_t n = len - off < SRE_STAGE_PIECE ? len - off : SRE_STAGE_PIECE;
+        if (ds->stage_busy[b]) {
+            if (hipEventSynchronize(ds->ev_stage[b]) != hipSuccess) return -1;     /* its last DMA is done */
+        }
+        memcpy(ds->h_stage[b], input + off, n);
+        if (hipMemcpyAsync(static_cast<uint8_t *>(ds->d_in) + off, ds->h_stage[b], n, hipMemcpyHostToDevice,
+                           ds->stream) != hipSuccess
+            || hipEventRecord(ds->ev_stage[b], ds->stream) != hipSuccess)
+        {
+            return -1;
+        }
+        ds->stage_busy[b] = 1;
+        off += n;
+    }
+    return 0;
+}
 
 /* The throughput scanner of a program for the compat path: built once per program
  * and mode (automaton + device tables cost milliseconds), owned by the PROGRAM's
@@ -269,14 +347,7 @@ pike_scan_route(sre_vm_pike_ctx_t *ctx, sre_char *input, size_t len, sre_int_t *
     }
 
     DeviceStream *ds = ctx->ds;
-    if (len > ds->in_cap) {
-        if (ds->d_in) (void) hipFree(ds->d_in);
-        ds->d_in = NULL;
-        ds->in_cap = 0;
-        if (hipMalloc(&ds->d_in, len + 4096) != hipSuccess) return 0;
-        ds->in_cap = len + 4096;
-    }
-    if (hipMemcpyAsync(ds->d_in, input, len, hipMemcpyHostToDevice, ds->stream) != hipSuccess) return 0;
+    if (stage_input(ds, input, len) != 0) return 0;
     int poisoned = 0;
     if (sre_hip_scan_one(ctx->scanner, static_cast<const uint8_t *>(ds->d_in) + skip, len - skip,
                          variant, ctx->rec, &poisoned, ds->stream) != 0)
@@ -309,6 +380,123 @@ pike_scan_route(sre_vm_pike_ctx_t *ctx, sre_char *input, size_t len, sre_int_t *
     if (poisoned) ctx->eof = 1;                              /* :616-622 */
     ctx->processed_bytes = ctx->ovector[1];                  /* :624-628 */
     ctx->empty_capture = (ctx->ovector[0] == ctx->ovector[1]);
+    *prc = rc;
+    return 1;
+}
+
+
+/*
+ * One reference exec() of a stream that is fed in chunks (eof or not), on the
+ * table-driven scanner: the ordered thread list travels from chunk to chunk as the
+ * automaton state plus one capture vector per listed thread (sre_k_stream_tail), so
+ * SRE_AGAIN, the temporary match range and pending matches are the reference's
+ * (sre_vm_pike.c:640-688, 692-735).  Returns 0 when the call is not taken (the exact
+ * VM kernel then owns the context for good).
+ */
+static int
+pike_stream_route(sre_vm_pike_ctx_t *ctx, sre_char *input, size_t len, unsigned eof,
+                  sre_int_t **pending_matched, sre_int_t *prc)
+{
+    if (ctx->eof) {
+        *prc = SRE_ERROR;                                   /* :165-168 */
+        return 1;
+    }
+    if (!ctx->scanner_tried) {
+        ctx->scanner_tried = 1;
+        ctx->scanner = compat_scanner(ctx->prog, SRE_HIP_PIKE_FIRST);
+        if (ctx->scanner) {
+            ctx->rec = static_cast<sre_int_t *>(
+                sre_palloc(ctx->pool, sre_hip_scanner_result_slots(ctx->scanner) * sizeof(sre_int_t)));
+            if (ctx->rec == NULL) ctx->scanner = NULL;
+        }
+    }
+    /* (look-ahead programs: a splice at the first byte of a chunk sees the context's
+     * seen_newline / seen_word, not the byte in front, sre_vm_pike.c:276-285, 492 — the
+     * whole-buffer automaton does not model that; they stay on the exact VM) */
+    if (ctx->scanner == NULL || !sre_hip_scanner_streams(ctx->scanner)
+        || ctx->ovec_slots > SRE_STREAM_MAX_SLOTS || ctx->prog->lookahead_asserts)
+    {
+        return 0;
+    }
+    DeviceStream *ds = ctx->ds;
+    size_t        skip = 0;
+    int           variant = 0;
+    if (!ctx->stream_mode) {
+        /* a search starts with this chunk (prologue of :165-233) */
+        if (ctx->prog->lookahead_asserts && (ctx->empty_capture || ctx->processed_bytes != 0)) return 0;
+        if (ctx->empty_capture) {                           /* :179-196 */
+            if (len == 0) return 0;
+            skip = 1;
+            variant = input[0] == '\n' ? 1 : 2;
+        } else if (ctx->processed_bytes != 0) {
+            variant = ctx->seen_newline ? 1 : 2;
+        }
+    }
+    if (ds->d_sctx == NULL) {
+        if (hipMalloc(reinterpret_cast<void **>(&ds->d_sctx), sizeof(sre_stream_ctx_t)) != hipSuccess
+            || hipHostMalloc(reinterpret_cast<void **>(&ds->h_sres), sizeof(sre_stream_result_t), hipHostMallocMapped)
+                   != hipSuccess
+            || hipHostGetDevicePointer(reinterpret_cast<void **>(&ds->d_sres), ds->h_sres, 0) != hipSuccess)
+        {
+            return 0;
+        }
+    }
+    if (!ctx->stream_mode
+        && hipMemsetAsync(ds->d_sctx, 0, offsetof(sre_stream_ctx_t, pending_vec), ds->stream) != hipSuccess)
+    {
+        return 0;
+    }
+    if (stage_input(ds, input, len) != 0) return 0;
+    ds->h_sres->rc = SRE_ERROR;
+    if (sre_hip_scan_stream_chunk(ctx->scanner, static_cast<const uint8_t *>(ds->d_in) + skip, len - skip, variant,
+                                  ctx->stream_mode, ctx->stream_state, eof ? 1 : 0,
+                                  (int64_t) ctx->processed_bytes + (int64_t) skip, ds->d_sctx, ds->d_sres, ds->h_sres,
+                                  (uint32_t) ctx->ovec_slots, ds->stream) != 0)
+    {
+        ds->failed = 1;
+        *prc = SRE_ERROR;
+        return 1;
+    }
+    const sre_stream_result_t *res = ds->h_sres;
+    const sre_int_t            rc = (sre_int_t) res->rc;
+    ctx->empty_capture = 0;
+    ctx->at_boundary = 0;
+    if (rc == SRE_AGAIN) {
+        for (size_t k = 0; k < ctx->ovec_slots && k < 2; k++) ctx->ovector[k] = (sre_int_t) res->ov[k];
+        if (pending_matched) {
+            if (res->has_pending) {
+                ctx->pending[0] = (sre_int_t) res->pending[0];
+                ctx->pending[1] = (sre_int_t) res->pending[1];
+                *pending_matched = ctx->pending;
+            } else {
+                *pending_matched = NULL;
+            }
+        }
+        ctx->processed_bytes += (sre_int_t) len;            /* :673 */
+        ctx->stream_mode = 1;
+        ctx->stream_state = (uint32_t) res->next_state;
+        *prc = SRE_AGAIN;
+        return 1;
+    }
+    ctx->stream_mode = 0;
+    ctx->stream_state = 0;
+    if (rc < 0) {
+        ctx->eof = 1;
+        *prc = rc == SRE_DECLINED ? SRE_DECLINED : SRE_ERROR;
+        return 1;
+    }
+    for (size_t k = 0; k < ctx->ovec_slots; k++) ctx->ovector[k] = (sre_int_t) res->ov[k];
+    if (rc == 0 && res->ev_in_chunk) {                      /* :586-601 */
+        const sre_int_t p = ctx->ovector[1] - ctx->processed_bytes;
+        if (p > 0) {
+            ctx->seen_newline = input[p - 1] == '\n';
+            ctx->seen_word = sre_isword(input[p - 1]);
+        }
+    }
+    if (res->poisoned) ctx->eof = 1;                         /* :616-622 */
+    ctx->processed_bytes = ctx->ovector[1];                  /* :624-628 */
+    ctx->empty_capture = (ctx->ovector[0] == ctx->ovector[1]);
+    ctx->at_boundary = 1;
     *prc = rc;
     return 1;
 }
@@ -350,6 +538,14 @@ sre_vm_pike_exec(sre_vm_pike_ctx_t *ctx, sre_char *input, size_t len, unsigned e
     {
         sre_int_t rc;
         if (pike_scan_route(ctx, input, len, &rc)) return rc;
+    }
+    /* a stream fed in chunks: the scanner carries the thread list from chunk to chunk */
+    if (!ctx->vm_touched && ctx->ovec_slots >= 2
+        && (ctx->stream_mode || (ctx->at_boundary && !eof && len >= SRE_COMPAT_STREAM_MIN_BYTES)))
+    {
+        sre_int_t rc;
+        if (pike_stream_route(ctx, input, len, eof, pending_matched, &rc)) return rc;
+        if (ctx->stream_mode) return SRE_ERROR;     /* (not reached: a stream in scanner mode stays there) */
     }
     if (!ctx->vm_touched) {
         ctx->vm_touched = 1;
@@ -435,18 +631,11 @@ sre_vm_thompson_exec(sre_vm_thompson_ctx_t *ctx, sre_char *input, size_t len, un
         }
         DeviceStream *ds = ctx->ds;
         if (ctx->scanner) {
-            if (len > ds->in_cap) {
-                if (ds->d_in) (void) hipFree(ds->d_in);
-                ds->d_in = NULL;
-                ds->in_cap = 0;
-                if (hipMalloc(&ds->d_in, len + 4096) == hipSuccess) ds->in_cap = len + 4096;
-            }
             sre_int_t *rec = static_cast<sre_int_t *>(
                 sre_palloc(ctx->pool, sre_hip_scanner_result_slots(ctx->scanner) * sizeof(sre_int_t)));
             if (rec == NULL) return SRE_ERROR;
             rec[0] = SRE_ERROR;
-            if (ds->in_cap >= len
-                && hipMemcpyAsync(ds->d_in, input, len, hipMemcpyHostToDevice, ds->stream) == hipSuccess
+            if (stage_input(ds, input, len) == 0
                 && sre_hip_scan_one(ctx->scanner, ds->d_in, len, 0, rec, NULL, ds->stream) == 0)
             {
                 ctx->started = 1;

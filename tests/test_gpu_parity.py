@@ -2,6 +2,7 @@
 golden vectors and against the oracle on the same inputs.  Bit-exact: rc,
 regex id, every ovector slot, temp/pending captures in streaming mode.
 """
+import ctypes
 import os
 
 import pytest
@@ -382,6 +383,121 @@ def test_compat_api_large_buffers_take_the_scanner(gpu):
             got = harness.findall(eng, prog, re.ncaps, data, limit)
             assert got == want, (pats, got[:3], want[:3], len(got), len(want))
             eng.recycle()
+
+
+def _feed(ctx, data, sizes, nov):
+    """Feed `data` in chunks of the given sizes (the last one with eof); one record per
+    exec call: rc, the ovector the call defined, the pending match of an AGAIN."""
+    out, off = [], 0
+    sizes = list(sizes)
+    while True:
+        n = sizes.pop(0) if sizes else len(data) - off
+        n = min(n, len(data) - off)
+        eof = off + n >= len(data) and not sizes
+        rc = ctx.exec(data[off:off + n], eof, want_pending=True)
+        off += n
+        if rc == S.SRE_AGAIN:
+            out.append((rc, tuple(ctx.ovector[:2]), ctx.pending))
+            continue
+        out.append((rc, tuple(ctx.ovector[:nov]) if rc >= 0 else None, None))
+        return out
+
+
+def test_compat_api_chunked_streams_take_the_scanner(gpu):
+    """sre_vm_pike_exec fed in CHUNKS (eof = 0, then a last chunk with eof): the chunks run
+    on the table-driven scanner, the thread list travelling from chunk to chunk as automaton
+    state + one capture vector per listed thread.  Every call must answer what the oracle
+    answers to the same call sequence: SRE_AGAIN with its temporary match range and the
+    pending match (sre_vm_pike.c:640-688, 692-735), then the match / SRE_DECLINED."""
+    import random
+    ora = harness.OracleEngine()
+    eng = harness.ProductEngine()
+    rng = random.Random(4242)
+    cfg3 = [b"a", b"ab", b"c", b"a(bc)", b"e(f)", b"gh", b"A", b"b", b"BLAH", rb"\s+", b"abcd", b"bc"]
+    zoo = [[rb"[a-z]+@[a-z]+\.[a-z]+"], [rb"([a-z]+)://([^/ ]+)(/[^ ?]*)?(\?[^ ]*)?"], [rb"a?a?a?aaa"],
+           [rb"(a+)(b+)?"], [rb"(?:a.*b|a)"], [rb"x(.*)y(.*)z"], [rb"(a|ab)(c|bcd)(d*)"], cfg3,
+           [rb"\Aab|\n^b"], [rb"(x+x+)+y"], [rb"^b+"], [rb"q(\w+)@"]]
+    tails = [b"@abc.cc ", b" abc://abc.cc/ab/c?a=b ", b"aaabbccb", b" a\nca", b"xabyabz", b"q"]
+    n = 0
+    for pats in zoo:
+        with S.Pool() as pool:
+            re = S.parse(pool, pats)
+            prog = S.compile(pool, re)
+            nov = 2 * (re.ncaps + 1)
+            for trial in range(6):
+                if trial < 3:
+                    data = S.gen_data_host(rng.choice([9000, 40000, 150000]), tails[rng.randrange(len(tails))])
+                else:
+                    alpha = [b"abc", b"ab c\n.x@:/?y", b"aaaaab xy\nz"][trial - 3]
+                    data = bytes(rng.choice(alpha) for _ in range(rng.choice([5000, 20000, 70000])))
+                first = rng.choice([4096, 5000, 8192, 30000])
+                sizes = [first] + [rng.choice([0, 1, 7, 64, 1000, 4096, 10000, 33333]) for _ in range(rng.randrange(0, 9))]
+                want = _feed(ora.pike(prog, re.ncaps), data, sizes, nov)
+                got = _feed(eng.pike(prog, re.ncaps), data, sizes, nov)
+                n += 1
+                assert got == want, (pats, len(data), sizes, got[-3:], want[-3:])
+                eng.recycle()
+    assert n == 72
+    # find-all over a chunked stream: after each match the caller re-feeds from the match end
+    chunk = S.gen_data_host(50000, b" bob@example.com\n")
+    for pats, data in (([rb"([a-z]+)@([a-z]+)\.[a-z]+"], chunk * 3 + b"x@y.z"), ([rb"^abc"], (b"abccc" * 3000 + b"\n") * 3)):
+        with S.Pool() as pool:
+            re = S.parse(pool, pats)
+            prog = S.compile(pool, re)
+            nov = 2 * (re.ncaps + 1)
+            res = []
+            for e in (ora, eng):
+                ctx, off, found = e.pike(prog, re.ncaps), 0, []
+                while len(found) < 50:
+                    end = min(off + 16384, len(data))
+                    rc = ctx.exec(data[off:end], end == len(data), want_pending=True)
+                    if rc == S.SRE_AGAIN:
+                        off = end
+                        continue
+                    if rc < 0:
+                        found.append((rc,))
+                        break
+                    found.append((rc,) + tuple(ctx.ovector[:nov]))
+                    off = ctx.ovector[1]
+                res.append(found)
+            eng.recycle()
+            assert res[0] == res[1], (pats, res[0][:3], res[1][:3])
+
+
+def test_compat_api_chunked_stream_rate(gpu):
+    """A 256 MiB stream through sre_vm_pike_exec in 1 MiB chunks (host memory): same final
+    answer as one whole-buffer call; the sustained rate is printed and written to
+    gpurun_out/stream_rate.json (PCIe- and host-memcpy-inclusive: never bench.py's value)."""
+    import json
+    import time
+    pats, tail = [rb"[a-z]+@[a-z]+\.[a-z]+"], b" a@abc.cc "
+    total, chunk = 256 << 20, 1 << 20
+    data = S.gen_data_host(total, tail)
+    L = len(data)
+    rows = {}
+    with S.Pool() as pool:
+        re = S.parse(pool, pats)
+        prog = S.compile(pool, re)
+        for name, step in (("1 MiB chunks", chunk), ("16 MiB chunks", 16 << 20)):
+            with S.Pool() as ep:
+                ctx = S.PikeCtx(ep, prog, re.ncaps)
+                buf = ctypes.create_string_buffer(data, L)
+                t0 = time.perf_counter()
+                off, rc, calls = 0, S.SRE_AGAIN, 0
+                while rc == S.SRE_AGAIN:
+                    n = min(step, L - off)
+                    rc = ctx.exec(None, off + n >= L, want_pending=False, base=buf, offset=off, length=n)
+                    off += n
+                    calls += 1
+                dt = time.perf_counter() - t0
+                assert rc == 0 and list(ctx.ovector) == [L - 9, L - 1], (name, rc, list(ctx.ovector))
+                rows[name] = {"calls": calls, "seconds": dt, "GBps": L / dt / 1e9}
+                print(name, rows[name])
+    out = os.path.join(harness.ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "stream_rate.json"), "w") as f:
+        json.dump(rows, f, indent=1)
+    assert rows["1 MiB chunks"]["GBps"] > 0.5, rows
 
 
 def test_full_size_streams_closed_form_properties(gpu):
