@@ -113,6 +113,8 @@ scanner_release(void *data)
     if (sc->d_nacc) (void) hipFree(sc->d_nacc);
     if (sc->ntab.accept) (void) hipFree(const_cast<uint64_t *>(sc->ntab.accept));
     if (sc->ntab.follow) (void) hipFree(const_cast<uint64_t *>(sc->ntab.follow));
+    if (sc->ntab.expand) (void) hipFree(const_cast<uint64_t *>(sc->ntab.expand));
+    if (sc->ntab.kind) (void) hipFree(const_cast<uint8_t *>(sc->ntab.kind));
     sre_nfa_free(sc->nfa);
     sre_scan_tables_release(sc->tab);
     sre_dfa_free(sc->dfa);
@@ -125,19 +127,27 @@ static int
 nfa_upload(sre_hip_scanner_t *sc)
 {
     const sre_nfa_t *n = sc->nfa;
-    uint32_t         ns = n->nslices <= 4 ? n->nslices : n->nslices <= 6 ? 6 : 8;
-    if (ns == 0) ns = 1;
-    std::vector<uint64_t> fol((size_t) ns * 256, 0);
+    const uint32_t   ns = n->nslices;           /* already rounded to a compiled variant */
+    std::vector<uint64_t> fol((size_t) ns * 256, 0), exp(16 * 256, 0);
     memcpy(fol.data(), n->follow.data(), n->follow.size() * sizeof(uint64_t));
-    uint64_t *d_acc = NULL, *d_fol = NULL;
+    if (n->nassert) memcpy(exp.data(), n->expand.data(), exp.size() * sizeof(uint64_t));
+    uint64_t *d_acc = NULL, *d_fol = NULL, *d_exp = NULL;
+    uint8_t  *d_kind = NULL;
     SRE_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_acc), 256 * sizeof(uint64_t)));
     sc->ntab.accept = d_acc;
     SRE_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_fol), fol.size() * sizeof(uint64_t)));
     sc->ntab.follow = d_fol;
+    SRE_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_exp), exp.size() * sizeof(uint64_t)));
+    sc->ntab.expand = d_exp;
+    SRE_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_kind), 256));
+    sc->ntab.kind = d_kind;
     SRE_HIP_TRY(hipMemcpy(d_acc, n->accept, 256 * sizeof(uint64_t), hipMemcpyHostToDevice));
     SRE_HIP_TRY(hipMemcpy(d_fol, fol.data(), fol.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    SRE_HIP_TRY(hipMemcpy(d_exp, exp.data(), exp.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    SRE_HIP_TRY(hipMemcpy(d_kind, n->kind, 256, hipMemcpyHostToDevice));
     sc->ntab.nbits = n->nbits;
     sc->ntab.nslices = ns;
+    sc->ntab.nassert = n->nassert;
     for (int v = 0; v < 3; v++) sc->ntab.init[v] = n->init[v];
     sc->ntab.any_bits = n->any_bits;
     sc->ntab.match_bits = n->match_bits;
@@ -265,7 +275,8 @@ sre_hip_scanner_kernel_name(sre_hip_scanner_t *sc)
                      sc->mode == SRE_HIP_PIKE_COUNT ? 2 : 1, (int) sc->tab->h.class_bits,
                      sc->tab->h.wide ? "true" : "false");
         } else if (sc->engine == SRE_HIP_ENGINE_NFA) {
-            sre_nfa_kernel_name(sc->mode, sc->ntab.nslices, sc->kernel_name, sizeof(sc->kernel_name));
+            sre_nfa_kernel_name(sc->mode, sc->ntab.nslices, sc->ntab.nassert != 0, sc->kernel_name,
+                                sizeof(sc->kernel_name));
         } else {
             snprintf(sc->kernel_name, sizeof(sc->kernel_name), "%s",
                      sc->mode == SRE_HIP_THOMPSON ? "sre_k_thompson_scan" : "sre_k_pike_scan");
@@ -396,7 +407,8 @@ scan_geometry(sre_hip_scanner_t *sc, size_t nstreams)
          * segments mean fewer summaries to verify and a smaller share of warm-up,
          * shorter ones keep every CU busy on small batches */
         if (sc->blocks_per_cu == 0) {
-            sc->blocks_per_cu = sc->engine == SRE_HIP_ENGINE_NFA ? sre_nfa_blocks_per_cu(sc->mode, sc->ntab.nslices)
+            sc->blocks_per_cu = sc->engine == SRE_HIP_ENGINE_NFA
+                                    ? sre_nfa_blocks_per_cu(sc->mode, sc->ntab.nslices, sc->ntab.nassert != 0)
                                                                  : sre_scan_blocks_per_cu(&sc->tab->h);
         }
         const uint64_t resident = 256ull * (uint64_t) sc->blocks_per_cu * SRE_SCAN_BLOCK;

@@ -15,6 +15,10 @@ typedef struct {
     uint64_t any_bits, match_bits;
     const uint64_t *accept;         /* [256]           device */
     const uint64_t *follow;         /* [nslices][256]  device */
+    /* look-ahead assertions (sre_nfa.h): their bits are byte nslices - 1 of the mask */
+    uint32_t nassert, pad;
+    const uint64_t *expand;         /* [4][4][256]     device */
+    const uint8_t  *kind;           /* [256]           device */
 } sre_nfa_tables_t;
 
 /* what one lane learnt about its segment */
@@ -40,9 +44,9 @@ typedef struct {
 #ifdef __cplusplus
 extern "C" {
 #endif
-size_t sre_nfa_lds_bytes(uint32_t nslices);
-int sre_nfa_blocks_per_cu(int mode, uint32_t nslices);
-const char *sre_nfa_kernel_name(int mode, uint32_t nslices, char *buf, size_t n);
+size_t sre_nfa_lds_bytes(uint32_t nslices, int la);
+int sre_nfa_blocks_per_cu(int mode, uint32_t nslices, int la);
+const char *sre_nfa_kernel_name(int mode, uint32_t nslices, int la, char *buf, size_t n);
 /* pass over segments [lo[s], nseg_s) of every stream (lo == NULL: all, speculative
  * entry sets from a 128-byte warm-up).  With lo: segment lo[s] enters with
  * belief[g] (its verified predecessor's exit set), later ones with belief[g] where

@@ -77,42 +77,70 @@ struct FollowOr<M, NSLICE, NSLICE> {
     static __device__ inline M get(M, uint32_t, uint32_t) { return 0; }
 };
 
+/* an entry of the accept table: the mask of threads that consume the byte and, with
+ * look-ahead assertions in the program, what the byte means to them */
+template <typename M, bool LA> struct AccEntry { M a; };
+template <> struct __attribute__((aligned(8))) AccEntry<uint32_t, true> {
+    uint32_t a;
+    uint32_t kk;        /* [15] the byte can start a match  [14:0] byte offset of its column (kind as the
+                           byte AT a position) in an expansion table row  [31:16] byte offset of its
+                           row (kind as the byte IN FRONT of the next position) */
+};
+template <> struct __attribute__((aligned(16))) AccEntry<uint64_t, true> {
+    uint64_t a;
+    uint32_t kk, pad;
+};
+
 /*
  * MODE 0: Thompson (events only); MODE 1: Pike first match (events + clean
  * positions).  NSLICE = byte slices of the mask; masks are 32-bit up to 4
- * slices, 64-bit above.
+ * slices, 64-bit above.  LA: the program has look-ahead assertions; their bits are
+ * byte NSLICE - 1 of the mask (sre_nfa.h).
  */
-template <int MODE, int NSLICE>
+template <int MODE, int NSLICE, bool LA>
 __global__ __launch_bounds__(SRE_SCAN_BLOCK) void
 sre_k_nfa(sre_nfa_tables_t T, sre_scan_geom_t G, sre_nfa_summary_t *__restrict__ sum,
           const int64_t *__restrict__ lo, const uint64_t *__restrict__ belief,
           const uint8_t *__restrict__ bvalid)
 {
     typedef typename std::conditional<(NSLICE <= 4), uint32_t, uint64_t>::type M;
+    typedef AccEntry<M, LA> Acc;
     typedef const __attribute__((address_space(3))) M *lds_m_t;
     constexpr int      TILE = SRE_SCAN_ROUND;
     constexpr int      WARM = SRE_SCAN_LINE;
     constexpr uint32_t ROWRAW = TILE;               /* raw bytes per round */
     constexpr uint32_t ROWB = 2 * ROWRAW + 16;      /* see tile_store */
+    constexpr int      FSL = LA ? NSLICE - 1 : NSLICE;      /* slices that can hold consuming threads */
+    constexpr uint32_t XROW = 4 * 256 * (uint32_t) sizeof(M), XCOL = 256 * (uint32_t) sizeof(M);
     /* static LDS: table addresses are compile-time constants and fold into the
-     * offset field of the lookups */
-    __shared__ __attribute__((aligned(16))) M acc_w[256];
-    __shared__ __attribute__((aligned(16))) M fol_w[NSLICE * 256];
-    __shared__ __attribute__((aligned(16))) uint8_t tile[SRE_SCAN_BLOCK * ROWB];
-    __shared__ RowDesc rows[SRE_SCAN_BLOCK];
+     * offset field of the lookups; the tile (and the row descriptors behind it) are
+     * dynamic: with the expansion tables the static part alone nears 64 KiB */
+    __shared__ __attribute__((aligned(16))) Acc acc_w[256];
+    __shared__ __attribute__((aligned(16))) M fol_w[(FSL ? FSL : 1) * 256];
+    __shared__ __attribute__((aligned(16))) M exp_w[LA ? 16 * 256 : 1];
+    extern __shared__ __attribute__((aligned(16))) uint8_t tile[];
+    RowDesc *rows = reinterpret_cast<RowDesc *>(tile + SRE_SCAN_BLOCK * ROWB);
 
     const uint32_t tid = threadIdx.x;
     const M  match = (M) T.match_bits, any = (M) T.any_bits;
     /* sticky MATCH bits: see the file comment */
-    acc_w[tid] = (M) T.accept[tid] | match;
+    acc_w[tid].a = (M) T.accept[tid] | match;
+    if (LA) {
+        const uint32_t kd = T.kind[tid];
+        reinterpret_cast<AccEntry<M, true> *>(acc_w)[tid].kk =
+            ((kd & 3u) * XCOL) | ((kd & 4u) ? 0x8000u : 0u) | (((kd & 3u) * XROW) << 16);
+        for (uint32_t i = tid; i < 16 * 256; i += SRE_SCAN_BLOCK) exp_w[i] = (M) T.expand[i];
+    }
 #pragma unroll
-    for (int k = 0; k < NSLICE; k++) {
+    for (int k = 0; k < FSL; k++) {
         const M slice_match = (M) ((T.match_bits >> (8 * k)) & 0xffu) & (M) tid;
         fol_w[k * 256 + tid] = (M) T.follow[k * 256 + tid] | (slice_match << (8 * k));
     }
-    const uint32_t acc_base = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) M *) acc_w;
+    const uint32_t acc_base = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) Acc *) acc_w;
     const uint32_t fol_base = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) M *) fol_w;
+    const uint32_t exp_base = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) M *) exp_w;
     const uint32_t sh = sizeof(M) == 4 ? 2u : 3u;      /* log2 of a table entry, in a register for SDWA */
+    const uint32_t sha = sizeof(Acc) == 4 ? 2u : sizeof(Acc) == 8 ? 3u : 4u;
 
     /* ---- which segment am I ---- */
     const uint64_t g = (uint64_t) blockIdx.x * SRE_SCAN_BLOCK + tid;
@@ -128,9 +156,10 @@ sre_k_nfa(sre_nfa_tables_t T, sre_scan_geom_t G, sre_nfa_summary_t *__restrict__
     const uint8_t *data = nullptr;
     int64_t        n = 0, seg_a = 0, seg_b = 0;
     M              S = 0, s_in = 0;
-    bool           warm = false, finished = false;
+    bool           warm = false, finished = false, last_seg = false;
     int64_t        first_ev = -1, last_clean = -1;
     int32_t        clean_mode = 0;
+    uint32_t       prev_off = 3u * XROW;        /* LA: expansion-table row of the byte in front (3: stream start) */
     RowDesc        mine;
     mine.addr = 0;
     mine.lo = 0;
@@ -140,6 +169,7 @@ sre_k_nfa(sre_nfa_tables_t T, sre_scan_geom_t G, sre_nfa_summary_t *__restrict__
         n = (int64_t) G.lens[sidx];
         seg_a = (int64_t) k * G.seg_bytes;
         seg_b = seg_a + G.seg_bytes;
+        last_seg = (k + 1 == G.seg_first[sidx + 1] - G.seg_first[sidx]);
         if (seg_b > n) seg_b = n;
         if (k == 0) {
             S = (M) T.init[G.init_variant];
@@ -157,6 +187,11 @@ sre_k_nfa(sre_nfa_tables_t T, sre_scan_geom_t G, sre_nfa_summary_t *__restrict__
         mine.addr = (uint64_t) reinterpret_cast<uintptr_t>(data) + (uint64_t) (seg_a - WARM);
         mine.lo = warm ? (seg_a >= WARM ? 0 : (int32_t) (WARM - seg_a)) : WARM;
         mine.hi16 = (int32_t) (WARM + (seg_b - seg_a)) - 16;
+        if (LA) {
+            /* the kind of the byte in front of the first byte this lane steps over */
+            const int64_t first_pos = warm ? (seg_a >= WARM ? seg_a - WARM : 0) : seg_a;
+            if (first_pos > 0) prev_off = (T.kind[data[first_pos - 1]] & 3u) * XROW;
+        }
     }
     rows[tid] = mine;
 
@@ -167,28 +202,47 @@ sre_k_nfa(sre_nfa_tables_t T, sre_scan_geom_t G, sre_nfa_summary_t *__restrict__
      * stepped without a new "is this the initial state" check and keeps
      * seen_start_state set (:286-306 fall through to :312), which decides whether a
      * later check can re-seed a search that already holds a match.  The skip fires
-     * at q - 1 iff the list there equals the snapshot taken at offset 0 (:266-273;
-     * the byte at q - 1 cannot start a match, or q would not be clean):
-     *   the SET in front of q - 1 differs from the snapshot's  -> an ordinary step (0)
+     * at q - 1 iff the list there equals the snapshot taken at offset 0 (:266-273)
+     * and the byte at q - 1 cannot start a match (without look-ahead assertions it
+     * never can, or q would not be clean; with them a thread that could consume it
+     * may have been held back by its assertion):
+     *   the byte at q - 1 can start a match                     -> an ordinary step (0)
+     *   the SET in front of q - 1 differs from the snapshot's   -> an ordinary step (0)
      *   it is equal and q - 1 is clean too (same list, fresh)   -> a skip target   (1)
      *   equal as a set but not known to be the same list        -> unusable        (-1)
      */
     const M snap = (M) T.init[G.init_variant];
-    auto clean_kind = [&](M s_before, bool prev_clean) -> int {
-        if (s_before != snap) return 0;
+    auto clean_kind = [&](M s_before, bool prev_clean, bool leading) -> int {
+        if (leading || s_before != snap) return 0;
         return prev_clean ? 1 : -1;
     };
-    /* one step on the byte selected from a word of the row: J = its byte index */
-    auto accept_of = [&](uint32_t word, int j) -> M {
-        const uint32_t a = (j & 3) == 0 ? byte_shl<0>(word, sh) : (j & 3) == 1 ? byte_shl<1>(word, sh)
-                         : (j & 3) == 2 ? byte_shl<2>(word, sh) : byte_shl<3>(word, sh);
-        return *(lds_m_t) (uintptr_t) (acc_base + a);
+    /* the accept-table entry of the byte selected from a word of the row: j = its byte index */
+    struct AccVal { M a; uint32_t kk; };
+    auto accept_of = [&](uint32_t word, int j) -> AccVal {
+        const uint32_t a = (j & 3) == 0 ? byte_shl<0>(word, sha) : (j & 3) == 1 ? byte_shl<1>(word, sha)
+                         : (j & 3) == 2 ? byte_shl<2>(word, sha) : byte_shl<3>(word, sha);
+        AccVal v;
+        v.a = *(lds_m_t) (uintptr_t) (acc_base + a);
+        v.kk = LA ? *(const __attribute__((address_space(3))) uint32_t *) (uintptr_t) (acc_base + a + (uint32_t) sizeof(M))
+                  : 0u;
+        return v;
     };
-    auto step = [&](M s, M a, M &t_out) -> M {
-        const M t = s & a;
+    /* LA: the assertions of the list that hold between the byte in front and this one put
+     * their continuations into the list (one lookup: sre_nfa.h) */
+    auto expand = [&](M s, uint32_t col_off) -> M {
+        const uint32_t word = (NSLICE - 1) < 4 ? (uint32_t) s : (uint32_t) ((uint64_t) s >> 32);
+        return s | *(lds_m_t) (uintptr_t) (exp_base + prev_off + col_off + byte_shl<((NSLICE - 1) & 3)>(word, sh));
+    };
+    auto step = [&](M s, const AccVal &e, M &t_out) -> M {
+        if (LA) {
+            s = expand(s, e.kk & 0x7fffu);
+            prev_off = e.kk >> 16;
+        }
+        const M t = s & e.a;
         t_out = t;
-        return FollowOr<M, NSLICE, 0>::get(t, fol_base, sh);
+        return FollowOr<M, FSL, 0>::get(t, fol_base, sh);
     };
+    auto is_leading = [&](const AccVal &e) -> bool { return LA && (e.kk & 0x8000u) != 0; };
 
     const uint32_t nrounds = WARM / TILE + G.seg_bytes / TILE;
     const uint32_t lag = (tid >> 5) & 1u;
@@ -219,20 +273,22 @@ sre_k_nfa(sre_nfa_tables_t T, sre_scan_geom_t G, sre_nfa_summary_t *__restrict__
                 roww[4 * x] = v.x; roww[4 * x + 1] = v.y; roww[4 * x + 2] = v.z; roww[4 * x + 3] = v.w;
             }
         }
-        const M s0 = S;
+        const M        s0 = S;
+        const uint32_t prev_off0 = prev_off;
         if (base + TILE <= seg_b) {
             /* the common round: 64 steps, then one look at the sticky MATCH bits */
             int32_t clean_at = -1, clean_how = 0;
             M       t14 = 0;
 #pragma unroll
             for (int j = 0; j < TILE; j++) {
-                M       t;
-                const M s_before = S;
-                S = step(S, accept_of(roww[j >> 2], j), t);
+                M         t;
+                const M   s_before = S;
+                const AccVal e = accept_of(roww[j >> 2], j);
+                S = step(S, e, t);
                 if (MODE == 1 && (j & 15) == 14) t14 = t;
                 /* clean positions are sampled at the end of every 16-byte group */
                 if (MODE == 1 && (j & 15) == 15 && t <= any) {
-                    const int how = clean_kind(s_before, t14 <= any);
+                    const int how = clean_kind(s_before, t14 <= any, is_leading(e));
                     if (how >= 0) {
                         clean_at = j + 1;
                         clean_how = how;
@@ -256,6 +312,7 @@ sre_k_nfa(sre_nfa_tables_t T, sre_scan_geom_t G, sre_nfa_summary_t *__restrict__
                 continue;
             }
             S = s0;
+            prev_off = prev_off0;
         }
         /* byte by byte: a round with an event, or the ragged end of the stream */
         {
@@ -268,7 +325,8 @@ sre_k_nfa(sre_nfa_tables_t T, sre_scan_geom_t G, sre_nfa_summary_t *__restrict__
                 /* from memory, not from the tile: a 16-byte piece that crosses the end
                  * of the stream is not staged (sre_hip_tile.h) */
                 const uint32_t b = data[p];
-                S = step(S, accept_of(b, 0), t);
+                const AccVal   e = accept_of(b, 0);
+                S = step(S, e, t);
                 if (S & match) {
                     if (!warm_round) {
                         first_ev = p;
@@ -278,7 +336,7 @@ sre_k_nfa(sre_nfa_tables_t T, sre_scan_geom_t G, sre_nfa_summary_t *__restrict__
                     S &= ~match;
                     prev_clean = false;
                 } else if (MODE == 1 && !warm_round && t <= any) {
-                    const int how = clean_kind(s_before, prev_clean);
+                    const int how = clean_kind(s_before, prev_clean, is_leading(e));
                     if (how >= 0) {
                         last_clean = p + 1;
                         clean_mode = how;
@@ -293,6 +351,11 @@ sre_k_nfa(sre_nfa_tables_t T, sre_scan_geom_t G, sre_nfa_summary_t *__restrict__
     }
 
     if (!active) return;
+    if (LA && last_seg && !finished && !(G.flags & SRE_GEOM_NO_EOF)) {
+        /* the extra iteration at end of input (sre_vm_pike.c:235): assertions that hold
+         * in front of the end list their continuations; a MATCH among them is an event */
+        if (expand(S, 3u * XCOL) & match) first_ev = n;
+    }
     sre_nfa_summary_t out;
     out.s_in = (uint64_t) s_in;
     out.s_out = (uint64_t) S;
@@ -409,21 +472,21 @@ sre_k_nfa_verify_c(int mode, sre_scan_geom_t G, const sre_nfa_summary_t *__restr
 typedef void (*nfa_kernel_t)(sre_nfa_tables_t, sre_scan_geom_t, sre_nfa_summary_t *, const int64_t *,
                              const uint64_t *, const uint8_t *);
 
-template <int MODE>
+template <int MODE, bool LA>
 nfa_kernel_t
 nfa_kernel_slices(uint32_t nslices)
 {
     switch (nslices) {
-    case 1: return sre_k_nfa<MODE, 1>;
-    case 2: return sre_k_nfa<MODE, 2>;
-    case 3: return sre_k_nfa<MODE, 3>;
-    case 4: return sre_k_nfa<MODE, 4>;
-    case 5: case 6: return sre_k_nfa<MODE, 6>;
-    default: return sre_k_nfa<MODE, 8>;
+    case 1: return LA ? nullptr : sre_k_nfa<MODE, 1, false>;    /* (assertions take a byte of their own) */
+    case 2: return sre_k_nfa<MODE, 2, LA>;
+    case 3: return sre_k_nfa<MODE, 3, LA>;
+    case 4: return sre_k_nfa<MODE, 4, LA>;
+    case 5: case 6: return sre_k_nfa<MODE, 6, LA>;
+    default: return sre_k_nfa<MODE, 8, LA>;
     }
 }
 
-/* the slice count a variant is compiled for */
+/* the slice count a variant is compiled for (the host builder rounds the same way) */
 uint32_t
 nfa_round_slices(uint32_t nslices)
 {
@@ -431,35 +494,43 @@ nfa_round_slices(uint32_t nslices)
 }
 
 nfa_kernel_t
-nfa_kernel(int mode, uint32_t nslices)
+nfa_kernel(int mode, uint32_t nslices, bool la)
 {
-    return mode == 0 ? nfa_kernel_slices<0>(nslices) : nfa_kernel_slices<1>(nslices);
+    if (la) return mode == 0 ? nfa_kernel_slices<0, true>(nslices) : nfa_kernel_slices<1, true>(nslices);
+    return mode == 0 ? nfa_kernel_slices<0, false>(nslices) : nfa_kernel_slices<1, false>(nslices);
 }
 
 }  // namespace
 
+/* dynamic LDS of a workgroup: the staging tile and the row descriptors */
+static size_t
+nfa_dynamic_lds(void)
+{
+    return (size_t) SRE_SCAN_BLOCK * (2 * SRE_SCAN_ROUND + 16) + (size_t) SRE_SCAN_BLOCK * 16;
+}
+
 extern "C" size_t
-sre_nfa_lds_bytes(uint32_t nslices)
+sre_nfa_lds_bytes(uint32_t nslices, int la)
 {
     const uint32_t ns = nfa_round_slices(nslices);
     const size_t   w = ns <= 4 ? 4 : 8;
-    /* all of it static: tables, tile, row descriptors */
-    return (size_t) (1 + ns) * 256 * w + (size_t) SRE_SCAN_BLOCK * (2 * SRE_SCAN_ROUND + 16)
-           + (size_t) SRE_SCAN_BLOCK * 16;
+    return (size_t) 256 * (la ? 2 * w : w) + (size_t) (la ? ns - 1 : ns) * 256 * w + (la ? 16 * 256 * w : 16)
+           + nfa_dynamic_lds();
 }
 
 extern "C" const char *
-sre_nfa_kernel_name(int mode, uint32_t nslices, char *buf, size_t n)
+sre_nfa_kernel_name(int mode, uint32_t nslices, int la, char *buf, size_t n)
 {
-    snprintf(buf, n, "sre_k_nfa<%d, %u>", mode == 0 ? 0 : 1, nfa_round_slices(nslices));
+    snprintf(buf, n, "sre_k_nfa<%d, %u, %s>", mode == 0 ? 0 : 1, nfa_round_slices(nslices), la ? "true" : "false");
     return buf;
 }
 
 extern "C" int
-sre_nfa_blocks_per_cu(int mode, uint32_t nslices)
+sre_nfa_blocks_per_cu(int mode, uint32_t nslices, int la)
 {
     int        n = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, nfa_kernel(mode, nslices), SRE_SCAN_BLOCK, 0);
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, nfa_kernel(mode, nslices, la != 0), SRE_SCAN_BLOCK,
+                                                                nfa_dynamic_lds());
     if (e != hipSuccess || n < 1) n = 1;
     if (n > 8) n = 8;
     return n;
@@ -471,11 +542,16 @@ sre_launch_nfa_scan(int mode, sre_nfa_tables_t tab, sre_scan_geom_t geom, sre_nf
                     hipStream_t stream)
 {
     if (geom.nsegs == 0) return hipSuccess;
-    /* the compiled variant may have more slices than the program needs: the
-     * extra slices of the device tables are zero (sre_hip_batch.cpp pads them) */
     const uint32_t grid = (uint32_t) ((geom.nsegs + SRE_SCAN_BLOCK - 1) / SRE_SCAN_BLOCK);
-    nfa_kernel_t   kern = nfa_kernel(mode, tab.nslices);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(SRE_SCAN_BLOCK), 0, stream, tab, geom, d_sum, d_lo,
+    nfa_kernel_t   kern = nfa_kernel(mode, tab.nslices, tab.nassert != 0);
+    if (kern == nullptr) return hipErrorInvalidValue;
+    if (sre_nfa_lds_bytes(tab.nslices, tab.nassert != 0) > 64 * 1024) {
+        /* static + dynamic LDS beyond the default limit of a workgroup */
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int) nfa_dynamic_lds());
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(SRE_SCAN_BLOCK), nfa_dynamic_lds(), stream, tab, geom, d_sum, d_lo,
                        d_belief, d_bvalid);
     return hipGetLastError();
 }

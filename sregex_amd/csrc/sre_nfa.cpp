@@ -45,11 +45,11 @@ struct NfaBuilder {
                     pc = in.x;
                 } else if (in.opcode == SRE_OP_SAVE) {
                     pc++;
-                } else if (in.opcode == SRE_OP_ASSERT) {
-                    /* only \A and ^ get here (look-ahead programs are declined) */
-                    if (!(in.ch == SRE_ASSERT_BIG_A ? a_ok : caret_ok)) break;
+                } else if (in.opcode == SRE_OP_ASSERT && !(in.ch & SRE_ASSERT_LOOKAHEAD)) {
+                    if (!(in.ch == SRE_ASSERT_BIG_A ? a_ok : caret_ok)) break;     /* :839-864 */
                     pc++;
                 } else {
+                    /* consuming instruction, MATCH, or a look-ahead assertion: listed (:866-884) */
                     out.insert(pc);
                     break;
                 }
@@ -72,8 +72,8 @@ sre_nfa_build(const sre_program_t *prog, const char **why)
     static const char *dummy;
     if (why == NULL) why = &dummy;
     *why = NULL;
-    if (prog->lookahead_asserts) {
-        *why = "look-ahead assertions ($ \\z \\b \\B) have no bit-parallel form here";
+    if (prog->lookahead_asserts > 8) {
+        *why = "more than 8 look-ahead assertions ($ \\z \\b \\B)";
         return NULL;
     }
     if (prog->nthreads > SRE_NFA_MAX_BITS || prog->len > 4096) {
@@ -87,7 +87,7 @@ sre_nfa_build(const sre_program_t *prog, const char **why)
     std::vector<std::set<uint32_t>> fol[2];
     fol[0].resize(prog->len);
     fol[1].resize(prog->len);
-    std::vector<uint32_t> listable;
+    std::vector<uint32_t> listable, asserts;
     for (uint32_t pc = 0; pc < prog->len; pc++) {
         const sre_insn_t &in = prog->insns[pc];
         switch (in.opcode) {
@@ -98,6 +98,9 @@ sre_nfa_build(const sre_program_t *prog, const char **why)
             break;
         case SRE_OP_MATCH:
             listable.push_back(pc);
+            break;
+        case SRE_OP_ASSERT:
+            if (in.ch & SRE_ASSERT_LOOKAHEAD) asserts.push_back(pc);
             break;
         default:
             break;
@@ -128,13 +131,33 @@ sre_nfa_build(const sre_program_t *prog, const char **why)
     };
     if (prog->len > 1 && prog->insns[1].opcode == SRE_OP_ANY) assign(1);
     for (uint32_t pc : listable) assign(pc);
+    n->nassert = (uint32_t) asserts.size();
+    n->assert_slice = 0;
+    /* the kernel variants are compiled for 1, 2, 3, 4, 6 or 8 byte slices */
+    auto round_slices = [](uint32_t ns) { return ns <= 4 ? (ns ? ns : 1u) : ns <= 6 ? 6u : 8u; };
+    if (n->nassert) {
+        /* the assertions' bits: the LAST byte of the mask the kernel variant works on, a
+         * byte of their own (the variant knows at compile time where to find them) */
+        const uint32_t body = (uint32_t) (n->bit_pc.size() + 7) / 8;
+        if (body + 1 > 8) {
+            *why = "more than 64 thread bits (threads, newline twins, the assertions' byte)";
+            delete n;
+            return NULL;
+        }
+        n->assert_slice = round_slices(body + 1) - 1;
+        while (n->bit_pc.size() < 8 * (size_t) n->assert_slice) n->bit_pc.push_back(0xffffffffu);   /* unused bits */
+        for (uint32_t pc : asserts) {
+            bit_of[pc] = (int) n->bit_pc.size();
+            n->bit_pc.push_back(pc);
+        }
+    }
     n->nbits = (uint32_t) n->bit_pc.size();
     if (n->nbits > SRE_NFA_MAX_BITS) {
         *why = "more than 64 thread bits (threads plus their newline twins)";
         delete n;
         return NULL;
     }
-    n->nslices = (n->nbits + 7) / 8;
+    n->nslices = round_slices((n->nbits + 7) / 8);
 
     auto mask_of = [&](const std::set<uint32_t> &pcs) {
         uint64_t m = 0;
@@ -182,6 +205,65 @@ sre_nfa_build(const sre_program_t *prog, const char **why)
         *why = "nullable regex: the first match event is at offset 0, nothing to skip";
         delete n;
         return NULL;
+    }
+
+    /* ---- look-ahead assertions: byte kinds and the expansion tables */
+    for (unsigned c = 0; c < 256; c++) {
+        uint8_t k = sre_isword(c) ? SRE_NFA_KIND_WORD : c == '\n' ? SRE_NFA_KIND_NL : SRE_NFA_KIND_OTHER;
+        bool    lead = false;
+        if (prog->leading_byte != -1) lead = (int) c == prog->leading_byte;
+        for (uint32_t i = 0; !lead && prog->leading_byte == -1 && i < prog->nleading; i++) {
+            lead = b.consumes(prog->insns[prog->leading_insns[i]], c);
+        }
+        n->kind[c] = (uint8_t) (k | (lead ? SRE_NFA_LEADING : 0u));
+    }
+    if (n->nassert) {
+        n->expand.assign(16 * 256, 0);
+        for (uint32_t prev = 0; prev < 4; prev++) {
+            for (uint32_t cur = 0; cur < 4; cur++) {
+                const bool prev_word = prev == SRE_NFA_KIND_WORD, cur_word = cur == SRE_NFA_KIND_WORD;
+                const bool at_start = prev == SRE_NFA_KIND_EDGE, at_end = cur == SRE_NFA_KIND_EDGE;
+                auto holds = [&](uint8_t ch) {
+                    switch (ch) {                                   /* :450-497 */
+                    case SRE_ASSERT_SMALL_Z: return at_end;
+                    case SRE_ASSERT_DOLLAR:  return at_end || cur == SRE_NFA_KIND_NL;
+                    case SRE_ASSERT_SMALL_B: return prev_word != cur_word;
+                    case SRE_ASSERT_BIG_B:   return prev_word == cur_word;
+                    default:                 return false;
+                    }
+                };
+                /* per assertion: everything its continuation lists at this position, and
+                 * transitively what the assertions among THAT list (they see the same two
+                 * bytes) */
+                std::vector<uint64_t> xbit(n->nassert, 0);
+                for (uint32_t i = 0; i < n->nassert; i++) {
+                    if (!holds(prog->insns[asserts[i]].ch)) continue;
+                    std::set<uint32_t> acc, todo;
+                    todo.insert(asserts[i]);
+                    std::set<uint32_t> done;
+                    while (!todo.empty()) {
+                        const uint32_t a = *todo.begin();
+                        todo.erase(todo.begin());
+                        if (!done.insert(a).second) continue;
+                        std::set<uint32_t> cl;
+                        b.closure(a + 1, at_start, at_start || prev == SRE_NFA_KIND_NL, cl);     /* :506-526 */
+                        for (uint32_t pc : cl) {
+                            acc.insert(pc);
+                            const sre_insn_t &in = prog->insns[pc];
+                            if (in.opcode == SRE_OP_ASSERT && holds(in.ch)) todo.insert(pc);
+                        }
+                    }
+                    xbit[i] = mask_of(acc);
+                }
+                for (uint32_t v = 0; v < 256; v++) {
+                    uint64_t m = 0;
+                    for (uint32_t i = 0; i < n->nassert; i++) {
+                        if ((v >> i) & 1) m |= xbit[i];
+                    }
+                    n->expand[(size_t) (prev * 4 + cur) * 256 + v] = m;
+                }
+            }
+        }
     }
 
     n->follow.assign((size_t) n->nslices * 256, 0);

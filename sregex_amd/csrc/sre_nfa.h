@@ -26,7 +26,18 @@
  * the plain bit accepts every byte but '\n', the twin accepts '\n' only and
  * carries the closure computed with ^ true — so the step needs no case split.
  * \A never holds behind a consumed byte (:841-848); it only shapes the initial
- * sets.  Look-ahead assertions ($ \z \b \B) are not admitted in this form.
+ * sets.
+ *
+ * Look-ahead assertions ($ \z \b \B) wait in the list like any thread (one bit each,
+ * all in ONE byte of the mask, at most eight) and are decided by the NEXT byte
+ * (sre_vm_pike.c:450-504): one that holds puts the closure of its continuation into
+ * the list at the same position (:506-526).  Whether it holds depends on the kind of
+ * the byte in front of the position (word / newline / start of the stream / other) and
+ * of the byte at it (word / newline / other / end of input) — the same for every
+ * assertion of the list — so per such context the expansion is again a
+ * union-homomorphism of the assertion bits, transitively closed, and is tabulated:
+ *      S_eff = S | expand[ctx][assertion byte of S];    T = S_eff & accept[byte]; ...
+ * A MATCH reached by an expansion is a match event at that position.
  */
 #ifndef SRE_NFA_H
 #define SRE_NFA_H
@@ -38,6 +49,11 @@
 
 #define SRE_NFA_MAX_BITS 64u
 
+/* kinds of a byte for the look-ahead assertions; as the byte IN FRONT of a position
+ * START replaces them at the beginning of the stream, as the byte AT it EOF at the end */
+enum { SRE_NFA_KIND_OTHER = 0, SRE_NFA_KIND_WORD = 1, SRE_NFA_KIND_NL = 2, SRE_NFA_KIND_EDGE = 3 };
+#define SRE_NFA_LEADING 4u          /* the byte can start a match (sre_vm_pike.c:992-1061) */
+
 struct sre_nfa_s {
     uint32_t nbits;             /* bits in use (<= 64) */
     uint32_t nslices;           /* ceil(nbits / 8) */
@@ -47,6 +63,11 @@ struct sre_nfa_s {
     uint64_t accept[256];
     std::vector<uint64_t> follow;   /* [nslices][256] */
     std::vector<uint32_t> bit_pc;   /* [nbits] */
+    /* look-ahead assertions */
+    uint32_t nassert;               /* 0: none */
+    uint32_t assert_slice;          /* the byte of the mask that holds their bits */
+    uint8_t  kind[256];             /* per input byte: SRE_NFA_KIND_* | SRE_NFA_LEADING */
+    std::vector<uint64_t> expand;   /* [4 prev kinds][4 cur kinds][256 values of the assertion byte] */
 };
 typedef struct sre_nfa_s sre_nfa_t;
 
@@ -55,8 +76,8 @@ extern "C" {
 typedef struct sre_nfa_s sre_nfa_t;
 #endif
 
-/* NULL + *why when the program has no bit-parallel form (more than 64 bits,
- * look-ahead assertions, or a nullable regex: its first event is at offset 0) */
+/* NULL + *why when the program has no bit-parallel form (more than 64 bits, more than
+ * 8 look-ahead assertions, or a nullable regex: its first event is at offset 0) */
 sre_nfa_t *sre_nfa_build(const sre_program_t *prog, const char **why);
 void sre_nfa_free(sre_nfa_t *nfa);
 

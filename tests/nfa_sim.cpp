@@ -24,7 +24,18 @@ void nfa_sim_run(void *h, const uint8_t *data, int64_t n, int variant, int64_t *
     const sre_nfa_t *a = static_cast<sre_nfa_t *>(h);
     uint64_t S = a->init[variant];
     int64_t  clean = 0, ev = -1, hw = 0;
-    for (int64_t p = 0; p < n; p++) {
+    uint32_t prev = SRE_NFA_KIND_EDGE;          /* start of the stream */
+    for (int64_t p = 0; p <= n; p++) {
+        const uint32_t cur = p < n ? (a->kind[data[p]] & 3u) : (uint32_t) SRE_NFA_KIND_EDGE;
+        if (a->nassert) {
+            /* look-ahead assertions that hold list their continuation at this position */
+            S |= a->expand[(size_t) (prev * 4 + cur) * 256 + ((S >> (8 * a->assert_slice)) & 0xff)];
+            if (S & a->match_bits) {
+                ev = p;                         /* a listed MATCH is popped at this step */
+                break;
+            }
+        }
+        if (p == n) break;
         const uint64_t t = S & a->accept[data[p]];
         uint64_t       r = 0;
         for (uint32_t k = 0; k < a->nslices; k++) r |= a->follow[(size_t) k * 256 + ((t >> (8 * k)) & 0xff)];
@@ -35,6 +46,7 @@ void nfa_sim_run(void *h, const uint8_t *data, int64_t n, int variant, int64_t *
             break;
         }
         if ((t & ~a->any_bits) == 0) clean = p + 1;
+        prev = cur;
     }
     out[0] = ev;
     out[1] = clean;

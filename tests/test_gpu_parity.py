@@ -594,6 +594,9 @@ NFA_ZOO = [
     [rb"[a-z]+@[a-z]+\.[a-z]+"], [rb"([a-z]+)://([^/ ]+)(/[^ ?]*)?(\?[^ ]*)?"], [rb"a?a?a?aaa"],
     [rb"(a+)(b+)?"], [rb"(?:a.*b|a)"], [rb"\Aab|\n^b"], [rb"^b+"], [rb"(^|a)b"], [rb"(x+x+)+y"],
     [b"a", b"ab", b"c", b"a(bc)", b"e(f)", b"gh", b"A", b"b", b"BLAH", rb"\s+", b"abcd", b"bc"],
+    # look-ahead assertions: decided by the next byte inside the set step (expansion tables)
+    [rb"(\w+)\b(.)"], [rb"c$"], [rb"^(.*)$"], [rb"(a+)\b(?:\s|$)"], [rb"(\B.)*?\b(x)"], [rb"(b)\z"],
+    [rb"a$", rb"\bb"], [rb"(?:$|a)(b|\b)"], [rb"\bab\b"], [rb"x\B[ab]{2,8}\b"], [rb"^\xe7\xab\xa0$", rb"(a|b)*a(a|b){5}c"],
 ]
 
 
@@ -668,7 +671,7 @@ def test_nfa_tier_takes_what_the_step_automaton_declines(gpu, blocks):
     print("engine admission over the reference runs (AUTO, first match):", engines)
     assert not bad, (len(bad), bad[:5])
     assert n > 30, (n, engines)
-    assert engines[S.ENGINE_VM] < 600, engines
+    assert engines[S.ENGINE_VM] < 40, engines
 
 
 def test_nfa_tier_large_stream_closed_form(gpu):
@@ -739,7 +742,11 @@ def test_scanner_random_patterns_vs_oracle(gpu, seg):
                 engines[("scan", mode)] = sc
             for mode in (S.HIP_THOMPSON, S.HIP_PIKE_FIRST):
                 # the bit-parallel NFA tier, forced (it is chosen by itself only when the
-                # step automaton declines): set pass + exact VM window
+                # step automaton declines): set pass + exact VM window.  (Not the look-ahead
+                # programs the builder declines: the reference VM itself may diverge on them,
+                # DESIGN.md 5.)
+                if ("scan", S.HIP_PIKE_FIRST) not in engines and prog_has_lookahead(pats):
+                    continue
                 try:
                     sc = S.Scanner(pool, prog, mode, S.ENGINE_NFA)
                 except RuntimeError:

@@ -90,7 +90,7 @@ def test_sets_decide_thompson_and_bracket_pike_on_reference_blocks(sim, blocks):
                 admitted += 1
                 if r:
                     bad.append((blk["file"], blk["name"], name, r))
-    assert admitted > 1200, admitted
+    assert admitted > 3000, admitted
     assert not bad, (len(bad), bad[:5])
 
 
@@ -116,5 +116,5 @@ def test_sets_random_patterns_vs_oracle(sim):
                 admitted += 1
                 if r:
                     bad.append((pats, d, r))
-    assert admitted > 1000, admitted
+    assert admitted > 2000, admitted
     assert not bad, (len(bad), bad[:5])
