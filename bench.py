@@ -133,6 +133,18 @@ def workload_spec(name, S, nbytes, rank=0, world=1):
         elif name == "nfa":
             pats, tail = [NFA_PAT], b" abaabaabab@ "
             text = "declined by the step automaton: /(?:a|b)*a(?:a|b){7}@/ Pike first-match, NFA tier"
+        elif name in ("dense", "densef"):
+            # a match every MiB: the stream is one 1 MiB gen-data block with a matching tail, repeated
+            block = S.gen_data_length(1 << 20, 10)
+            nblk = max(1, nbytes // block)
+            mode = S.HIP_PIKE_COUNT if name == "dense" else S.HIP_PIKE_FIRST
+            text = ("configs[1] pattern, a match every MiB (%d x %d-byte gen-data blocks ending in ' a@abc.cc '), %s"
+                    % (nblk, block, "find-all count" if name == "dense" else "first match"))
+            return dict(name=name, pats=pats, mode=mode, lens=[nblk * block], tails=[b" a@abc.cc "], text=text,
+                        block=block, check=(
+                            (lambda recs, n=nblk * block, k=nblk: _assert_eq(recs[0], [0, k, n - 9, n - 1]))
+                            if name == "dense" else
+                            (lambda recs, b=block: _assert_eq(recs[0], [0, 1, b - 9, b - 1]))))
         n = S.gen_data_length(nbytes, len(tail))
         lens, tails = [n], [tail]
         text = "%s; 1 stream x %.2f GiB gen-data (abccc.. + %r)" % (text, n / GIB, tail.decode())
@@ -158,6 +170,10 @@ def workload_spec(name, S, nbytes, rank=0, world=1):
     return dict(name=name, pats=pats, mode=mode, lens=lens, tails=tails, text=text, check=check)
 
 
+def _assert_eq(got, want):
+    assert got == want, (got, want)
+
+
 class Resident:
     """device buffers of the rank, re-used by every workload of a run"""
 
@@ -170,21 +186,27 @@ class Resident:
             self._side = self.torch.cuda.Stream()
         return self._side
 
-    def fill(self, lens, tails):
+    def fill(self, lens, tails, block=0):
         need = [max(n, 16) for n in lens]
         if [b.numel() for b in self.bufs] != need:
             self.bufs = []
             self.torch.cuda.empty_cache()
             self.bufs = [self.torch.empty(n, dtype=self.torch.uint8, device="cuda") for n in need]
         for b, n, t in zip(self.bufs, lens, tails):
-            assert self.lib.sre_hip_gen_data(b.data_ptr(), n, t, len(t), self.hstream) == 0
+            if block:
+                # one generated block, repeated (a device-to-device broadcast copy)
+                assert self.lib.sre_hip_gen_data(b.data_ptr(), block, t, len(t), self.hstream) == 0
+                self.torch.cuda.synchronize()
+                b[block:n].view(-1, block).copy_(b[:block].expand(n // block - 1, block))
+            else:
+                assert self.lib.sre_hip_gen_data(b.data_ptr(), n, t, len(t), self.hstream) == 0
         return [b.data_ptr() for b in self.bufs]
 
 
 def measure(spec, S, torch, res, hstream, stream, steps, warmup, barrier):
     """W untimed + K timed passes of one workload over this rank's resident input,
     through the public batched C ABI, results included."""
-    ptrs = res.fill(spec["lens"], spec["tails"])
+    ptrs = res.fill(spec["lens"], spec["tails"], spec.get("block", 0))
     lens = spec["lens"]
     pool = S.Pool()
     prog = S.compile(pool, S.parse(pool, spec["pats"]))
@@ -236,7 +258,8 @@ def measure(spec, S, torch, res, hstream, stream, steps, warmup, barrier):
     # wall clock over the K steps (two streams: no single stream sees all of it)
     step_gpu_ms = dt / steps * 1e3
     out = dict(dt=dt, total=total, recs=recs, kernel_ms=kms, step_gpu_ms=step_gpu_ms,
-               matches=sum(1 for r in recs if r[0] >= 0),
+               matches=(sum(r[1] for r in recs if r[0] >= 0) if spec["mode"] == S.HIP_PIKE_COUNT
+                        else sum(1 for r in recs if r[0] >= 0)),
                segment_bytes=sc.last_segment_bytes, fixup_rounds=sc.last_fixups,
                lineage_passes=sc.last_lineage_passes, engine=sc.engine_name, kernel=sc.kernel_name)
     pool.destroy()
@@ -272,11 +295,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true",
                     help="N=1: do not measure the other configurations beside the headline (config.variants)")
-    ap.add_argument("--config", default="cfg2", choices=["cfg1", "cfg2", "cfg2m", "cfg3", "cfg4", "nfa"],
+    ap.add_argument("--config", default="cfg2", choices=["cfg1", "cfg2", "cfg2m", "cfg3", "cfg4", "nfa", "dense", "densef"],
                     help="N=1 headline workload: cfg2 = BASELINE configs[1] (default); cfg2m = same with a "
                          "matching tail (captures span the whole stream); cfg3 = configs[2] multi-regex "
                          "find-all count; cfg4 = configs[3] URI, 4 groups; cfg1 = configs[0]'s pattern, "
-                         "Thompson; nfa = a program the step automaton declines (NFA tier)")
+                         "Thompson; nfa = a program the step automaton declines (NFA tier); dense / densef = a match "
+                         "every MiB, find-all count / first match")
     ap.add_argument("--many-streams", action="store_true",
                     help="use the N>1 workload shape (64 MiB streams) even on one GPU")
     args = ap.parse_args()
@@ -376,7 +400,7 @@ def main():
             # time and whole-step fraction of the HBM peak (every kernel of the step), the
             # dominant kernel alone beside it
             variants = {}
-            for name in ("cfg2m", "cfg3", "cfg4", "nfa", "many"):
+            for name in ("cfg2m", "cfg3", "cfg4", "nfa", "dense", "densef", "many"):
                 try:
                     vs = workload_spec(name, S, 8 * GIB if name == "many" else args.bytes)
                     vm = measure(vs, S, torch, res, hstream, stream, min(args.steps, 6), 2, barrier)

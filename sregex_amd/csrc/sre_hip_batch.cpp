@@ -584,30 +584,22 @@ static int
 scan_settle(sre_hip_scanner_t *sc, size_t n, hipStream_t stream, bool with_captures, bool *psettled)
 {
     bool settled = true;
-        /* segments behind a broken state chain are re-run from the exact carried
-         * state until every stream's verified prefix reaches its end */
-        for (bool first = true;; first = false) {
-            if (!first) {
-                SRE_HIP_TRY(hipMemcpyAsync(sc->h_status, sc->d_status, n * sizeof(sre_stream_status_t),
-                                           hipMemcpyDeviceToHost, stream));
-                SRE_HIP_TRY(hipStreamSynchronize(stream));
-            }
-            size_t pending = 0;
-            for (size_t i = 0; i < n; i++) {
-                if (sc->h_status[i].done) {
-                    sc->h_lo[i] = -1;
-                } else {
-                    sc->h_lo[i] = sc->h_status[i].first_bad;
-                    pending++;
-                }
-            }
-            if (pending == 0) break;
-            settled = false;
+    int  batch = sc->mode == SRE_HIP_PIKE_COUNT ? 2 : SRE_SPECULATIVE_FIXUPS + 1;
+    /* h_status holds the status of the pass before.  Rounds are queued in batches and the
+     * status is read once per batch: a round finds its streams and their first wrong segment
+     * in the status words on the device, and is a no-op for a stream that has settled.
+     * FIRST / Thompson: two speculative rounds, then the exact entry states (all three
+     * queued at once); COUNT: 2, 4, 8, ... speculative rounds. */
+    for (;;) {
+        size_t pending = 0;
+        for (size_t i = 0; i < n; i++) pending += sc->h_status[i].done ? 0 : 1;
+        if (pending == 0) break;
+        settled = false;
+        for (int r = 0; r < batch; r++) {
             if (++sc->fixup_rounds > 1000000) {
                 fprintf(stderr, "[sregex-hip] scanner fix-up did not converge\n");
                 return -1;
             }
-            SRE_HIP_TRY(hipMemcpyAsync(sc->d_lo, sc->h_lo, n * sizeof(int64_t), hipMemcpyHostToDevice, stream));
             const uint8_t *d_entry = NULL;
             if (sc->mode != SRE_HIP_PIKE_COUNT && sc->fixup_rounds > SRE_SPECULATIVE_FIXUPS) {
                 /* speculation does not settle this stream (an automaton that never
@@ -630,7 +622,7 @@ scan_settle(sre_hip_scanner_t *sc, size_t n, hipStream_t stream, bool with_captu
                 d_entry = d_ent;
                 sc->exact_passes++;
             }
-            SRE_HIP_TRY(sre_launch_scan(sc->tab->d_tab, sc->tab->h, sc->geom, sc->d_sum, sc->d_lo, d_entry, stream));
+            SRE_HIP_TRY(sre_launch_scan(sc->tab->d_tab, sc->tab->h, sc->geom, sc->d_sum, sc->d_status, d_entry, stream));
             SRE_HIP_TRY(sre_launch_verify(sc->tab->h, sc->geom, sc->d_sum, sc->d_acc, sc->d_status, stream));
             if (with_captures) {
                 SRE_HIP_TRY(sre_launch_captures(sc->tab->d_tab, sc->tab->h, sc->geom, sc->d_sum,
@@ -638,6 +630,11 @@ scan_settle(sre_hip_scanner_t *sc, size_t n, hipStream_t stream, bool with_captu
                                                 sc->ovec_slots, NULL, NULL, 0, stream));
             }
         }
+        SRE_HIP_TRY(hipMemcpyAsync(sc->h_status, sc->d_status, n * sizeof(sre_stream_status_t),
+                                   hipMemcpyDeviceToHost, stream));
+        SRE_HIP_TRY(hipStreamSynchronize(stream));
+        batch = sc->mode == SRE_HIP_PIKE_COUNT ? (batch < 16 ? 2 * batch : 16) : 1;
+    }
     if (psettled) *psettled = settled;
     return 0;
 hip_failed:
@@ -797,7 +794,7 @@ sre_hip_scan_stream_chunk(sre_hip_scanner_t *sc, const void *d_buf, size_t len, 
     int continues, uint32_t entry_state, int eof, int64_t base, sre_stream_ctx_t *d_ctx,
     sre_stream_result_t *d_res, const sre_stream_result_t *h_res, uint32_t ovec_slots, hipStream_t stream)
 {
-    if (sc->engine != SRE_HIP_ENGINE_SCAN || sc->mode != SRE_HIP_PIKE_FIRST) return -1;
+    if (sc->engine != SRE_HIP_ENGINE_SCAN || sc->mode == SRE_HIP_PIKE_COUNT) return -1;
     sc->fixup_rounds = 0;
     sc->exact_passes = 0;
     sc->lineage_passes = 0;
@@ -839,8 +836,10 @@ hip_failed:
 extern "C" int
 sre_hip_scanner_streams(sre_hip_scanner_t *sc)
 {
-    return sc->engine == SRE_HIP_ENGINE_SCAN && sc->mode == SRE_HIP_PIKE_FIRST
-           && sc->tab->h.max_threads <= SRE_STREAM_MAX_THREADS && sc->tab->h.nslots <= SRE_STREAM_MAX_SLOTS;
+    if (sc->engine != SRE_HIP_ENGINE_SCAN) return 0;
+    if (sc->mode == SRE_HIP_THOMPSON) return 1;         /* the state alone */
+    return sc->mode == SRE_HIP_PIKE_FIRST && sc->tab->h.max_threads <= SRE_STREAM_MAX_THREADS
+           && sc->tab->h.nslots <= SRE_STREAM_MAX_SLOTS;
 }
 
 /* ------------------------------------------------------------------ helpers */

@@ -243,11 +243,12 @@ hipError_t sre_launch_read_pattern(const void *d_src, uint64_t n, uint32_t seg_b
 size_t sre_scan_lds_bytes(const sre_scan_tables_t *h_tab);
 int sre_scan_blocks_per_cu(const sre_scan_tables_t *h_tab);
 
-/* control pass over segments [lo[s], nseg_s) of every stream; lo == NULL: all.
- * carry[s] (with lo) = exact entry of segment lo[s] taken from summaries[lo[s]-1]. */
+/* control pass over every stream (d_lo == NULL), or a fix-up round: of every stream whose
+ * status (d_lo, from the previous round's sre_launch_verify) is not done, the segments from
+ * first_bad on; segment first_bad enters with the exact carry of summaries[first_bad - 1]. */
 /* d_entry (optional, with lo): exact entry state per segment, 0xff = none (sre_launch_exact_entries) */
 hipError_t sre_launch_scan(const sre_scan_tables_t *d_tab, sre_scan_tables_t h_tab,
-    sre_scan_geom_t geom, sre_seg_summary_t *d_sum, const int64_t *d_lo, const uint8_t *d_entry,
+    sre_scan_geom_t geom, sre_seg_summary_t *d_sum, const sre_stream_status_t *d_lo, const uint8_t *d_entry,
     hipStream_t stream);
 hipError_t sre_launch_exact_entries(const sre_scan_tables_t *d_tab, sre_scan_tables_t h_tab,
     sre_scan_geom_t geom, const sre_seg_summary_t *d_sum, const sre_stream_status_t *d_status,

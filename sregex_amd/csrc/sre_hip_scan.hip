@@ -461,7 +461,7 @@ byte_x4(uint32_t v, uint32_t sh)
 template <int MODE, int BITS, bool WIDE>
 __global__ __launch_bounds__(SRE_SCAN_BLOCK, MODE == SRE_HIP_PIKE_COUNT ? 3 : 4) void
 sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
-           sre_seg_summary_t *__restrict__ sum, const int64_t *__restrict__ lo,
+           sre_seg_summary_t *__restrict__ sum, const sre_stream_status_t *__restrict__ st_lo,
            const uint8_t *__restrict__ entry)
 {
     constexpr int      TILE = SRE_SCAN_ROUND;
@@ -544,6 +544,7 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
     bool           active = g < G.nsegs;
     uint32_t       sidx = 0;
     uint64_t       k = 0;                   /* segment index inside the stream */
+    int64_t        lo_s = -2;               /* first segment of this stream that is re-run (-2: first pass) */
     if (active) {
         uint32_t a = 0, b = G.nstreams;     /* seg_first[a] <= g < seg_first[b] */
         while (b - a > 1) {
@@ -552,7 +553,12 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
         }
         sidx = a;
         k = g - G.seg_first[a];
-        if (lo != nullptr && (lo[sidx] < 0 || (int64_t) k < lo[sidx])) active = false;
+        /* a fix-up round: the streams that are not settled yet, from their first wrong
+         * segment on — read from the status words of the previous round, on the device */
+        if (st_lo != nullptr) {
+            lo_s = st_lo[sidx].done ? -1 : st_lo[sidx].first_bad;
+            if (lo_s < 0 || (int64_t) k < lo_s) active = false;
+        }
     }
 
     Walk w;
@@ -600,7 +606,7 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
              * state the previous chunk ended in (sre_k_stream_tail) */
             w.st = (G.flags & SRE_GEOM_CONTINUES) ? G.entry_state : T.init[G.init_variant];
             w.cur_sp = 0;
-        } else if (lo != nullptr && (int64_t) k == lo[sidx]) {
+        } else if (lo_s >= 0 && (int64_t) k == lo_s) {
             /* exact carry from the verified predecessor */
             const sre_seg_summary_t &c = sum[g - 1];
             w.st = c.s_out & ~SRE_STATE_SKIP;
@@ -634,8 +640,8 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
              * recur), otherwise from the initial state. */
             warm = true;
             seed = T.init[0];
-            if (lo != nullptr && lo[sidx] > 0) {
-                const sre_seg_summary_t &c = sum[G.seg_first[sidx] + lo[sidx] - 1];
+            if (lo_s > 0) {
+                const sre_seg_summary_t &c = sum[G.seg_first[sidx] + lo_s - 1];
                 const uint32_t           cs = c.s_out & ~SRE_STATE_SKIP;
                 if (cs != 0) {
                     if (!(MODE == SRE_HIP_PIKE_COUNT && (T.state_flags[cs] & 1))) {
@@ -1973,6 +1979,23 @@ sre_k_stream_tail(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
         res->rc = SRE_STREAM_UNSETTLED;
         return;
     }
+    if (T.mode == 0) {
+        /* Thompson (sre_vm_thompson.c:63-270): SRE_OK at the first MATCH thread met, else
+         * SRE_DECLINED at eof / SRE_AGAIN with the list (= the state) carried on */
+        if (st.ev_pos >= 0) {
+            res->rc = 0;
+            ctx->state = 0;
+        } else if (eof) {
+            res->rc = RC_DECLINED;
+            ctx->state = 0;
+        } else {
+            const uint32_t sF = sum[nseg - 1].s_out & ~SRE_STATE_SKIP;
+            ctx->state = tabp->unskip[sF];
+            res->next_state = ctx->state;
+            res->rc = -2;                   /* SRE_AGAIN */
+        }
+        return;
+    }
 
     Tracer tr;
     tr.T = &T;
@@ -2109,7 +2132,7 @@ sre_k_stream_tail(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
 }  // namespace
 
 typedef void (*sre_scan_kernel_t)(const sre_scan_tables_t *, sre_scan_geom_t, sre_seg_summary_t *,
-                                  const int64_t *, const uint8_t *);
+                                  const sre_stream_status_t *, const uint8_t *);
 
 template <int MODE>
 static sre_scan_kernel_t
@@ -2168,7 +2191,8 @@ sre_scan_blocks_per_cu(const sre_scan_tables_t *h_tab)
 
 extern "C" hipError_t
 sre_launch_scan(const sre_scan_tables_t *d_tab, sre_scan_tables_t h_tab, sre_scan_geom_t geom,
-                sre_seg_summary_t *d_sum, const int64_t *d_lo, const uint8_t *d_entry, hipStream_t stream)
+                sre_seg_summary_t *d_sum, const sre_stream_status_t *d_lo, const uint8_t *d_entry,
+                hipStream_t stream)
 {
     if (geom.nsegs == 0) return hipSuccess;
     const uint32_t grid = (uint32_t) ((geom.nsegs + SRE_SCAN_BLOCK - 1) / SRE_SCAN_BLOCK);

@@ -600,7 +600,54 @@ struct sre_vm_thompson_ctx_s {
     int            started;
     sre_hip_scanner_t *scanner;
     int            scanner_tried;
+    /* a stream fed in chunks on the scanner: the list travels as the automaton state */
+    int            stream_mode, finished;
+    uint32_t       stream_state;
 };
+
+/* One chunk of a chunked stream (sre_vm_thompson.c:63-270) on the scanner.  Without
+ * look-ahead assertions no closure runs at the first byte of a later chunk, so the
+ * chunk-local \A / ^ of this VM (:302-317) cannot be observed and the whole-buffer
+ * automaton is exact; look-ahead programs stay on the exact VM kernel. */
+static int
+thompson_stream_route(sre_vm_thompson_ctx_t *ctx, sre_char *input, size_t len, unsigned eof, sre_int_t *prc)
+{
+    if (!ctx->scanner_tried) {
+        ctx->scanner_tried = 1;
+        ctx->scanner = compat_scanner(ctx->prog, SRE_HIP_THOMPSON);
+    }
+    if (ctx->scanner == NULL || !sre_hip_scanner_streams(ctx->scanner) || ctx->prog->lookahead_asserts) return 0;
+    DeviceStream *ds = ctx->ds;
+    if (ds->d_sctx == NULL) {
+        if (hipMalloc(reinterpret_cast<void **>(&ds->d_sctx), sizeof(sre_stream_ctx_t)) != hipSuccess
+            || hipHostMalloc(reinterpret_cast<void **>(&ds->h_sres), sizeof(sre_stream_result_t), hipHostMallocMapped)
+                   != hipSuccess
+            || hipHostGetDevicePointer(reinterpret_cast<void **>(&ds->d_sres), ds->h_sres, 0) != hipSuccess)
+        {
+            return 0;
+        }
+    }
+    if (stage_input(ds, input, len) != 0) return 0;
+    ds->h_sres->rc = SRE_ERROR;
+    if (sre_hip_scan_stream_chunk(ctx->scanner, ds->d_in, len, 0, ctx->stream_mode, ctx->stream_state, eof ? 1 : 0, 0,
+                                  ds->d_sctx, ds->d_sres, ds->h_sres, 0, ds->stream) != 0)
+    {
+        ds->failed = 1;
+        *prc = SRE_ERROR;
+        return 1;
+    }
+    const sre_int_t rc = (sre_int_t) ds->h_sres->rc;
+    ctx->started = 1;
+    if (rc == SRE_AGAIN) {
+        ctx->stream_mode = 1;
+        ctx->stream_state = (uint32_t) ds->h_sres->next_state;
+    } else {
+        ctx->stream_mode = 0;
+        ctx->finished = 1;
+    }
+    *prc = rc == SRE_OK || rc == SRE_AGAIN || rc == SRE_DECLINED ? rc : SRE_ERROR;
+    return 1;
+}
 
 extern "C" SRE_API sre_vm_thompson_ctx_t *
 sre_vm_thompson_create_ctx(sre_pool_t *pool, sre_program_t *prog)
@@ -623,6 +670,11 @@ sre_vm_thompson_exec(sre_vm_thompson_ctx_t *ctx, sre_char *input, size_t len, un
         if (ctx->ds == NULL) return SRE_ERROR;
     }
     if (ctx->ds->failed) return SRE_ERROR;
+    if (!ctx->finished && (ctx->stream_mode || (!ctx->started && !eof && len >= SRE_COMPAT_STREAM_MIN_BYTES))) {
+        sre_int_t rc;
+        if (thompson_stream_route(ctx, input, len, eof, &rc)) return rc;
+        if (ctx->stream_mode) return SRE_ERROR;
+    }
     if (!ctx->started && eof && len >= SRE_COMPAT_SCAN_MIN_BYTES) {
         /* first and only chunk of a large stream: match / no match from the scanner */
         if (!ctx->scanner_tried) {

@@ -412,7 +412,7 @@ def test_compat_api_chunked_streams_take_the_scanner(gpu):
     import random
     ora = harness.OracleEngine()
     eng = harness.ProductEngine()
-    rng = random.Random(4242)
+    rng = random.Random(4242 + int(os.environ.get("SRE_FUZZ_SEED", "0")))
     cfg3 = [b"a", b"ab", b"c", b"a(bc)", b"e(f)", b"gh", b"A", b"b", b"BLAH", rb"\s+", b"abcd", b"bc"]
     zoo = [[rb"[a-z]+@[a-z]+\.[a-z]+"], [rb"([a-z]+)://([^/ ]+)(/[^ ?]*)?(\?[^ ]*)?"], [rb"a?a?a?aaa"],
            [rb"(a+)(b+)?"], [rb"(?:a.*b|a)"], [rb"x(.*)y(.*)z"], [rb"(a|ab)(c|bcd)(d*)"], cfg3,
@@ -438,6 +438,39 @@ def test_compat_api_chunked_streams_take_the_scanner(gpu):
                 assert got == want, (pats, len(data), sizes, got[-3:], want[-3:])
                 eng.recycle()
     assert n == 72
+    # sre_vm_thompson_exec in chunks: the list travels as the automaton state alone
+    n = 0
+    for pats in zoo:
+        with S.Pool() as pool:
+            re = S.parse(pool, pats)
+            prog = S.compile(pool, re)
+            for trial in range(4):
+                if trial < 2:
+                    data = S.gen_data_host(rng.choice([9000, 40000, 150000]), tails[rng.randrange(len(tails))])
+                else:
+                    alpha = [b"abc", b"ab c\n.x@:/?y"][trial - 2]
+                    data = bytes(rng.choice(alpha) for _ in range(rng.choice([5000, 20000, 70000])))
+                    if trial == 3:
+                        data = data.replace(b"a", b"d")     # mostly no match: AGAIN ... DECLINED
+                first = rng.choice([4096, 5000, 8192, 30000])
+                sizes = [first] + [rng.choice([0, 1, 7, 64, 1000, 4096, 10000, 33333]) for _ in range(rng.randrange(0, 9))]
+                res = []
+                for e in (ora, eng):
+                    ctx, off, rcs, todo = e.thompson(prog), 0, [], list(sizes)
+                    while True:
+                        k = min(todo.pop(0) if todo else len(data) - off, len(data) - off)
+                        eof = off + k >= len(data) and not todo
+                        rc = ctx.exec(data[off:off + k], eof)
+                        rc = rc[0] if isinstance(rc, (list, tuple)) else rc
+                        rcs.append(rc)
+                        off += k
+                        if rc != S.SRE_AGAIN:
+                            break
+                    res.append(rcs)
+                n += 1
+                assert res[0] == res[1], (pats, len(data), sizes, res)
+                eng.recycle()
+    assert n == 48
     # find-all over a chunked stream: after each match the caller re-feeds from the match end
     chunk = S.gen_data_host(50000, b" bob@example.com\n")
     for pats, data in (([rb"([a-z]+)@([a-z]+)\.[a-z]+"], chunk * 3 + b"x@y.z"), ([rb"^abc"], (b"abccc" * 3000 + b"\n") * 3)):
