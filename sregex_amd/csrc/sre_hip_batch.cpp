@@ -63,6 +63,7 @@ struct sre_hip_scanner_s {
     int                       lineage_passes;   /* of the last scan (diagnostics) */
     uint32_t                  next_init_variant;    /* compat path: a re-armed context's search */
     int                       blocks_per_cu;
+    uint32_t                  geom_one;         /* SRE_GEOM_ONE when the batch in flight is one stream in the kernel arguments */
     int                       fixup_rounds;     /* of the last scan (diagnostics) */
     hipEvent_t                ev0, ev1;         /* around the dominant scan kernel */
     int                       ev_valid;
@@ -425,7 +426,10 @@ scan_geometry(sre_hip_scanner_t *sc, size_t nstreams)
          * slots ran 30 % slower than 505 */
         const uint64_t lanes = resident * rounds - (resident * rounds >> 6);
         seg = (total / lanes + SRE_SCAN_SEG_ALIGN) / SRE_SCAN_SEG_ALIGN * SRE_SCAN_SEG_ALIGN;
-        if (seg < 1024) seg = 1024;
+        /* a small batch does not fill the chip whatever the segment size, and a lane's walk
+         * is a serial chain (~1.5 us per 64-byte round): short segments, although half of
+         * what such a lane reads is then warm-up (a 1 MiB chunk: 35 us at 1 KiB, 13 us at 256 B) */
+        if (seg < 256) seg = 256;
         /* rows that are a multiple of 4 KiB apart land on the same HBM channels */
         if (seg % 4096 == 0) seg += SRE_SCAN_SEG_ALIGN;
     }
@@ -442,6 +446,12 @@ scan_geometry(sre_hip_scanner_t *sc, size_t nstreams)
     sc->geom.nstreams = (uint32_t) nstreams;
     sc->geom.seg_bytes = (uint32_t) seg;
     sc->geom.nsegs = nsegs;
+    /* one stream: described in the kernel arguments, nothing to upload (table-driven
+     * scanner; the NFA tier's window kernel reads the arrays) */
+    sc->geom.one_ptr = static_cast<const uint8_t *>(sc->h_ptrs[0]);
+    sc->geom.one_len = sc->h_lens[0];
+    sc->geom_one = (nstreams == 1 && sc->engine == SRE_HIP_ENGINE_SCAN) ? SRE_GEOM_ONE : 0u;
+    sc->geom.flags = (sc->geom.flags & ~SRE_GEOM_ONE) | sc->geom_one;
 
     if (sc->engine == SRE_HIP_ENGINE_NFA) {
         if (nsegs > sc->nsum_cap) {
@@ -546,8 +556,10 @@ sre_hip_scan_enqueue(sre_hip_scanner_t *sc, const void *const *d_streams, const 
         if (nfa_finish(sc, NULL, stream) != 0) return -1;
     } else {
         if (scan_geometry(sc, nstreams) != 0) return -1;
-        SRE_HIP_TRY(hipMemcpyAsync(sc->d_in, sc->h_in, (3 * nstreams + 1) * sizeof(uint64_t),
-                                   hipMemcpyHostToDevice, stream));
+        if (!sc->geom_one) {
+            SRE_HIP_TRY(hipMemcpyAsync(sc->d_in, sc->h_in, (3 * nstreams + 1) * sizeof(uint64_t),
+                                       hipMemcpyHostToDevice, stream));
+        }
         /* speculative pass, chain check, captures — all queued; results() only
          * has to look at the status words */
         if (sc->ev0 == NULL) {
@@ -804,15 +816,14 @@ sre_hip_scan_stream_chunk(sre_hip_scanner_t *sc, const void *d_buf, size_t len, 
     sc->h_lens[0] = len;
     sc->geom.init_variant = (uint32_t) init_variant;
     if (scan_geometry(sc, 1) != 0) return -1;
-    sc->geom.flags = (continues ? SRE_GEOM_CONTINUES : 0u) | (eof ? 0u : SRE_GEOM_NO_EOF);
+    sc->geom.flags = (continues ? SRE_GEOM_CONTINUES : 0u) | (eof ? 0u : SRE_GEOM_NO_EOF) | sc->geom_one;
     sc->geom.entry_state = entry_state;
-    SRE_HIP_TRY(hipMemcpyAsync(sc->d_in, sc->h_in, 4 * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
+    /* two launches per chunk: the scan, and the chain check + tail in one workgroup; should
+     * the speculative entry states of the chunk's lanes have been wrong (rare), the tail
+     * says so and the rounds are run first */
     SRE_HIP_TRY(sre_launch_scan(sc->tab->d_tab, sc->tab->h, sc->geom, sc->d_sum, NULL, NULL, stream));
-    SRE_HIP_TRY(sre_launch_verify(sc->tab->h, sc->geom, sc->d_sum, sc->d_acc, sc->d_status, stream));
-    /* the tail runs right behind the chain check; should the speculative entry states of
-     * the chunk's lanes have been wrong (rare), it says so and the rounds are run first */
     SRE_HIP_TRY(sre_launch_stream_tail(sc->tab->d_tab, sc->tab->h, sc->geom, sc->d_sum, sc->d_status,
-                                       sc->d_scratch, d_ctx, d_res, base, eof, ovec_slots, stream));
+                                       sc->d_scratch, d_ctx, d_res, base, eof, ovec_slots, 1, stream));
     SRE_HIP_TRY(hipStreamSynchronize(stream));
     if (h_res->rc == SRE_STREAM_UNSETTLED) {
         SRE_HIP_TRY(hipMemcpyAsync(sc->h_status, sc->d_status, sizeof(sre_stream_status_t),
@@ -820,7 +831,7 @@ sre_hip_scan_stream_chunk(sre_hip_scanner_t *sc, const void *d_buf, size_t len, 
         SRE_HIP_TRY(hipStreamSynchronize(stream));
         if (scan_settle(sc, 1, stream, false, NULL) != 0) goto hip_failed;
         SRE_HIP_TRY(sre_launch_stream_tail(sc->tab->d_tab, sc->tab->h, sc->geom, sc->d_sum, sc->d_status,
-                                           sc->d_scratch, d_ctx, d_res, base, eof, ovec_slots, stream));
+                                           sc->d_scratch, d_ctx, d_res, base, eof, ovec_slots, 0, stream));
         SRE_HIP_TRY(hipStreamSynchronize(stream));
     }
     sc->geom.flags = 0;

@@ -41,7 +41,7 @@ nfa_stream_of(const sre_scan_geom_t &G, uint64_t g)
     uint32_t a = 0, b = G.nstreams;
     while (b - a > 1) {
         uint32_t m = (a + b) >> 1;
-        if (G.seg_first[m] <= g) a = m; else b = m;
+        if (geom_first(G, m) <= g) a = m; else b = m;
     }
     return a;
 }
@@ -149,7 +149,7 @@ sre_k_nfa(sre_nfa_tables_t T, sre_scan_geom_t G, sre_nfa_summary_t *__restrict__
     uint64_t       k = 0;
     if (active) {
         sidx = nfa_stream_of(G, g);
-        k = g - G.seg_first[sidx];
+        k = g - geom_first(G, sidx);
         if (lo != nullptr && (lo[sidx] < 0 || (int64_t) k < lo[sidx])) active = false;
     }
 
@@ -165,11 +165,11 @@ sre_k_nfa(sre_nfa_tables_t T, sre_scan_geom_t G, sre_nfa_summary_t *__restrict__
     mine.lo = 0;
     mine.hi16 = -1;
     if (active) {
-        data = G.streams[sidx];
-        n = (int64_t) G.lens[sidx];
+        data = geom_ptr(G, sidx);
+        n = (int64_t) geom_len(G, sidx);
         seg_a = (int64_t) k * G.seg_bytes;
         seg_b = seg_a + G.seg_bytes;
-        last_seg = (k + 1 == G.seg_first[sidx + 1] - G.seg_first[sidx]);
+        last_seg = (k + 1 == geom_first(G, sidx + 1) - geom_first(G, sidx));
         if (seg_b > n) seg_b = n;
         if (k == 0) {
             S = (M) T.init[G.init_variant];
@@ -378,7 +378,7 @@ sre_k_nfa_verify_a(sre_scan_geom_t G, const sre_nfa_summary_t *__restrict__ sum,
     const uint64_t g = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= G.nsegs) return;
     const uint32_t s = nfa_stream_of(G, g);
-    const uint64_t k = g - G.seg_first[s];
+    const uint64_t k = g - geom_first(G, s);
     if (k > 0) {
         const sre_nfa_summary_t &p = sum[g - 1];
         /* behind a segment that ended the scan nothing is needed */
@@ -408,8 +408,8 @@ sre_k_nfa_verify_b(sre_scan_geom_t G, const sre_nfa_summary_t *__restrict__ sum,
     uint32_t           s = s_first;
     if (g < G.nsegs) {
         if (!uniform) s = nfa_stream_of(G, g);
-        const uint64_t k = g - G.seg_first[s];
-        const uint64_t nseg = G.seg_first[s + 1] - G.seg_first[s];
+        const uint64_t k = g - geom_first(G, s);
+        const uint64_t nseg = geom_first(G, s + 1) - geom_first(G, s);
         uint64_t       bad = acc[s].bad, end = acc[s].end;
         if (bad > nseg) bad = nseg;
         if (end > nseg) end = nseg;
@@ -443,7 +443,7 @@ sre_k_nfa_verify_c(int mode, sre_scan_geom_t G, const sre_nfa_summary_t *__restr
     accs[s].bad = accs[s].end = ~0ull;
     accs[s].clean = 0;
     if (lo != nullptr && lo[s] < 0) return;     /* settled in an earlier round */
-    const uint64_t first = G.seg_first[s], nseg = G.seg_first[s + 1] - first;
+    const uint64_t first = geom_first(G, s), nseg = geom_first(G, s + 1) - first;
     uint64_t       bad = acc.bad, end = acc.end;
     if (bad > nseg) bad = nseg;
     if (end > nseg) end = nseg;

@@ -224,10 +224,34 @@ typedef struct {
     uint32_t init_variant;          /* SRE_DFA_INIT_* of the search that starts at offset 0 */
     uint32_t flags;                 /* SRE_GEOM_* */
     uint32_t entry_state;           /* SRE_GEOM_CONTINUES: the automaton state in front of offset 0 */
+    /* SRE_GEOM_ONE: the only stream, in the kernel arguments themselves (the three arrays
+     * are not read: a call on one buffer uploads nothing) */
+    const uint8_t *one_ptr;
+    uint64_t one_len;
 } sre_scan_geom_t;
 
 #define SRE_GEOM_CONTINUES 1u       /* the buffers are chunks of streams whose search began earlier */
 #define SRE_GEOM_NO_EOF    2u       /* more chunks follow: no EOF step at the end of the buffer */
+#define SRE_GEOM_ONE       4u       /* nstreams == 1, described by one_ptr / one_len / nsegs */
+
+#ifdef __HIPCC__
+static __device__ inline const uint8_t *
+geom_ptr(const sre_scan_geom_t &G, uint32_t s)
+{
+    return (G.flags & SRE_GEOM_ONE) ? G.one_ptr : G.streams[s];
+}
+static __device__ inline uint64_t
+geom_len(const sre_scan_geom_t &G, uint32_t s)
+{
+    return (G.flags & SRE_GEOM_ONE) ? G.one_len : G.lens[s];
+}
+/* first segment of stream i (i == nstreams: the total) */
+static __device__ inline uint64_t
+geom_first(const sre_scan_geom_t &G, uint32_t i)
+{
+    return (G.flags & SRE_GEOM_ONE) ? (i ? G.nsegs : 0) : G.seg_first[i];
+}
+#endif
 
 #ifdef __cplusplus
 extern "C" {
@@ -253,13 +277,15 @@ hipError_t sre_launch_scan(const sre_scan_tables_t *d_tab, sre_scan_tables_t h_t
 hipError_t sre_launch_exact_entries(const sre_scan_tables_t *d_tab, sre_scan_tables_t h_tab,
     sre_scan_geom_t geom, const sre_seg_summary_t *d_sum, const sre_stream_status_t *d_status,
     uint8_t *d_fn, uint8_t *d_comp, uint8_t *d_chunk_entry, uint8_t *d_entry, hipStream_t stream);
-/* streaming: finish one chunk of ONE stream (geom.nstreams == 1) after scan + verify:
- * the match if the search ended, else the carried state for the next chunk and the
- * temporary / pending captures of SRE_AGAIN.  `base` = absolute offset of the chunk. */
+/* streaming: finish one chunk of ONE stream (geom.nstreams == 1) after the scan: the match
+ * if the search ended, else the carried state for the next chunk and the temporary /
+ * pending captures of SRE_AGAIN.  `base` = absolute offset of the chunk.  verify != 0: the
+ * chain check runs inside the same kernel (no sre_launch_verify in front) and writes
+ * *d_status; else *d_status is what sre_launch_verify left. */
 hipError_t sre_launch_stream_tail(const sre_scan_tables_t *d_tab, sre_scan_tables_t h_tab,
-    sre_scan_geom_t geom, const sre_seg_summary_t *d_sum, const sre_stream_status_t *d_status,
+    sre_scan_geom_t geom, const sre_seg_summary_t *d_sum, sre_stream_status_t *d_status,
     uint16_t *d_scratch, sre_stream_ctx_t *d_ctx, sre_stream_result_t *result, int64_t base, int eof,
-    uint32_t ovec_slots, hipStream_t stream);
+    uint32_t ovec_slots, int verify, hipStream_t stream);
 size_t sre_scan_verify_acc_bytes(uint32_t nstreams);
 hipError_t sre_scan_verify_acc_init(void *d_acc, uint32_t nstreams, hipStream_t stream);
 hipError_t sre_launch_verify(sre_scan_tables_t h_tab, sre_scan_geom_t geom,

@@ -185,7 +185,7 @@ stream_of(const sre_scan_geom_t &G, uint64_t g)
     uint32_t a = 0, b = G.nstreams;
     while (b - a > 1) {
         uint32_t m = (a + b) >> 1;
-        if (G.seg_first[m] <= g) a = m; else b = m;
+        if (geom_first(G, m) <= g) a = m; else b = m;
     }
     return a;
 }
@@ -451,6 +451,10 @@ byte_x4(uint32_t v, uint32_t sh)
     return r;
 }
 
+#ifndef SRE_COUNT_BLOCKS
+#define SRE_COUNT_BLOCKS 3          /* workgroups per CU the COUNT kernel's registers are budgeted for */
+#endif
+
 /*
  * BITS = class bits per input byte: one fast-table lookup advances 8 / BITS
  * bytes (BITS == 8: the index is the byte itself).  A lane consumes
@@ -459,7 +463,7 @@ byte_x4(uint32_t v, uint32_t sh)
  * same fast loop, nothing recorded.
  */
 template <int MODE, int BITS, bool WIDE>
-__global__ __launch_bounds__(SRE_SCAN_BLOCK, MODE == SRE_HIP_PIKE_COUNT ? 3 : 4) void
+__global__ __launch_bounds__(SRE_SCAN_BLOCK, MODE == SRE_HIP_PIKE_COUNT ? SRE_COUNT_BLOCKS : 4) void
 sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
            sre_seg_summary_t *__restrict__ sum, const sre_stream_status_t *__restrict__ st_lo,
            const uint8_t *__restrict__ entry)
@@ -549,10 +553,10 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
         uint32_t a = 0, b = G.nstreams;     /* seg_first[a] <= g < seg_first[b] */
         while (b - a > 1) {
             uint32_t m = (a + b) >> 1;
-            if (G.seg_first[m] <= g) a = m; else b = m;
+            if (geom_first(G, m) <= g) a = m; else b = m;
         }
         sidx = a;
-        k = g - G.seg_first[a];
+        k = g - geom_first(G, a);
         /* a fix-up round: the streams that are not settled yet, from their first wrong
          * segment on — read from the status words of the previous round, on the device */
         if (st_lo != nullptr) {
@@ -593,11 +597,11 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
     mine.lo = 0;
     mine.hi16 = -1;                         /* nothing readable */
     if (active) {
-        w.data = G.streams[sidx];
-        w.n = (int64_t) G.lens[sidx];
+        w.data = geom_ptr(G, sidx);
+        w.n = (int64_t) geom_len(G, sidx);
         seg_a = (int64_t) k * G.seg_bytes;
         seg_b = seg_a + G.seg_bytes;
-        const uint64_t nseg = G.seg_first[sidx + 1] - G.seg_first[sidx];
+        const uint64_t nseg = geom_first(G, sidx + 1) - geom_first(G, sidx);
         last_seg = (k + 1 == nseg);
         if (seg_b > w.n) seg_b = w.n;
 
@@ -641,7 +645,7 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
             warm = true;
             seed = T.init[0];
             if (lo_s > 0) {
-                const sre_seg_summary_t &c = sum[G.seg_first[sidx] + lo_s - 1];
+                const sre_seg_summary_t &c = sum[geom_first(G, sidx) + lo_s - 1];
                 const uint32_t           cs = c.s_out & ~SRE_STATE_SKIP;
                 if (cs != 0) {
                     if (!(MODE == SRE_HIP_PIKE_COUNT && (T.state_flags[cs] & 1))) {
@@ -990,14 +994,14 @@ sre_k_seg_functions(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t 
     const uint64_t g = (uint64_t) blockIdx.x * 4 + (tid >> 6);
     if (g >= G.nsegs) return;
     const uint32_t s = stream_of(G, g);
-    const uint64_t k = g - G.seg_first[s];
+    const uint64_t k = g - geom_first(G, s);
     if (status[s].done || (int64_t) k < status[s].first_bad) return;
     if (lane >= nst) {
         fn[g * 64 + lane] = 0;
         return;
     }
-    const uint8_t *data = G.streams[s];
-    const int64_t  n = (int64_t) G.lens[s];
+    const uint8_t *data = geom_ptr(G, s);
+    const int64_t  n = (int64_t) geom_len(G, s);
     int64_t        p = (int64_t) k * G.seg_bytes, seg_b = p + G.seg_bytes;
     if (seg_b > n) seg_b = n;
     uint32_t cur = lane;
@@ -1044,7 +1048,7 @@ sre_k_fn_resolve(sre_scan_geom_t G, const sre_seg_summary_t *__restrict__ sum,
 {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= G.nstreams || status[s].done || status[s].first_bad < 1) return;
-    const uint64_t first = G.seg_first[s], g_hi = G.seg_first[s + 1];
+    const uint64_t first = geom_first(G, s), g_hi = geom_first(G, s + 1);
     uint64_t       g = first + (uint64_t) status[s].first_bad;
     uint32_t       v = sum[g - 1].s_out & 63u;          /* the verified prefix's exit state */
     while (g < g_hi) {
@@ -1097,7 +1101,7 @@ sre_k_verify_a(sre_scan_geom_t G, const sre_seg_summary_t *__restrict__ sum, Ver
     const uint64_t g = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= G.nsegs) return;
     const uint32_t s = stream_of(G, g);
-    const uint64_t k = g - G.seg_first[s];
+    const uint64_t k = g - geom_first(G, s);
     const uint32_t s_in = sum[g].s_in;
     bool           bad = s_in == 0xffffffffu;
     if (k > 0) {
@@ -1136,8 +1140,8 @@ sre_k_verify_b(sre_scan_geom_t G, const sre_seg_summary_t *__restrict__ sum, Ver
     unsigned long long my_count = 0, my_ev = 0, my_sp = 0;
     if (g < G.nsegs) {
         const uint32_t s = uniform ? s_first : stream_of(G, g);
-        const uint64_t k = g - G.seg_first[s];
-        const uint64_t nseg = G.seg_first[s + 1] - G.seg_first[s];
+        const uint64_t k = g - geom_first(G, s);
+        const uint64_t nseg = geom_first(G, s + 1) - geom_first(G, s);
         uint64_t       bad = acc[s].bad, end = acc[s].end;
         if (bad > nseg) bad = nseg;
         if (end > nseg) end = nseg;
@@ -1194,9 +1198,9 @@ sre_k_verify_b2(sre_scan_geom_t G, const sre_seg_summary_t *__restrict__ sum, Ve
     uint32_t           s = s_first;
     if (g < G.nsegs) {
         if (!uniform) s = stream_of(G, g);
-        const uint64_t k = g - G.seg_first[s];
+        const uint64_t k = g - geom_first(G, s);
         const uint64_t evseg = acc[s].evseg;        /* 1 + the event's segment, 0 none */
-        const uint64_t nseg = G.seg_first[s + 1] - G.seg_first[s];
+        const uint64_t nseg = geom_first(G, s + 1) - geom_first(G, s);
         if (!(sum[g].flags & SRE_SUM_STABLE)) {
             if (evseg != 0 && k + 1 < evseg) mine = k + 1;
             /* (streaming: the walks that start at the end of a chunk; its last segment is
@@ -1225,17 +1229,11 @@ sre_k_verify_b2(sre_scan_geom_t G, const sre_seg_summary_t *__restrict__ sum, Ve
     }
 }
 
-__global__ void
-sre_k_verify_c(sre_scan_tables_t T, sre_scan_geom_t G, const sre_seg_summary_t *__restrict__ sum,
-               VerifyAcc *__restrict__ accs, sre_stream_status_t *__restrict__ status)
+/* the status word of one stream from its accumulated chain-check results; `sum` = the
+ * stream's first summary */
+__device__ inline sre_stream_status_t
+assemble_status(const sre_scan_tables_t &T, const sre_seg_summary_t *__restrict__ sum, uint64_t nseg, const VerifyAcc &acc)
 {
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= G.nstreams) return;
-    /* take this stream's accumulator and leave it reset for the next pass */
-    const VerifyAcc acc = accs[s];
-    accs[s].bad = accs[s].end = ~0ull;
-    accs[s].count = accs[s].evseg = accs[s].spseg = accs[s].unst = accs[s].unst_end = 0;
-    const uint64_t first = G.seg_first[s], nseg = G.seg_first[s + 1] - first;
     uint64_t       bad = acc.bad, end = acc.end;
     if (bad > nseg) bad = nseg;
     if (end > nseg) end = nseg;
@@ -1261,7 +1259,7 @@ sre_k_verify_c(sre_scan_tables_t T, sre_scan_geom_t G, const sre_seg_summary_t *
     st.unst_seg = acc.unst ? (int64_t) acc.unst - 1 : -1;
     st.unst_end = acc.unst_end ? (int64_t) acc.unst_end - 1 : -1;
     if (done && evseg > 0) {
-        const sre_seg_summary_t &c = sum[first + evseg - 1];
+        const sre_seg_summary_t &c = sum[evseg - 1];
         st.ev_apos = c.lm_apos;
         st.ev_astate = c.lm_astate;
         st.ev_state = c.lm_state;
@@ -1280,11 +1278,11 @@ sre_k_verify_c(sre_scan_tables_t T, sre_scan_geom_t G, const sre_seg_summary_t *
             if (T.mode != SRE_HIP_PIKE_COUNT || spseg == 0) {
                 sp = 0;                     /* one search per stream, from its start */
             } else if (spseg < evseg) {
-                sp = sum[first + spseg - 1].cur_sp;
+                sp = sum[spseg - 1].cur_sp;
             } else {
                 for (int64_t q = (int64_t) evseg - 2; q >= 0; q--) {
-                    if (sum[first + q].cur_sp >= 0) {
-                        sp = sum[first + q].cur_sp;
+                    if (sum[q].cur_sp >= 0) {
+                        sp = sum[q].cur_sp;
                         break;
                     }
                 }
@@ -1292,8 +1290,114 @@ sre_k_verify_c(sre_scan_tables_t T, sre_scan_geom_t G, const sre_seg_summary_t *
             st.ev_sp = sp;
         }
     }
-    if (done && end < nseg && (sum[first + end].flags & SRE_SUM_ERROR)) st.error = 1;
-    status[s] = st;
+    if (done && end < nseg && (sum[end].flags & SRE_SUM_ERROR)) st.error = 1;
+    return st;
+}
+
+__global__ void
+sre_k_verify_c(sre_scan_tables_t T, sre_scan_geom_t G, const sre_seg_summary_t *__restrict__ sum,
+               VerifyAcc *__restrict__ accs, sre_stream_status_t *__restrict__ status)
+{
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= G.nstreams) return;
+    /* take this stream's accumulator and leave it reset for the next pass */
+    const VerifyAcc acc = accs[s];
+    accs[s].bad = accs[s].end = ~0ull;
+    accs[s].count = accs[s].evseg = accs[s].spseg = accs[s].unst = accs[s].unst_end = 0;
+    const uint64_t first = geom_first(G, s), nseg = geom_first(G, s + 1) - first;
+    status[s] = assemble_status(T, sum + first, nseg, acc);
+}
+
+/*
+ * The chain check of ONE stream (FIRST / Thompson) by one workgroup — phases A, B, B2 and C
+ * of the kernels above between workgroup barriers instead of kernel boundaries: a chunk of
+ * a chunked stream has a few thousand segments, and four dependent launches cost more
+ * than the scan itself there.  Every thread of the workgroup calls it; the status is in
+ * *out (shared memory) behind the last barrier, and thread 0 has stored it to *status.
+ */
+template <int NT>
+__device__ void
+verify_one_stream(const sre_scan_tables_t &T, const sre_seg_summary_t *__restrict__ sum, uint64_t nseg,
+                  sre_stream_status_t *__restrict__ status, VerifyAcc *sh_acc, sre_stream_status_t *out)
+{
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) {
+        sh_acc->bad = sh_acc->end = ~0ull;
+        sh_acc->count = sh_acc->evseg = sh_acc->spseg = sh_acc->unst = sh_acc->unst_end = 0;
+    }
+    __syncthreads();
+    /* A: first broken link, first segment that ended the search */
+    {
+        unsigned long long bad = ~0ull, end = ~0ull;
+        for (uint64_t k = tid; k < nseg; k += NT) {
+            const uint32_t s_in = sum[k].s_in;
+            if ((s_in == 0xffffffffu || (k > 0 && s_in != sum[k - 1].s_out)) && k < bad) bad = k;
+            if ((sum[k].flags & SRE_SUM_TERM) && k < end) end = k;
+        }
+        for (int d = 32; d >= 1; d >>= 1) {
+            const unsigned long long b2 = __shfl_down(bad, d, 64), e2 = __shfl_down(end, d, 64);
+            bad = b2 < bad ? b2 : bad;
+            end = e2 < end ? e2 : end;
+        }
+        if ((tid & 63u) == 0) {
+            if (bad != ~0ull) atomicMin(&sh_acc->bad, bad);
+            if (end != ~0ull) atomicMin(&sh_acc->end, end);
+        }
+    }
+    __syncthreads();
+    /* B: over the verified-and-needed prefix */
+    uint64_t limit;
+    {
+        uint64_t bad = sh_acc->bad, end = sh_acc->end;
+        if (bad > nseg) bad = nseg;
+        if (end > nseg) end = nseg;
+        limit = end < bad ? end + 1 : bad;
+        unsigned long long cnt = 0, ev = 0, sp = 0;
+        for (uint64_t k = tid; k < limit; k += NT) {
+            const sre_seg_summary_t &c = sum[k];
+            cnt += (unsigned long long) c.count;
+            if (c.flags & SRE_SUM_LASTEV) ev = k + 1;
+            if (c.cur_sp >= 0) sp = k + 1;
+        }
+        for (int d = 32; d >= 1; d >>= 1) {
+            cnt += __shfl_down(cnt, d, 64);
+            const unsigned long long e2 = __shfl_down(ev, d, 64), s2 = __shfl_down(sp, d, 64);
+            ev = e2 > ev ? e2 : ev;
+            sp = s2 > sp ? s2 : sp;
+        }
+        if ((tid & 63u) == 0) {
+            if (cnt) atomicAdd(&sh_acc->count, cnt);
+            if (ev) atomicMax(&sh_acc->evseg, ev);
+            if (sp) atomicMax(&sh_acc->spseg, sp);
+        }
+    }
+    __syncthreads();
+    /* B2: the last segments that are not stable (sre_k_verify_b2) */
+    {
+        const uint64_t     evseg = sh_acc->evseg;
+        unsigned long long mine = 0, mine_end = 0;
+        for (uint64_t k = tid; k < nseg; k += NT) {
+            if (!(sum[k].flags & SRE_SUM_STABLE)) {
+                if (evseg != 0 && k + 1 < evseg) mine = k + 1;
+                if (k + 1 < nseg) mine_end = k + 1;
+            }
+        }
+        for (int d = 32; d >= 1; d >>= 1) {
+            const unsigned long long o = __shfl_down(mine, d, 64), o2 = __shfl_down(mine_end, d, 64);
+            mine = o > mine ? o : mine;
+            mine_end = o2 > mine_end ? o2 : mine_end;
+        }
+        if ((tid & 63u) == 0) {
+            if (mine) atomicMax(&sh_acc->unst, mine);
+            if (mine_end) atomicMax(&sh_acc->unst_end, mine_end);
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        *out = assemble_status(T, sum, nseg, *sh_acc);
+        *status = *out;
+    }
+    __syncthreads();
 }
 
 /* =================================================================== captures */
@@ -1519,13 +1623,13 @@ sre_k_lineage_maps(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G
     const uint32_t s = stream_of(G, g);
     const sre_stream_status_t &st = status[s];
     if (!st.need_maps) return;
-    const uint64_t first = G.seg_first[s];
+    const uint64_t first = geom_first(G, s);
     const int64_t  k = (int64_t) (g - first);
     const int64_t  sp = st.ev_sp;
     if (k > st.ev_seg || (k + 1) * (int64_t) G.seg_bytes <= sp) return;
 
-    const uint8_t *data = G.streams[s];
-    const int64_t  n = (int64_t) G.lens[s];
+    const uint8_t *data = geom_ptr(G, s);
+    const int64_t  n = (int64_t) geom_len(G, s);
     int64_t        lo = k * (int64_t) G.seg_bytes, hi = lo + G.seg_bytes;
     uint32_t       cur = sum[g].s_in & ~SRE_STATE_SKIP;
     if (hi > n) hi = n;
@@ -1866,9 +1970,9 @@ sre_k_captures(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
 
     Tracer tr;
     tr.T = &T;
-    tr.sum = sum + G.seg_first[s];
-    tr.data = G.streams[s];
-    tr.n = (int64_t) G.lens[s];
+    tr.sum = sum + geom_first(G, s);
+    tr.data = geom_ptr(G, s);
+    tr.n = (int64_t) geom_len(G, s);
     tr.sp = st.ev_sp;
     tr.seg_bytes = G.seg_bytes;
     const uint32_t variant = st.ev_sp == 0 ? G.init_variant : restart_variant(tr.data, st.ev_sp);
@@ -1916,7 +2020,7 @@ sre_k_captures(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
         lw.ev_seg = st.ev_seg;
         lw.unst_seg = st.unst_seg;
         lw.unst_end = (int64_t) 1 << 62;        /* (the event's walk never starts behind its segment) */
-        lw.first = G.seg_first[s];
+        lw.first = geom_first(G, s);
         lw.maps = maps;
         lw.blocks = blocks;
         lw.use_maps = use_maps != 0;
@@ -1953,22 +2057,29 @@ sre_k_captures(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
  *     and the temporary match range is read off them (prepare_temp_captures,
  *     :692-735, offset quirk of :711/:721 kept).
  */
-__global__ __launch_bounds__(64) void
+#define SRE_TAIL_THREADS 256
+
+/* verify != 0: the chain check of the chunk runs here too (verify_one_stream), in front of
+ * the tail, and leaves the status word in status[0] */
+__global__ __launch_bounds__(SRE_TAIL_THREADS) void
 sre_k_stream_tail(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
-                  const sre_seg_summary_t *__restrict__ sum, const sre_stream_status_t *__restrict__ status,
+                  const sre_seg_summary_t *__restrict__ sum, sre_stream_status_t *__restrict__ status,
                   uint16_t *__restrict__ scratch, sre_stream_ctx_t *__restrict__ ctx,
-                  sre_stream_result_t *__restrict__ res, int64_t base, int eof, uint32_t ovec_slots)
+                  sre_stream_result_t *__restrict__ res, int64_t base, int eof, uint32_t ovec_slots, int verify)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     __shared__ sre_scan_tables_t Ts;
+    __shared__ VerifyAcc sh_acc;
+    __shared__ sre_stream_status_t sh_st;
     stage_walk_tables(tabp, lds, &Ts);
+    const uint64_t             nseg = geom_first(G, 1) - geom_first(G, 0);
+    if (verify) verify_one_stream<SRE_TAIL_THREADS>(Ts, sum, nseg, status, &sh_acc, &sh_st);
     if (threadIdx.x != 0) return;
     const sre_scan_tables_t   &T = Ts;
-    const sre_stream_status_t  st = status[0];
+    const sre_stream_status_t  st = verify ? sh_st : status[0];
     const uint32_t             nsym = T.ncls + 1;
     const bool                 continues = (G.flags & SRE_GEOM_CONTINUES) != 0;
-    const int64_t              n = (int64_t) G.lens[0];
-    const uint64_t             nseg = G.seg_first[1] - G.seg_first[0];
+    const int64_t              n = (int64_t) geom_len(G, 0);
 
     res->rc = RC_ERROR;
     res->has_pending = 0;
@@ -2000,7 +2111,7 @@ sre_k_stream_tail(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
     Tracer tr;
     tr.T = &T;
     tr.sum = sum;
-    tr.data = G.streams[0];
+    tr.data = geom_ptr(G, 0);
     tr.n = n;
     tr.sp = 0;
     tr.seg_bytes = G.seg_bytes;
@@ -2163,15 +2274,13 @@ sre_scan_lds_bytes(const sre_scan_tables_t *h_tab)
      * 16-bit scaled indices, plus the pad */
     const size_t half = (size_t) SRE_SCAN_ROUND * h_tab->class_bits / 8 * (h_tab->wide ? 2 : 1);
     /* [fast rows][class map][transitions][state flags][tile] */
+    /* (COUNT runs at the three workgroups per CU its registers allow: an earlier "two are
+     * faster" was an artefact of segment sizes that left a second, mostly empty round of
+     * workgroups — profiles/r02_experiments.txt) */
     static const char *pad_env = getenv("SRE_HIP_LDS_PAD");      /* experiment knob: fewer workgroups per CU */
     const size_t pad = pad_env ? (size_t) atoi(pad_env) : 0;
     size_t       need = pad + (size_t) h_tab->fast_rows * SRE_FAST_ROW_BYTES + 256 + tr + ((h_tab->nstates + 15u) & ~15u)
                         + 16 + (size_t) SRE_SCAN_BLOCK * (2 * half + 16);
-    /* COUNT: two workgroups per CU, not the three its registers allow — measured on one
-     * box, configs[2] stream: 3 per CU 1.65 ms, 2 per CU 1.37 ms, 1 per CU 2.46 ms
-     * (profiles/r02_experiments.txt).  The request is padded past a third of the CU's
-     * 160 KiB (the kernel has at least 4.7 KiB of static LDS on top). */
-    if (h_tab->mode == SRE_HIP_PIKE_COUNT && pad_env == NULL && need < 50 * 1024) need = 50 * 1024;
     return need + (size_t) SRE_SCAN_BLOCK * 16;      /* row descriptors */
 }
 
@@ -2347,9 +2456,9 @@ sre_launch_exact_entries(const sre_scan_tables_t *d_tab, sre_scan_tables_t h_tab
 
 extern "C" hipError_t
 sre_launch_stream_tail(const sre_scan_tables_t *d_tab, sre_scan_tables_t h_tab, sre_scan_geom_t geom,
-                       const sre_seg_summary_t *d_sum, const sre_stream_status_t *d_status,
+                       const sre_seg_summary_t *d_sum, sre_stream_status_t *d_status,
                        uint16_t *d_scratch, sre_stream_ctx_t *d_ctx, sre_stream_result_t *result, int64_t base,
-                       int eof, uint32_t ovec_slots, hipStream_t stream)
+                       int eof, uint32_t ovec_slots, int verify, hipStream_t stream)
 {
     const size_t shmem = (size_t) h_tab.fast_bytes + 256
                          + ((size_t) h_tab.nstates * (h_tab.ncls + 1) + 3) * sizeof(sre_dev_trans_t)
@@ -2363,7 +2472,7 @@ sre_launch_stream_tail(const sre_scan_tables_t *d_tab, sre_scan_tables_t h_tab, 
             raised = true;
         }
     }
-    hipLaunchKernelGGL(sre_k_stream_tail, dim3(1), dim3(64), shmem, stream, d_tab, geom, d_sum, d_status,
-                       d_scratch, d_ctx, result, base, eof, ovec_slots);
+    hipLaunchKernelGGL(sre_k_stream_tail, dim3(1), dim3(SRE_TAIL_THREADS), shmem, stream, d_tab, geom, d_sum, d_status,
+                       d_scratch, d_ctx, result, base, eof, ovec_slots, verify);
     return hipGetLastError();
 }

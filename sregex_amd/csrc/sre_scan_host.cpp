@@ -196,10 +196,12 @@ sre_scan_tables_build(const sre_program_t *prog, const sre_dfa_t *d, int mode, c
     h.fast_rows = d->nstates + 1 + h.nshadow;       /* rows of the scan kernel's LDS copy */
     h.wide = bits <= 2;
     if (mode == SRE_HIP_PIKE_COUNT && bits == 4) {
-        /* one op less per lookup (-2.6 % on configs[2]) — if the larger tile still lets two
-         * workgroups share a CU, which is what this mode runs at (sre_scan_lds_bytes) */
+        /* one op less per lookup (-2.6 % on configs[2]) — if the larger tile still lets three
+         * workgroups share a CU, which is what this mode's registers allow and what pays more
+         * (configs[2]: 1.31 ms at two per CU either way, 1.08 ms narrow at three) */
         h.wide = 1;
-        if (sre_scan_lds_bytes(&h) + 9 * 1024 > 80 * 1024) h.wide = 0;
+        if (sre_scan_lds_bytes(&h) + 2 * 1024 > 160 * 1024 / 3) h.wide = 0;
+        if (getenv("SRE_HIP_NO_WIDE4")) h.wide = 0;     /* experiment knob */
     }
 
     std::vector<sre_dev_trans_t> trans(d->trans.size());

@@ -14,9 +14,12 @@ d=json.loads(sys.stdin.read()); r=d['roofline']
 print('step_ms %.4f kernel_ms %.4f frac %.4f kfrac %.4f seg %s' % (r['step_ms'], r['kernel_ms'], r['frac'], r['kernel_frac'], d['config']['segment_bytes']))")
   echo "$CFG $EXTRA | $name | $out"
 }
-for CFG in cfg3 nfa cfg4 cfg2 cfg1; do
+C4=$PWD/sregex_amd/lib_c4/libsregex.so
+for CFG in cfg3 dense; do
 EXTRA=
-one "cap 40960 (default)" A=1; one "cap 16384 (old)" SRE_HIP_SEG_CAP=16384
+one "wide, 2 per CU (default)" A=1
+one "narrow, 3 per CU" SRE_HIP_NO_WIDE4=1 SRE_HIP_LDS_PAD=0
+one "narrow, 2 per CU" SRE_HIP_NO_WIDE4=1
+one "narrow, 4 per CU (66 spills)" SRE_HIP_NO_WIDE4=1 SRE_HIP_LDS_PAD=0 SREGEX_AMD_LIB=$C4
+one "wide, 2 per CU again" A=1
 done
-CFG=cfg2 EXTRA=--many-streams
-one "cap 40960 (default)" A=1; one "cap 16384 (old)" SRE_HIP_SEG_CAP=16384
