@@ -19,6 +19,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
+#include <chrono>
 #include <vector>
 
 /* speculative fix-up rounds before a FIRST / Thompson scan computes exact entry states */
@@ -570,10 +572,14 @@ sre_hip_scan_enqueue(sre_hip_scanner_t *sc, const void *const *d_streams, const 
         SRE_HIP_TRY(sre_launch_scan(sc->tab->d_tab, sc->tab->h, sc->geom, sc->d_sum, NULL, NULL, stream));
         SRE_HIP_TRY(hipEventRecord(sc->ev1, stream));
         sc->ev_valid = 1;
-        SRE_HIP_TRY(sre_launch_verify(sc->tab->h, sc->geom, sc->d_sum, sc->d_acc, sc->d_status, stream));
-        SRE_HIP_TRY(sre_launch_captures(sc->tab->d_tab, sc->tab->h, sc->geom, sc->d_sum, sc->d_status,
-                                        sc->d_scratch, sc->d_records, sc->ovec_slots,
-                                        NULL, NULL, 0, stream));
+        {
+            /* one small buffer: chain check and captures in one workgroup */
+            const int fused = sc->geom_one && sc->geom.nsegs <= SRE_VERIFY_ONE_SEGS && sc->mode != SRE_HIP_PIKE_COUNT;
+            if (!fused) SRE_HIP_TRY(sre_launch_verify(sc->tab->h, sc->geom, sc->d_sum, sc->d_acc, sc->d_status, stream));
+            SRE_HIP_TRY(sre_launch_captures(sc->tab->d_tab, sc->tab->h, sc->geom, sc->d_sum, sc->d_status,
+                                            sc->d_scratch, sc->d_records, sc->ovec_slots,
+                                            NULL, NULL, 0, fused, stream));
+        }
     }
     /* records (and the scanner's status words behind them) in one copy */
     SRE_HIP_TRY(hipMemcpyAsync(sc->h_out, sc->d_out,
@@ -639,7 +645,7 @@ scan_settle(sre_hip_scanner_t *sc, size_t n, hipStream_t stream, bool with_captu
             if (with_captures) {
                 SRE_HIP_TRY(sre_launch_captures(sc->tab->d_tab, sc->tab->h, sc->geom, sc->d_sum,
                                                 sc->d_status, sc->d_scratch, sc->d_records,
-                                                sc->ovec_slots, NULL, NULL, 0, stream));
+                                                sc->ovec_slots, NULL, NULL, 0, 0, stream));
             }
         }
         SRE_HIP_TRY(hipMemcpyAsync(sc->h_status, sc->d_status, n * sizeof(sre_stream_status_t),
@@ -723,7 +729,7 @@ sre_hip_scan_results(sre_hip_scanner_t *sc, sre_int_t *results)
                 SRE_HIP_TRY(sre_launch_captures(sc->tab->d_tab, sc->tab->h, sc->geom, sc->d_sum,
                                                 sc->d_status, sc->d_scratch, sc->d_records,
                                                 sc->ovec_slots, sc->d_maps, sc->d_blocks,
-                                                1, stream));
+                                                1, 0, stream));
             }
         }
     }
@@ -822,9 +828,28 @@ sre_hip_scan_stream_chunk(sre_hip_scanner_t *sc, const void *d_buf, size_t len, 
      * the speculative entry states of the chunk's lanes have been wrong (rare), the tail
      * says so and the rounds are run first */
     SRE_HIP_TRY(sre_launch_scan(sc->tab->d_tab, sc->tab->h, sc->geom, sc->d_sum, NULL, NULL, stream));
-    SRE_HIP_TRY(sre_launch_stream_tail(sc->tab->d_tab, sc->tab->h, sc->geom, sc->d_sum, sc->d_status,
-                                       sc->d_scratch, d_ctx, d_res, base, eof, ovec_slots, 1, stream));
-    SRE_HIP_TRY(hipStreamSynchronize(stream));
+    {
+        /* (a large chunk has too many segments for one workgroup: the chain check's own kernels) */
+        const int fused = sc->geom.nsegs <= SRE_VERIFY_ONE_SEGS;
+        if (!fused) SRE_HIP_TRY(sre_launch_verify(sc->tab->h, sc->geom, sc->d_sum, sc->d_acc, sc->d_status, stream));
+        SRE_HIP_TRY(sre_launch_stream_tail(sc->tab->d_tab, sc->tab->h, sc->geom, sc->d_sum, sc->d_status,
+                                           sc->d_scratch, d_ctx, d_res, base, eof, ovec_slots, fused, stream));
+    }
+    /* the result lands in host-visible memory, rc last: watching that word costs less than
+     * the runtime's wait (an interrupt and a wake-up) — for as long as a chunk of this size
+     * can reasonably take, then the ordinary wait */
+    {
+        const volatile int64_t *prc = &h_res->rc;
+        const auto              t0 = std::chrono::steady_clock::now();
+        const auto              limit = std::chrono::microseconds(200 + (int64_t) (len >> 12));
+        while (*prc == SRE_STREAM_PENDING) {
+            if (std::chrono::steady_clock::now() - t0 > limit) {
+                SRE_HIP_TRY(hipStreamSynchronize(stream));
+                break;
+            }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+    }
     if (h_res->rc == SRE_STREAM_UNSETTLED) {
         SRE_HIP_TRY(hipMemcpyAsync(sc->h_status, sc->d_status, sizeof(sre_stream_status_t),
                                    hipMemcpyDeviceToHost, stream));

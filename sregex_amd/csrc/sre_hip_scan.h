@@ -179,7 +179,10 @@ typedef struct {
 } sre_stream_ctx_t;
 
 /* sre_stream_result_t.rc: the chunk's lanes were not all verified; run the fix-up rounds */
+#define SRE_VERIFY_ONE_SEGS 8192u    /* most segments the tail / capture kernels check themselves (verify != 0) */
 #define SRE_STREAM_UNSETTLED (-100)
+/* ... set by the host before the launch: the tail kernel has not published its result yet */
+#define SRE_STREAM_PENDING   (-101)
 
 /* result of one streaming exec, written to host-visible memory */
 typedef struct {
@@ -294,12 +297,13 @@ hipError_t sre_launch_verify(sre_scan_tables_t h_tab, sre_scan_geom_t geom,
 /* captures of each stream's final match -> records [rc, count, ovector].
  * status[s].need_maps is set to 1 when the lineage is too long for the plain walk and the
  * per-segment maps are required (then call sre_launch_lineage and this again
- * with use_maps = 1). */
+ * with use_maps = 1).  verify != 0 (one stream of at most SRE_VERIFY_ONE_SEGS segments, not
+ * COUNT): the chain check runs inside, no sre_launch_verify in front. */
 hipError_t sre_launch_captures(const sre_scan_tables_t *d_tab, sre_scan_tables_t h_tab,
     sre_scan_geom_t geom, const sre_seg_summary_t *d_sum, sre_stream_status_t *d_status,
     uint16_t *d_scratch, int64_t *d_records, uint32_t ovec_slots,
     const sre_seg_lineage_t *d_maps, const sre_seg_lineage_t *d_blocks, int use_maps,
-    hipStream_t stream);
+    int verify, hipStream_t stream);
 /* ancestor maps of every segment in front of a flagged stream's match, and
  * their 256-segment compositions */
 hipError_t sre_launch_lineage(const sre_scan_tables_t *d_tab, sre_scan_tables_t h_tab,

@@ -1315,24 +1315,46 @@ sre_k_verify_c(sre_scan_tables_t T, sre_scan_geom_t G, const sre_seg_summary_t *
  * than the scan itself there.  Every thread of the workgroup calls it; the status is in
  * *out (shared memory) behind the last barrier, and thread 0 has stored it to *status.
  */
+#define SRE_VERIFY_ONE_MAX SRE_VERIFY_ONE_SEGS     /* segments one workgroup checks (8 per thread) */
+
 template <int NT>
 __device__ void
 verify_one_stream(const sre_scan_tables_t &T, const sre_seg_summary_t *__restrict__ sum, uint64_t nseg,
                   sre_stream_status_t *__restrict__ status, VerifyAcc *sh_acc, sre_stream_status_t *out)
 {
+    constexpr int  PER = SRE_VERIFY_ONE_MAX / NT;
     const uint32_t tid = threadIdx.x;
     if (tid == 0) {
         sh_acc->bad = sh_acc->end = ~0ull;
         sh_acc->count = sh_acc->evseg = sh_acc->spseg = sh_acc->unst = sh_acc->unst_end = 0;
     }
+    /* every summary is read ONCE, all of a thread's loads in flight together; the phases
+     * below work on what it kept: [0] link broken [1] TERM [2] LASTEV [3] search start known
+     * [4] not stable, and the segment's match count */
+    uint32_t bits[PER], cnt[PER];
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+        const uint64_t k = (uint64_t) i * NT + tid;
+        bits[i] = 0;
+        cnt[i] = 0;
+        if (k < nseg) {
+            const sre_seg_summary_t &c = sum[k];
+            const uint32_t s_in = c.s_in, fl = c.flags;
+            const uint32_t prev_out = k > 0 ? sum[k - 1].s_out : s_in;
+            bits[i] = ((s_in == 0xffffffffu || s_in != prev_out) ? 1u : 0u) | ((fl & SRE_SUM_TERM) ? 2u : 0u)
+                      | ((fl & SRE_SUM_LASTEV) ? 4u : 0u) | (c.cur_sp >= 0 ? 8u : 0u) | ((fl & SRE_SUM_STABLE) ? 0u : 16u);
+            cnt[i] = (uint32_t) c.count;
+        }
+    }
     __syncthreads();
     /* A: first broken link, first segment that ended the search */
     {
         unsigned long long bad = ~0ull, end = ~0ull;
-        for (uint64_t k = tid; k < nseg; k += NT) {
-            const uint32_t s_in = sum[k].s_in;
-            if ((s_in == 0xffffffffu || (k > 0 && s_in != sum[k - 1].s_out)) && k < bad) bad = k;
-            if ((sum[k].flags & SRE_SUM_TERM) && k < end) end = k;
+#pragma unroll
+        for (int i = PER - 1; i >= 0; i--) {
+            const uint64_t k = (uint64_t) i * NT + tid;
+            if (bits[i] & 1u) bad = k;
+            if (bits[i] & 2u) end = k;
         }
         for (int d = 32; d >= 1; d >>= 1) {
             const unsigned long long b2 = __shfl_down(bad, d, 64), e2 = __shfl_down(end, d, 64);
@@ -1346,27 +1368,29 @@ verify_one_stream(const sre_scan_tables_t &T, const sre_seg_summary_t *__restric
     }
     __syncthreads();
     /* B: over the verified-and-needed prefix */
-    uint64_t limit;
     {
         uint64_t bad = sh_acc->bad, end = sh_acc->end;
         if (bad > nseg) bad = nseg;
         if (end > nseg) end = nseg;
-        limit = end < bad ? end + 1 : bad;
-        unsigned long long cnt = 0, ev = 0, sp = 0;
-        for (uint64_t k = tid; k < limit; k += NT) {
-            const sre_seg_summary_t &c = sum[k];
-            cnt += (unsigned long long) c.count;
-            if (c.flags & SRE_SUM_LASTEV) ev = k + 1;
-            if (c.cur_sp >= 0) sp = k + 1;
+        const uint64_t     limit = end < bad ? end + 1 : bad;
+        unsigned long long c = 0, ev = 0, sp = 0;
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            const uint64_t k = (uint64_t) i * NT + tid;
+            if (k < limit) {
+                c += cnt[i];
+                if (bits[i] & 4u) ev = k + 1;
+                if (bits[i] & 8u) sp = k + 1;
+            }
         }
         for (int d = 32; d >= 1; d >>= 1) {
-            cnt += __shfl_down(cnt, d, 64);
+            c += __shfl_down(c, d, 64);
             const unsigned long long e2 = __shfl_down(ev, d, 64), s2 = __shfl_down(sp, d, 64);
             ev = e2 > ev ? e2 : ev;
             sp = s2 > sp ? s2 : sp;
         }
         if ((tid & 63u) == 0) {
-            if (cnt) atomicAdd(&sh_acc->count, cnt);
+            if (c) atomicAdd(&sh_acc->count, c);
             if (ev) atomicMax(&sh_acc->evseg, ev);
             if (sp) atomicMax(&sh_acc->spseg, sp);
         }
@@ -1376,8 +1400,10 @@ verify_one_stream(const sre_scan_tables_t &T, const sre_seg_summary_t *__restric
     {
         const uint64_t     evseg = sh_acc->evseg;
         unsigned long long mine = 0, mine_end = 0;
-        for (uint64_t k = tid; k < nseg; k += NT) {
-            if (!(sum[k].flags & SRE_SUM_STABLE)) {
+#pragma unroll
+        for (int i = 0; i < PER; i++) {
+            const uint64_t k = (uint64_t) i * NT + tid;
+            if (k < nseg && (bits[i] & 16u)) {
                 if (evseg != 0 && k + 1 < evseg) mine = k + 1;
                 if (k + 1 < nseg) mine_end = k + 1;
             }
@@ -1934,7 +1960,11 @@ stage_walk_tables(const sre_scan_tables_t *__restrict__ tabp, uint8_t *lds, sre_
     }
 }
 
-__global__ __launch_bounds__(64) void
+/* NT == 64: one lane per stream behind sre_launch_verify.  NT == 1024: ONE stream of at most
+ * SRE_VERIFY_ONE_SEGS segments, FIRST / Thompson — the workgroup runs the chain check itself
+ * (verify_one_stream), then lane 0 walks: a small buffer costs two launches, not six. */
+template <int NT>
+__global__ __launch_bounds__(NT) void
 sre_k_captures(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
                const sre_seg_summary_t *__restrict__ sum,
                sre_stream_status_t *__restrict__ status, uint16_t *__restrict__ scratch,
@@ -1945,6 +1975,11 @@ sre_k_captures(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     __shared__ sre_scan_tables_t Ts;
     stage_walk_tables(tabp, lds, &Ts);
+    if (NT != 64) {
+        __shared__ VerifyAcc sh_acc;
+        __shared__ sre_stream_status_t sh_st;
+        verify_one_stream<NT>(Ts, sum, geom_first(G, 1), status, &sh_acc, &sh_st);
+    }
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= G.nstreams) return;
     if (use_maps && !status[s].need_maps) return;   /* second pass: flagged streams only */
@@ -2057,7 +2092,7 @@ sre_k_captures(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
  *     and the temporary match range is read off them (prepare_temp_captures,
  *     :692-735, offset quirk of :711/:721 kept).
  */
-#define SRE_TAIL_THREADS 256
+#define SRE_TAIL_THREADS 1024
 
 /* verify != 0: the chain check of the chunk runs here too (verify_one_stream), in front of
  * the tail, and leaves the status word in status[0] */
@@ -2075,35 +2110,38 @@ sre_k_stream_tail(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
     const uint64_t             nseg = geom_first(G, 1) - geom_first(G, 0);
     if (verify) verify_one_stream<SRE_TAIL_THREADS>(Ts, sum, nseg, status, &sh_acc, &sh_st);
     if (threadIdx.x != 0) return;
+    /* the host may be spinning on res->rc (host-visible memory): it is written last, behind
+     * a system-scope fence, once everything else of the result is in place */
+    int64_t rc_out = RC_ERROR;
+    auto body = [&]() {
     const sre_scan_tables_t   &T = Ts;
     const sre_stream_status_t  st = verify ? sh_st : status[0];
     const uint32_t             nsym = T.ncls + 1;
     const bool                 continues = (G.flags & SRE_GEOM_CONTINUES) != 0;
     const int64_t              n = (int64_t) geom_len(G, 0);
 
-    res->rc = RC_ERROR;
     res->has_pending = 0;
     res->ev_in_chunk = 0;
     res->poisoned = 0;
     res->next_state = 0;
     if (!st.done) {
-        res->rc = SRE_STREAM_UNSETTLED;
+        rc_out = SRE_STREAM_UNSETTLED;
         return;
     }
     if (T.mode == 0) {
         /* Thompson (sre_vm_thompson.c:63-270): SRE_OK at the first MATCH thread met, else
          * SRE_DECLINED at eof / SRE_AGAIN with the list (= the state) carried on */
         if (st.ev_pos >= 0) {
-            res->rc = 0;
+            rc_out = 0;
             ctx->state = 0;
         } else if (eof) {
-            res->rc = RC_DECLINED;
+            rc_out = RC_DECLINED;
             ctx->state = 0;
         } else {
             const uint32_t sF = sum[nseg - 1].s_out & ~SRE_STATE_SKIP;
             ctx->state = tabp->unskip[sF];
             res->next_state = ctx->state;
-            res->rc = -2;                   /* SRE_AGAIN */
+            rc_out = -2;                   /* SRE_AGAIN */
         }
         return;
     }
@@ -2186,10 +2224,10 @@ sre_k_stream_tail(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
             for (uint64_t q = 0; q < ovec_slots && q < SRE_STREAM_MAX_SLOTS; q++) {
                 res->ov[q] = q < ncopy ? ctx->pending_vec[ofs + q] : -1;
             }
-            res->rc = id;
+            rc_out = id;
             res->poisoned = st.error ? 1 : 0;
         } else {
-            res->rc = RC_DECLINED;
+            rc_out = RC_DECLINED;
         }
         ctx->state = 0;
         ctx->has_pending = 0;
@@ -2228,7 +2266,7 @@ sre_k_stream_tail(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
     res->next_state = sNext;
     res->ov[0] = a0;
     res->ov[1] = a1;
-    res->rc = -2;                       /* SRE_AGAIN */
+    rc_out = -2;                       /* SRE_AGAIN */
     if (ctx->has_pending) {
         const int64_t id = ctx->pending_regex;
         uint64_t      ofs = 0;
@@ -2238,6 +2276,10 @@ sre_k_stream_tail(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
         res->pending[0] = ctx->pending_vec[ofs];
         res->pending[1] = ctx->pending_vec[ofs + 1];
     }
+    };
+    body();
+    __threadfence_system();
+    *reinterpret_cast<volatile int64_t *>(&res->rc) = rc_out;
 }
 
 }  // namespace
@@ -2367,26 +2409,35 @@ sre_launch_captures(const sre_scan_tables_t *d_tab, sre_scan_tables_t h_tab, sre
                     const sre_seg_summary_t *d_sum, sre_stream_status_t *d_status,
                     uint16_t *d_scratch, int64_t *d_records, uint32_t ovec_slots,
                     const sre_seg_lineage_t *d_maps, const sre_seg_lineage_t *d_blocks,
-                    int use_maps, hipStream_t stream)
+                    int use_maps, int verify, hipStream_t stream)
 {
     if (geom.nstreams == 0) return hipSuccess;
-    const uint32_t block = 64, grid = (geom.nstreams + block - 1) / block;
+    if (verify && (geom.nstreams != 1 || geom.nsegs > SRE_VERIFY_ONE_SEGS || h_tab.mode == SRE_HIP_PIKE_COUNT || use_maps)) {
+        return hipErrorInvalidValue;
+    }
+    const uint32_t block = verify ? 1024 : 64, grid = (geom.nstreams + block - 1) / block;
     const size_t   shmem = (size_t) h_tab.fast_bytes + 256
                          + ((size_t) h_tab.nstates * (h_tab.ncls + 1) + 3) * sizeof(sre_dev_trans_t)
                          + (size_t) h_tab.lin_total * 9 + ((size_t) h_tab.nstates + 1 + h_tab.list_total) * 4 + 16;
     if (shmem > 48 * 1024) {
         /* a big automaton (many byte classes x states): one lane per stream, so the
          * workgroup may as well own most of the CU's LDS */
-        static bool raised = false;
-        if (!raised) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sre_k_captures),
+        static bool raised[2];
+        if (!raised[verify != 0]) {
+            hipError_t e = hipFuncSetAttribute(verify ? reinterpret_cast<const void *>(sre_k_captures<1024>)
+                                                      : reinterpret_cast<const void *>(sre_k_captures<64>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, SRE_CAPTURE_LDS_LIMIT);
             if (e != hipSuccess) return e;
-            raised = true;
+            raised[verify != 0] = true;
         }
     }
-    hipLaunchKernelGGL(sre_k_captures, dim3(grid), dim3(block), shmem, stream, d_tab, geom, d_sum,
-                       d_status, d_scratch, d_records, ovec_slots, d_maps, d_blocks, use_maps);
+    if (verify) {
+        hipLaunchKernelGGL(sre_k_captures<1024>, dim3(1), dim3(1024), shmem, stream, d_tab, geom, d_sum,
+                           d_status, d_scratch, d_records, ovec_slots, d_maps, d_blocks, use_maps);
+    } else {
+        hipLaunchKernelGGL(sre_k_captures<64>, dim3(grid), dim3(block), shmem, stream, d_tab, geom, d_sum,
+                           d_status, d_scratch, d_records, ovec_slots, d_maps, d_blocks, use_maps);
+    }
     return hipGetLastError();
 }
 

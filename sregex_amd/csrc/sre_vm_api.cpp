@@ -70,6 +70,7 @@ struct DeviceStream {
     sre_stream_result_t *h_sres, *d_sres;
     /* pinned double buffer of stage_input */
     uint8_t            *h_stage[2];
+    uint8_t            *d_stage;            /* device view of h_stage[0] */
     hipEvent_t          ev_stage[2];
     int                 stage_busy[2];
 };
@@ -236,12 +237,26 @@ struct sre_vm_pike_ctx_s {
 };
 
 /*
- * Host -> device staging of a chunk.  The caller's buffer is pageable memory, and a
- * plain hipMemcpyAsync from it crawls (~1 GB/s measured here: the runtime stages it
- * through small internal buffers, synchronously).  Large chunks therefore go through
- * TWO pinned buffers owned by the device stream: the CPU copies piece k + 1 into one
- * while the DMA engine moves piece k out of the other.
+ * Host -> device copy of a chunk from the caller's (pageable) buffer, by size — measured
+ * with tools/h2d_sizes.py (profiles/r02_h2d_sizes.txt), microseconds per copy incl. the wait:
+ *            hipMemcpyAsync from pageable    memcpy to pinned + DMA    DMA from pinned alone
+ *   64 KiB              13                          13                        12
+ *    1 MiB              66                          62                        29
+ *    4 MiB              94                         219                        85
+ *   16 MiB             307  (55 GB/s)              823  (20 GB/s)            303
+ * From 2 MiB on the runtime's own path (it pins the caller's pages for the transfer) runs at
+ * DMA speed and the CPU copy into a staging buffer (30 GB/s) is the slower way; below, the
+ * two are equal and the pinned buffer saves the runtime's bookkeeping.  (The pinned buffer
+ * must be hipHostMallocNonCoherent: DMA out of the default coherent kind runs at 1.5 GB/s.)
  */
+/* copy of a pinned host buffer (mapped into the device's address space) to device memory;
+ * 16 bytes per lane and access, whole buffer rounded up to 16 (both are allocated larger) */
+__global__ __launch_bounds__(256) void
+sre_k_pull(const uint4 *__restrict__ src, uint4 *__restrict__ dst, uint32_t n16)
+{
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n16; i += gridDim.x * 256u) dst[i] = src[i];
+}
+
 #define SRE_STAGE_PIECE   (2u << 20)
 #define SRE_STAGE_MIN     (64u << 10)
 
@@ -256,35 +271,33 @@ stage_input(DeviceStream *ds, const sre_char *input, size_t len)
         ds->in_cap = len + (len >> 2) + 4096;
     }
     if (len == 0) return 0;
-    if (len < SRE_STAGE_MIN) {
+    if (len < SRE_STAGE_MIN || len > SRE_STAGE_PIECE) {
         return hipMemcpyAsync(ds->d_in, input, len, hipMemcpyHostToDevice, ds->stream) == hipSuccess ? 0 : -1;
     }
+    /* one pinned buffer: exec() is synchronous, the copy out of it has finished (its
+     * consumer has) before the next call writes into it */
+    static const bool pull = getenv("SRE_HIP_NO_PULL") == NULL;
     if (ds->h_stage[0] == NULL) {
-        for (int b = 0; b < 2; b++) {
-            if (hipHostMalloc(reinterpret_cast<void **>(&ds->h_stage[b]), SRE_STAGE_PIECE, hipHostMallocNonCoherent) != hipSuccess
-                || hipEventCreateWithFlags(&ds->ev_stage[b], hipEventDisableTiming) != hipSuccess)
-            {
-                return -1;
-            }
-        }
-    }
-    size_t off = 0;
-    for (int b = 0; off < len; b ^= 1) {
-        const size_t n = len - off < SRE_STAGE_PIECE ? len - off : SRE_STAGE_PIECE;
-        if (ds->stage_busy[b]) {
-            if (hipEventSynchronize(ds->ev_stage[b]) != hipSuccess) return -1;     /* its last DMA is done */
-        }
-        memcpy(ds->h_stage[b], input + off, n);
-        if (hipMemcpyAsync(static_cast<uint8_t *>(ds->d_in) + off, ds->h_stage[b], n, hipMemcpyHostToDevice,
-                           ds->stream) != hipSuccess
-            || hipEventRecord(ds->ev_stage[b], ds->stream) != hipSuccess)
+        /* read by a kernel: the coherent (fine-grained) kind, which the GPU never caches — the
+         * buffer is rewritten by the CPU between kernels; read by the DMA engine: the
+         * non-coherent kind (out of the coherent one it runs at 1.5 GB/s) */
+        if (hipHostMalloc(reinterpret_cast<void **>(&ds->h_stage[0]), SRE_STAGE_PIECE,
+                          pull ? hipHostMallocMapped : hipHostMallocNonCoherent | hipHostMallocMapped) != hipSuccess
+            || hipHostGetDevicePointer(reinterpret_cast<void **>(&ds->d_stage), ds->h_stage[0], 0) != hipSuccess)
         {
             return -1;
         }
-        ds->stage_busy[b] = 1;
-        off += n;
     }
-    return 0;
+    memcpy(ds->h_stage[0], input, len);
+    if (pull) {
+        /* the GPU fetches the buffer itself: a kernel in front of the scan on the same queue
+         * instead of a DMA-engine copy the scan has to be synchronised with */
+        const uint32_t n16 = (uint32_t) ((len + 15) / 16);
+        hipLaunchKernelGGL(sre_k_pull, dim3((n16 + 1023) / 1024 < 256 ? (n16 + 1023) / 1024 : 256), dim3(256), 0,
+                           ds->stream, reinterpret_cast<const uint4 *>(ds->d_stage), static_cast<uint4 *>(ds->d_in), n16);
+        return hipGetLastError() == hipSuccess ? 0 : -1;
+    }
+    return hipMemcpyAsync(ds->d_in, ds->h_stage[0], len, hipMemcpyHostToDevice, ds->stream) == hipSuccess ? 0 : -1;
 }
 
 /* The throughput scanner of a program for the compat path: built once per program
@@ -447,7 +460,7 @@ pike_stream_route(sre_vm_pike_ctx_t *ctx, sre_char *input, size_t len, unsigned 
         return 0;
     }
     if (stage_input(ds, input, len) != 0) return 0;
-    ds->h_sres->rc = SRE_ERROR;
+    ds->h_sres->rc = SRE_STREAM_PENDING;
     if (sre_hip_scan_stream_chunk(ctx->scanner, static_cast<const uint8_t *>(ds->d_in) + skip, len - skip, variant,
                                   ctx->stream_mode, ctx->stream_state, eof ? 1 : 0,
                                   (int64_t) ctx->processed_bytes + (int64_t) skip, ds->d_sctx, ds->d_sres, ds->h_sres,
@@ -628,7 +641,7 @@ thompson_stream_route(sre_vm_thompson_ctx_t *ctx, sre_char *input, size_t len, u
         }
     }
     if (stage_input(ds, input, len) != 0) return 0;
-    ds->h_sres->rc = SRE_ERROR;
+    ds->h_sres->rc = SRE_STREAM_PENDING;
     if (sre_hip_scan_stream_chunk(ctx->scanner, ds->d_in, len, 0, ctx->stream_mode, ctx->stream_state, eof ? 1 : 0, 0,
                                   ds->d_sctx, ds->d_sres, ds->h_sres, 0, ds->stream) != 0)
     {
