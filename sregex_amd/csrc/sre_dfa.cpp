@@ -44,6 +44,12 @@ struct Builder {
     std::vector<std::vector<uint32_t>> lists;          /* per state */
     std::vector<uint8_t>               sss, variant;   /* per state */
     std::vector<uint8_t>               prevk;          /* per state: PREV_* of the byte in front */
+    std::vector<std::vector<uint8_t>>  fresh;          /* per state, per thread: a look-ahead assertion (or MATCH)
+                                                          thread whose own closure path saved a group-0 start,
+                                                          i.e. a match it completes at this position is empty */
+    uint64_t                           slot0_mask = 0; /* the group-0 start slots of all regexes */
+    unsigned                           prev_mask = PREV_WORD | PREV_NL | PREV_START;   /* kinds of the byte in front
+                                                          that some assertion of the program can tell apart */
     std::vector<std::vector<uint32_t>> visited;        /* per state: instructions tagged by the generation
                                                           that built the list (kept if it holds a look-ahead) */
     bool                 visited_start = false;        /* pc 0 reached by the last closure(s) */
@@ -151,9 +157,13 @@ struct Builder {
     /* seen_start: 0 clear, 1 set (consumed by the next check), 2 set by a skip
      * re-seed that is still travelling to its target byte (see step) */
     uint32_t intern(const std::vector<uint32_t> &pcs, bool matched, int seen_start, int var,
-                    unsigned prev)
+                    unsigned prev, const std::vector<uint64_t> &saves)
     {
         if (pcs.empty()) return SRE_DFA_DEAD;
+        std::vector<uint8_t> fr(pcs.size(), 0);
+        for (size_t i = 0; i < pcs.size(); i++) {
+            if ((is_lookahead(pcs[i]) || prog->insns[pcs[i]].opcode == SRE_OP_MATCH) && (saves[i] & slot0_mask)) fr[i] = 1;
+        }
         if (prog->nleading == 0) {       /* the skip does not exist: flags are inert */
             seen_start = 0;
             var = 0;
@@ -170,8 +180,13 @@ struct Builder {
             for (uint32_t pc = 0; pc < prog->len; pc++) {
                 if (tags[pc] == gen) vis.push_back(pc);
             }
+            prev &= prev_mask;
             key.push_back(0x80000000u | prev);
             key.insert(key.end(), vis.begin(), vis.end());
+            key.push_back(0xc0000000u);
+            for (size_t i = 0; i < fr.size(); i++) {
+                if (fr[i]) key.push_back((uint32_t) i);
+            }
         } else {
             prev = 0;
         }
@@ -185,6 +200,7 @@ struct Builder {
         variant.push_back((uint8_t) var);
         prevk.push_back((uint8_t) prev);
         visited.push_back(vis);
+        fresh.push_back(fr);
         return id;
     }
 
@@ -239,6 +255,7 @@ sre_dfa_build(const sre_program_t *prog, uint32_t max_states, const char **why)
             if (in.ch & SRE_ASSERT_DOLLAR) has_dollar = true;
             if (in.ch & (SRE_ASSERT_SMALL_B | SRE_ASSERT_BIG_B)) has_b = true;
         }
+        if (!has_b) b.prev_mask &= ~(unsigned) PREV_WORD;
         for (unsigned c = 0; c < 256; c++) {
             std::vector<uint8_t> sig;
             for (uint32_t pc = 0; pc < prog->len; pc++) {
@@ -270,6 +287,14 @@ sre_dfa_build(const sre_program_t *prog, uint32_t max_states, const char **why)
     b.variant.push_back(0);
     b.prevk.push_back(0);
     b.visited.push_back(std::vector<uint32_t>());
+    b.fresh.push_back(std::vector<uint8_t>());
+    {
+        uint32_t slot = 0;
+        for (uint32_t r = 0; r < prog->nregexes; r++) {
+            b.slot0_mask |= 1ull << slot;
+            slot += 2 * (prog->multi_ncaps[r] + 1);
+        }
+    }
     std::vector<std::vector<uint32_t>> init_lists(SRE_DFA_NINIT);
     std::vector<std::vector<uint8_t>>  lin_par_of_init(SRE_DFA_NINIT);
     std::vector<std::vector<uint64_t>> lin_sav_of_init(SRE_DFA_NINIT);
@@ -281,12 +306,13 @@ sre_dfa_build(const sre_program_t *prog, uint32_t max_states, const char **why)
         b.npar.clear();
         b.nsav.clear();
         b.vis_now.clear();
-        b.closure(0, v == SRE_DFA_INIT_START, v != SRE_DFA_INIT_RESTART, false,
+        b.closure(0, v == SRE_DFA_INIT_START, v == SRE_DFA_INIT_START || v == SRE_DFA_INIT_RESTART_NL, false,
                   SRE_DFA_NO_PARENT, b.nl, b.npar, b.nsav, &ds, &dr, true);
-        /* in front of the position: the buffer start (look-ahead programs are
-         * only ever started on a fresh context, see sre_dfa.h) */
-        d->init[v] = b.intern(b.nl, false, 1, v,
-                              v == SRE_DFA_INIT_START ? PREV_START : v == SRE_DFA_INIT_RESTART_NL ? PREV_NL : 0);
+        /* in front of the position: the buffer start, or the byte the context remembers
+         * (seen_newline / seen_word, sre_vm_pike.c:586-601) */
+        d->init[v] = b.intern(b.nl, false, 1, v == SRE_DFA_INIT_RESTART_WORD ? (int) SRE_DFA_INIT_RESTART : v,
+                              v == SRE_DFA_INIT_START ? PREV_START : v == SRE_DFA_INIT_RESTART_NL ? PREV_NL
+                              : v == SRE_DFA_INIT_RESTART_WORD ? PREV_WORD : 0, b.nsav);
         lin_par_of_init[v] = b.npar;
         lin_sav_of_init[v] = b.nsav;
         init_lists[v] = b.nl;
@@ -308,7 +334,7 @@ sre_dfa_build(const sre_program_t *prog, uint32_t max_states, const char **why)
         if (prog->nleading && prog->lookahead_asserts == 0 && b.sss[s] == 2) {      /* (chunked streams of look-ahead
                                                                                       programs stay on the exact VM) */
             const std::vector<uint32_t> Lc = b.lists[s];
-            unskip_of[s] = b.intern(Lc, d->matched[s] != 0, 1, b.variant[s], 0);
+            unskip_of[s] = b.intern(Lc, d->matched[s] != 0, 1, b.variant[s], 0, std::vector<uint64_t>(Lc.size(), 0));
         }
         const std::vector<uint32_t> L = b.lists[s];
         const bool                  was_matched = d->matched[s] != 0;
@@ -366,7 +392,7 @@ sre_dfa_build(const sre_program_t *prog, uint32_t max_states, const char **why)
                 b.closure(0, false, c == '\n', false, SRE_DFA_NO_PARENT, b.nl, b.npar, b.nsav, &ds, &dr, true);
                 b.nearly.assign(b.nl.size(), 0);
                 t.skipped = 1;
-                t.next = b.intern(b.nl, was_matched, 2, var, prev_next);
+                t.next = b.intern(b.nl, was_matched, 2, var, prev_next, b.nsav);
             } else {
                 /* the list as a work queue: a look-ahead assertion that holds
                  * puts the closure of its continuation in front (:506-526) */
@@ -391,6 +417,9 @@ sre_dfa_build(const sre_program_t *prog, uint32_t max_states, const char **why)
                         t.ev_src = it.src;
                         t.ev_regex = (uint16_t) in.arg;
                         t.ev_early = it.early;
+                        /* its group-0 start was saved at this very position: by the splice
+                         * that listed it, or on the closure path of the thread it descends from */
+                        t.ev_empty = ((it.early & b.slot0_mask) != 0 || b.fresh[s][it.src]) ? 1 : 0;
                         break;
                     }
                     if (in.opcode == SRE_OP_ASSERT) {                 /* :450-504 */
@@ -432,11 +461,12 @@ sre_dfa_build(const sre_program_t *prog, uint32_t max_states, const char **why)
                         t.ev_regex = (uint16_t) dr;
                         t.ev_saves = ds;
                         t.ev_early = it.early & ~ds;
+                        t.ev_empty = (ds & b.slot0_mask) ? 1 : 0;     /* start == end == pos + 1 */
                         break;
                     }
                 }
                 t.next = b.intern(b.nl, was_matched || t.ev_kind != SRE_DFA_EV_NONE,
-                                  (base_flag || b.visited_start) ? 1 : 0, var, prev_next);
+                                  (base_flag || b.visited_start) ? 1 : 0, var, prev_next, b.nsav);
             }
             t.lin_off = (uint32_t) d->lin_parent.size();
             t.lin_n = (uint16_t) b.nl.size();

@@ -38,7 +38,10 @@ enum {
     SRE_DFA_INIT_START      = 0,  /* stream start:  \A holds, ^ holds        */
     SRE_DFA_INIT_RESTART_NL = 1,  /* re-armed search, ^ holds                */
     SRE_DFA_INIT_RESTART    = 2,  /* re-armed search, ^ fails                */
-    SRE_DFA_NINIT           = 3
+    SRE_DFA_INIT_RESTART_WORD = 3, /* re-armed search, ^ fails, the byte in front is a word byte (the
+                                     context's seen_word, sre_vm_pike.c:472-473, 594); the same list
+                                     as RESTART unless the program has \b or \B */
+    SRE_DFA_NINIT           = 4
 };
 
 #define SRE_DFA_DEAD          0u      /* state 0: empty thread list */
@@ -49,6 +52,8 @@ struct sre_dfa_trans_t {
     uint32_t next;
     uint8_t  ev_kind;
     uint8_t  ev_src;        /* index (old list) of the thread that reached MATCH */
+    uint8_t  ev_empty;      /* the match is empty (start == end): the caller's next search starts one
+                               byte further (sre_vm_pike.c:179-196) */
     uint16_t ev_regex;
     uint64_t ev_saves;      /* DONE: slots saved on the way to MATCH (value pos + 1) */
     uint64_t ev_early;      /* slots saved by a look-ahead splice in front of the event (value pos) */
@@ -65,9 +70,8 @@ struct sre_dfa_s {
     uint32_t max_threads;           /* longest thread list of any state */
     uint32_t nslots;
     int      has_caret;             /* program contains ^ or \A */
-    int      has_lookahead;         /* program contains $ \z \b \B: valid from a FRESH context only
-                                       (init[SRE_DFA_INIT_START]); a re-armed search would need the
-                                       context's seen_word, which no initial list models */
+    int      has_lookahead;         /* program contains $ \z \b \B (a re-armed search starts from
+                                       init[SRE_DFA_INIT_RESTART_WORD] when the context's seen_word is set) */
     std::vector<sre_dfa_trans_t> trans;      /* [nstates][ncls + 1] */
     std::vector<uint8_t>         lin_parent; /* old-list index or SRE_DFA_NO_PARENT */
     std::vector<uint64_t>        lin_saves;  /* slots saved on the closure path (value pos + 1) */

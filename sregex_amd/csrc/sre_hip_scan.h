@@ -54,7 +54,11 @@
 #define SRE_SCAN_SEG_ALIGN    256u    /* segments are a multiple of the line size */
 
 /* device-only event kind: a DONE (match end = pos + 1) whose match is empty */
+#define SRE_SCAN_NINIT 4u            /* = SRE_DFA_NINIT: initial lists, and their pseudo transitions behind the
+                                       real ones (sre_dfa.cpp) */
 #define SRE_DEV_EV_DONE_EMPTY 3
+#define SRE_DEV_EV_POP_FULL   4     /* a popped MATCH thread whose match is NOT empty (behind a look-ahead
+                                       assertion: foo$); plain SRE_DFA_EV_POP on the device = empty */
 
 /* full transition record (global memory; slow path and lineage kernels) */
 typedef struct {
@@ -73,6 +77,8 @@ typedef struct {
 typedef struct {
     uint32_t nstates, ncls, nslots, max_threads;
     uint32_t init[4];                   /* SRE_DFA_INIT_* -> state */
+    uint32_t word_restart;              /* init[RESTART_WORD] differs: a re-armed search looks at the word-ness
+                                           of the byte in front of it (restart_variant) */
     int32_t  mode;                      /* SRE_HIP_* */
     uint32_t fast_bytes;                /* nstates * 1024 */
     uint32_t stride, class_bits;        /* input bytes per fast-table step */

@@ -196,9 +196,13 @@ stream_of(const sre_scan_geom_t &G, uint64_t g)
  * after an empty match it is the byte the caller skipped (:179-196).  (Without
  * ^ in the program the three initial lists coincide.) */
 __device__ inline uint32_t
-restart_variant(const uint8_t *data, int64_t sp)
+restart_variant(const sre_scan_tables_t &T, const uint8_t *data, int64_t sp)
 {
-    return data[sp - 1] == '\n' ? 1u : 2u;
+    const uint32_t c = data[sp - 1];
+    if (c == '\n') return 1u;
+    /* \b / \B at the search start: the context's seen_word (:472-473, 594), ASCII [0-9A-Za-z_] */
+    if (T.word_restart && ((c - '0') < 10u || ((c | 32u) - 'a') < 26u || c == '_')) return 3u;
+    return 2u;
 }
 
 enum : uint32_t {
@@ -352,8 +356,8 @@ __device__ void slow_run(Walk &w, int64_t p, int64_t p_to, bool warm, uint32_t w
         {
             /* next exec: from the match end; one byte further after an empty
              * match (sre_vm_pike.c:179-196, 624-628) */
-            const bool    pop = (w.ev_kind == EV_POP);
-            const bool    empty = pop || w.ev_kind == SRE_DEV_EV_DONE_EMPTY;
+            const bool    pop = (w.ev_kind == EV_POP || w.ev_kind == SRE_DEV_EV_POP_FULL);
+            const bool    empty = w.ev_kind == EV_POP || w.ev_kind == SRE_DEV_EV_DONE_EMPTY;
             const int64_t e = pop ? w.ev_pos : w.ev_pos + 1;
             w.complete_match();
             if (empty) {
@@ -366,7 +370,7 @@ __device__ void slow_run(Walk &w, int64_t p, int64_t p_to, bool warm, uint32_t w
             } else {
                 w.cur_sp = e;
             }
-            w.st = T.init[restart_variant(w.data, w.cur_sp)];
+            w.st = T.init[restart_variant(T, w.data, w.cur_sp)];
             p = w.cur_sp;
             /* an empty match that ended with a consumed byte can put the skipped
              * byte just outside this span */
@@ -408,7 +412,7 @@ resolve_fast_span(const sre_scan_tables_t *Tp, const uint16_t *tr2, const uint8_
             r.last_sym = sym;
             r.last_sp = r.sp;
             r.sp = gpos + b + 1;
-            st = T.init[restart_variant(data, r.sp)];
+            st = T.init[restart_variant(T, data, r.sp)];
         } else {
             st = tr.next;
         }
@@ -451,6 +455,9 @@ byte_x4(uint32_t v, uint32_t sh)
     return r;
 }
 
+#ifndef SRE_SCAN_PREFETCH
+#define SRE_SCAN_PREFETCH 1         /* stages of HBM loads in flight per lane (1 or 2), see sre_k_scan */
+#endif
 #ifndef SRE_COUNT_BLOCKS
 #define SRE_COUNT_BLOCKS 3          /* workgroups per CU the COUNT kernel's registers are budgeted for */
 #endif
@@ -735,10 +742,12 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
 
     const uint32_t nrounds = WARM / TILE + G.seg_bytes / TILE;
     const uint32_t lag = (tid >> 5) & 1u;
-    uint4          regs[4];
+    /* DIST = how many stages ahead the HBM loads are issued.  1: one set of staging registers,
+     * a stage's loads fly while the previous round is walked.  2: two sets, taking turns — a
+     * load has a whole iteration more to arrive before the wave needs it. */
+    constexpr uint32_t DIST = SRE_SCAN_PREFETCH;
     __syncthreads();                        /* row tables are complete */
-    tile_fetch(regs, rows, tid, 0);
-    for (uint32_t s = 0; s <= nrounds; s++) {
+    auto round = [&](const uint32_t s, uint4 (&regs)[4]) __attribute__((always_inline)) {
         /* LDS operations of one wave execute in order; the fences only stop the
          * compiler from moving tile reads across the stores */
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -747,14 +756,14 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         /* the next stage's HBM loads fly while this round is consumed from LDS */
-        if (s < nrounds) tile_fetch(regs, rows, tid, s + 1);
+        if (s + DIST <= nrounds) tile_fetch(regs, rows, tid, s + DIST);
 
-        if (s < lag || s - lag >= nrounds) continue;
+        if (s < lag || s - lag >= nrounds) return;
         const uint32_t r = s - lag;                     /* this lane's round */
         const bool     warm_round = (r < WARM / TILE);
-        if (!active || w.f(F_FINISHED) || (warm_round && !warm)) continue;
+        if (!active || w.f(F_FINISHED) || (warm_round && !warm)) return;
         const int64_t base = seg_a - WARM + (int64_t) r * TILE;
-        if (base >= seg_b || base < 0) continue;
+        if (base >= seg_b || base < 0) return;
         w.anchor_pos = warm_round ? -1 : base;
         w.anchor_state = w.st;
 
@@ -832,7 +841,7 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
                         in_pe_sym = w.ev_sym;
                     }
                 }
-                continue;
+                return;
             }
         }
         if (MODE != SRE_HIP_PIKE_COUNT && !warm_round) {
@@ -884,6 +893,19 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
                 in_pe_state = w.ev_state;
                 in_pe_sym = w.ev_sym;
             }
+        }
+    
+    };
+    uint4 regs[4];
+    tile_fetch(regs, rows, tid, 0);
+    if (DIST == 1) {
+        for (uint32_t s = 0; s <= nrounds; s++) round(s, regs);
+    } else {
+        uint4 regs2[4];
+        if (nrounds >= 1) tile_fetch(regs2, rows, tid, 1);
+        for (uint32_t s = 0; s <= nrounds; s += 2) {
+            round(s, regs);
+            if (s + 1 <= nrounds) round(s + 1, regs2);
         }
     }
 
@@ -1662,10 +1684,10 @@ sre_k_lineage_maps(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G
     if (k == st.ev_seg && st.ev_pos < hi) hi = st.ev_pos;      /* list at the event position */
     if (sp >= lo) {
         lo = sp;
-        cur = T.init[sp == 0 ? G.init_variant : restart_variant(data, sp)];
+        cur = T.init[sp == 0 ? G.init_variant : restart_variant(T, data, sp)];
     } else if (k < (int64_t) st.valid_from) {
         /* the recorded entry state belongs to an older search (Tracer::entry_state) */
-        cur = T.init[sp == 0 ? G.init_variant : restart_variant(data, sp)];
+        cur = T.init[sp == 0 ? G.init_variant : restart_variant(T, data, sp)];
         for (int64_t x = sp; x < lo; x++) cur = trl[cur * nsym + clsl[data[x]]].next;
     }
 
@@ -1928,7 +1950,7 @@ stage_walk_tables(const sre_scan_tables_t *__restrict__ tabp, uint8_t *lds, sre_
         uint32_t *fast = reinterpret_cast<uint32_t *>(lds);
         uint8_t  *clsl = lds + tabp->fast_bytes;
         uint8_t  *trl = clsl + 256;
-        const uint32_t tr_bytes = (tabp->nstates * (tabp->ncls + 1) + 3) * (uint32_t) sizeof(sre_dev_trans_t);
+        const uint32_t tr_bytes = (tabp->nstates * (tabp->ncls + 1) + SRE_SCAN_NINIT) * (uint32_t) sizeof(sre_dev_trans_t);
         uint64_t *savl = reinterpret_cast<uint64_t *>(trl + tr_bytes);
         uint32_t *lofl = reinterpret_cast<uint32_t *>(savl + tabp->lin_total);
         uint32_t *lpcl = lofl + tabp->nstates + 1;
@@ -2010,7 +2032,7 @@ sre_k_captures(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
     tr.n = (int64_t) geom_len(G, s);
     tr.sp = st.ev_sp;
     tr.seg_bytes = G.seg_bytes;
-    const uint32_t variant = st.ev_sp == 0 ? G.init_variant : restart_variant(tr.data, st.ev_sp);
+    const uint32_t variant = st.ev_sp == 0 ? G.init_variant : restart_variant(T, tr.data, st.ev_sp);
     tr.init_state = T.init[variant];
     tr.apos = (st.ev_apos >= st.ev_sp) ? st.ev_apos : -1;
     tr.astate = st.ev_astate;
@@ -2417,7 +2439,7 @@ sre_launch_captures(const sre_scan_tables_t *d_tab, sre_scan_tables_t h_tab, sre
     }
     const uint32_t block = verify ? 1024 : 64, grid = (geom.nstreams + block - 1) / block;
     const size_t   shmem = (size_t) h_tab.fast_bytes + 256
-                         + ((size_t) h_tab.nstates * (h_tab.ncls + 1) + 3) * sizeof(sre_dev_trans_t)
+                         + ((size_t) h_tab.nstates * (h_tab.ncls + 1) + SRE_SCAN_NINIT) * sizeof(sre_dev_trans_t)
                          + (size_t) h_tab.lin_total * 9 + ((size_t) h_tab.nstates + 1 + h_tab.list_total) * 4 + 16;
     if (shmem > 48 * 1024) {
         /* a big automaton (many byte classes x states): one lane per stream, so the
@@ -2512,7 +2534,7 @@ sre_launch_stream_tail(const sre_scan_tables_t *d_tab, sre_scan_tables_t h_tab, 
                        int eof, uint32_t ovec_slots, int verify, hipStream_t stream)
 {
     const size_t shmem = (size_t) h_tab.fast_bytes + 256
-                         + ((size_t) h_tab.nstates * (h_tab.ncls + 1) + 3) * sizeof(sre_dev_trans_t)
+                         + ((size_t) h_tab.nstates * (h_tab.ncls + 1) + SRE_SCAN_NINIT) * sizeof(sre_dev_trans_t)
                          + (size_t) h_tab.lin_total * 9 + ((size_t) h_tab.nstates + 1 + h_tab.list_total) * 4 + 16;
     if (shmem > 48 * 1024) {
         static bool raised = false;

@@ -61,8 +61,9 @@ sre_scan_tables_build(const sre_program_t *prog, const sre_dfa_t *d, int mode, c
         *why = "COUNT with ^ or \\A over several regexes needs the per-context newline flag";
         return NULL;
     }
-    if (mode == SRE_HIP_PIKE_COUNT && d->has_lookahead) {
-        *why = "COUNT with $ \\z \\b \\B needs the per-context word flag";
+    if (mode == SRE_HIP_PIKE_COUNT && d->has_lookahead && prog->nregexes > 1) {
+        /* ... and so does the word flag (:594) */
+        *why = "COUNT with $ \\z \\b \\B over several regexes needs the per-context word flag";
         return NULL;
     }
 
@@ -74,7 +75,9 @@ sre_scan_tables_build(const sre_program_t *prog, const sre_dfa_t *d, int mode, c
     h.ncls = d->ncls;
     h.nslots = d->nslots;
     h.max_threads = d->max_threads;
+    static_assert(SRE_SCAN_NINIT == SRE_DFA_NINIT, "initial lists");
     for (int v = 0; v < SRE_DFA_NINIT; v++) h.init[v] = d->init[v];
+    h.word_restart = d->init[SRE_DFA_INIT_RESTART_WORD] != d->init[SRE_DFA_INIT_RESTART];
     h.mode = mode;
     h.fast_bytes = d->nstates * SRE_FAST_ROW_BYTES;
     h.nregexes = prog->nregexes;
@@ -90,15 +93,13 @@ sre_scan_tables_build(const sre_program_t *prog, const sre_dfa_t *d, int mode, c
     /* is class k the newline?  (classes separate it whenever ^ is in the program) */
     std::vector<uint8_t> rep_is_nl(d->ncls + 1, 0);
     if (d->has_caret) rep_is_nl[d->cls_map[(unsigned char) '\n']] = 1;
-    /* a DONE whose closure also saved the matched regex's group-0 start: the
-     * match is empty (start == end == pos + 1) although a byte was consumed —
-     * the ".*?" thread stepping into a nullable regex behind an assertion */
-    auto done_is_empty = [&](const sre_dfa_trans_t &tr) -> bool {
-        if (tr.ev_kind != SRE_DFA_EV_DONE) return false;
-        uint32_t slot0 = 0;
-        for (uint32_t i = 0; i < tr.ev_regex; i++) slot0 += 2 * (prog->multi_ncaps[i] + 1);
-        return ((tr.ev_saves >> slot0) & 1) != 0;
-    };
+    /* ... a word byte?  (classes separate them whenever \b or \B is) */
+    std::vector<uint8_t> rep_is_word(d->ncls + 1, 0);
+    if (d->init[SRE_DFA_INIT_RESTART_WORD] != d->init[SRE_DFA_INIT_RESTART]) {
+        for (unsigned c = 0; c < 256; c++) {
+            if (sre_isword(c)) rep_is_word[d->cls_map[c]] = 1;
+        }
+    }
     auto build_fast = [&](int fmode) {
     std::vector<uint32_t> fast((size_t) d->nstates * 256);
     for (uint32_t s = 0; s < d->nstates; s++) {
@@ -113,12 +114,13 @@ sre_scan_tables_build(const sre_program_t *prog, const sre_dfa_t *d, int mode, c
                 }
                 const sre_dfa_trans_t &tr = d->t(st, k);
                 if (fmode == SRE_HIP_PIKE_COUNT && tr.ev_kind == SRE_DFA_EV_DONE
-                    && tr.next == SRE_DFA_DEAD && !done_is_empty(tr))
+                    && tr.next == SRE_DFA_DEAD && !tr.ev_empty)
                 {
                     /* a non-empty match completes and nothing outlives it: the
                      * next search starts at the next byte (sre_vm_pike.c:624-628) */
                     /* the byte in front of that search is the one just consumed */
-                    st = d->init[rep_is_nl[k] ? SRE_DFA_INIT_RESTART_NL : SRE_DFA_INIT_RESTART];
+                    st = d->init[rep_is_nl[k] ? SRE_DFA_INIT_RESTART_NL : rep_is_word[k] ? SRE_DFA_INIT_RESTART_WORD
+                                              : SRE_DFA_INIT_RESTART];
                     cnt++;
                 } else if (tr.ev_kind != SRE_DFA_EV_NONE || tr.next == SRE_DFA_DEAD) {
                     flags |= SRE_FAST_SLOW;
@@ -210,7 +212,8 @@ sre_scan_tables_build(const sre_program_t *prog, const sre_dfa_t *d, int mode, c
         sre_dev_trans_t       &b = trans[i];
         memset(&b, 0, sizeof(b));
         b.next = a.next;
-        b.kind = done_is_empty(a) ? SRE_DEV_EV_DONE_EMPTY : a.ev_kind;
+        b.kind = a.ev_kind == SRE_DFA_EV_DONE ? (a.ev_empty ? SRE_DEV_EV_DONE_EMPTY : SRE_DFA_EV_DONE)
+               : a.ev_kind == SRE_DFA_EV_POP ? (a.ev_empty ? SRE_DFA_EV_POP : SRE_DEV_EV_POP_FULL) : 0;
         b.src = a.ev_src;
         b.regex = a.ev_regex;
         b.lin_off = a.lin_off;
@@ -297,7 +300,7 @@ sre_scan_tables_build(const sre_program_t *prog, const sre_dfa_t *d, int mode, c
          * for SRE_SCAN_LDS_LIMIT in all; the capture walker and the lineage kernel
          * may take SRE_CAPTURE_LDS_LIMIT.  Otherwise the exact VM engine takes the
          * program. */
-        const size_t tr = ((size_t) d->nstates * nsym + 3) * sizeof(sre_dev_trans_t);
+        const size_t tr = ((size_t) d->nstates * nsym + SRE_SCAN_NINIT) * sizeof(sre_dev_trans_t);
         const size_t scan_lds = sre_scan_lds_bytes(&h);
         const size_t fast_end = (size_t) h.fast_rows * SRE_FAST_ROW_BYTES + 768 + (bits == 8 ? 512 : (8 / bits) * 512);
         const size_t cap_lds = (size_t) h.fast_bytes + 256 + tr + (size_t) h.lin_total * 9

@@ -338,9 +338,6 @@ pike_scan_route(sre_vm_pike_ctx_t *ctx, sre_char *input, size_t len, sre_int_t *
         }
     }
     if (ctx->scanner == NULL) return 0;
-    /* look-ahead assertions: the automaton models a FRESH context only (a
-     * re-armed search needs seen_word, sre_vm_pike.c:472-473, 594) */
-    if (ctx->prog->lookahead_asserts && (ctx->empty_capture || ctx->processed_bytes != 0)) return 0;
     /* the NFA tier's exact window runs a FRESH context from a clean position */
     if (sre_hip_scanner_engine(ctx->scanner) == SRE_HIP_ENGINE_NFA
         && (ctx->empty_capture || ctx->processed_bytes != 0))
@@ -350,13 +347,15 @@ pike_scan_route(sre_vm_pike_ctx_t *ctx, sre_char *input, size_t len, sre_int_t *
 
     size_t skip = 0;
     int    variant;
+    /* which initial list: ^ goes by the context's seen_newline, \b / \B by its seen_word
+     * (sre_vm_pike.c:472-473, 586-601, 851-860) — SRE_DFA_INIT_* */
     if (ctx->empty_capture) {                               /* :179-196 */
         skip = 1;
-        variant = input[0] == '\n' ? 1 : 2;
+        variant = input[0] == '\n' ? 1 : sre_isword(input[0]) ? 3 : 2;
     } else if (ctx->processed_bytes == 0) {
         variant = 0;
     } else {
-        variant = ctx->seen_newline ? 1 : 2;
+        variant = ctx->seen_newline ? 1 : ctx->seen_word ? 3 : 2;
     }
 
     DeviceStream *ds = ctx->ds;

@@ -138,7 +138,12 @@ int64_t dfa_sim_findall(void *dv, const sre_program_t *prog, const uint8_t *data
     std::vector<uint32_t> trace;
     std::vector<int64_t>  vec(d->nslots + 1);
     int64_t               count = 0, chunk = 0;
-    bool                  empty_capture = false, seen_newline = false, ctx_eof = false;
+    bool                  empty_capture = false, seen_newline = false, seen_word = false, ctx_eof = false;
+    auto isword = [](uint8_t c) { return (c >= '0' && c <= '9') || (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z') || c == '_'; };
+    /* a re-armed search: ^ from seen_newline, \b / \B from seen_word (sre_vm_pike.c:472-473, 586-601) */
+    auto rearmed = [&](bool nl, bool word) {
+        return nl ? SRE_DFA_INIT_RESTART_NL : word ? SRE_DFA_INIT_RESTART_WORD : SRE_DFA_INIT_RESTART;
+    };
 
     while (count < max_matches) {
         if (ctx_eof) return -(count + 1);      /* SRE_ERROR ends the iteration */
@@ -147,11 +152,11 @@ int64_t dfa_sim_findall(void *dv, const sre_program_t *prog, const uint8_t *data
         if (empty_capture) {                                   /* sre_vm_pike.c:179-196 */
             if (chunk == n) break;
             sp = chunk + 1;
-            variant = data[chunk] == '\n' ? SRE_DFA_INIT_RESTART_NL : SRE_DFA_INIT_RESTART;
+            variant = rearmed(data[chunk] == '\n', isword(data[chunk]));
         } else if (chunk == 0) {
             variant = SRE_DFA_INIT_START;
         } else {
-            variant = seen_newline ? SRE_DFA_INIT_RESTART_NL : SRE_DFA_INIT_RESTART;
+            variant = rearmed(seen_newline, seen_word);
         }
         Search r = run_search(d, data, n, sp, variant, &trace);
         if (r.rc < 0) break;
@@ -166,9 +171,14 @@ int64_t dfa_sim_findall(void *dv, const sre_program_t *prog, const uint8_t *data
         for (int64_t k = 0; k < nov; k++) rec[1 + k] = k < ncopy ? vec[ofs + k] : -1;
 
         /* :586-601 — flags for the next search come from slot 1 of the match */
-        if (vec[1] >= 0 && vec[1] > chunk) seen_newline = data[vec[1] - 1] == '\n';
+        if (vec[1] >= 0 && vec[1] > chunk) {
+            seen_newline = data[vec[1] - 1] == '\n';
+            seen_word = isword(data[vec[1] - 1]);
+        }
         int64_t start = vec[ofs], end = vec[ofs + 1];
         empty_capture = (start == end);
+        /* what the COUNT scan goes by instead of captures: the event transition's own flag */
+        if ((d->t(r.ev_state, r.ev_sym).ev_empty != 0) != empty_capture) return -1000000;
         chunk = end;
         count++;
         ctx_eof = r.poisoned;

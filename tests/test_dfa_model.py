@@ -98,11 +98,7 @@ def test_model_findall_goldens(sim):
             if not d:
                 continue
             want = rec["matches"] if rec["matches"][-1] == [S.SRE_ERROR] else rec["matches"][:-1]
-            if sim.dfa_sim_has_lookahead(d):
-                # a re-armed search would need the context's seen_word: first match only
-                assert _findall(sim, d, prog, rec["ncaps"], data, 1) == want[:1], rec["re"]
-            else:
-                assert _findall(sim, d, prog, rec["ncaps"], data) == want, rec["re"]
+            assert _findall(sim, d, prog, rec["ncaps"], data) == want, rec["re"]
             sim.dfa_sim_free(d)
             n += 1
     assert n >= 8
@@ -170,10 +166,12 @@ def test_model_lookahead_assertions_vs_oracle(sim):
             assert d, (pats, why)
             for _ in range(150):
                 data = bytes(rng.choice(alphabet) for _ in range(rng.randrange(0, 24)))
-                want = harness.findall(ora, prog, re.ncaps, data, 1)[:1]
-                if want and want[0][0] < 0:
-                    want = []
-                assert _findall(sim, d, prog, re.ncaps, data, 1) == want, (pats, data)
+                # the whole find-all iteration: re-armed searches start from the context's
+                # seen_newline / seen_word (SRE_DFA_INIT_RESTART_NL / _WORD)
+                want = harness.findall(ora, prog, re.ncaps, data, 1 << 30)
+                if want[-1] != [S.SRE_ERROR]:
+                    want = want[:-1]
+                assert _findall(sim, d, prog, re.ncaps, data) == want, (pats, data)
             sim.dfa_sim_free(d)
 
 
@@ -194,17 +192,12 @@ def test_model_random_patterns_vs_oracle(sim):
             if not d:
                 continue
             built += 1
-            look = sim.dfa_sim_has_lookahead(d)
             for _ in range(8):
                 data = bytes(rng.choice(alphabet) for _ in range(rng.choice([0, 1, 2, 5, 17, 40, 90])))
-                want = harness.findall(ora, prog, re.ncaps, data, 1 if look else 1 << 30)
-                if look:
-                    want = [] if want[0][0] < 0 else want[:1]
-                    got = _findall(sim, d, prog, re.ncaps, data, 1)
-                else:
-                    if want[-1] != [S.SRE_ERROR]:
-                        want = want[:-1]
-                    got = _findall(sim, d, prog, re.ncaps, data)
+                want = harness.findall(ora, prog, re.ncaps, data, 1 << 30)
+                if want[-1] != [S.SRE_ERROR]:
+                    want = want[:-1]
+                got = _findall(sim, d, prog, re.ncaps, data)
                 assert got == want, (pats, data)
                 t = ora.thompson(prog)
                 th = t.exec(data, True)

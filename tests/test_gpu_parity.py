@@ -118,6 +118,39 @@ def test_batched_count_vs_oracle(gpu, engine):
             assert rec == cnt, (pats, rec, cnt)
 
 
+def test_count_with_lookahead_assertions_on_the_scanner(gpu):
+    """Find-all counting of a program with $ \\z \\b \\B on the table-driven scanner
+    (ENGINE_SCAN is forced: a decline raises).  A re-armed search starts from the initial
+    list of its context's seen_newline / seen_word (SRE_DFA_INIT_RESTART_NL / _WORD); a match
+    that ends in front of a byte by look-ahead (foo$) is followed by a search that reads
+    that byte again; an empty one skips a byte (sre_vm_pike.c:179-196, 586-601)."""
+    import random
+    ora = harness.OracleEngine()
+    rng = random.Random(77)
+    zoo = [[rb"\b(\w+)\b"], [rb"a$"], [rb"\bfoo\b"], [rb"\B"], [rb"\b"], [rb"$"], [rb"(a+)\b(?:\s|$)"], [rb"x*\b"],
+           [rb"(\w)\B(\w)"], [rb"^(\w+)$"], [rb"(?:$|a)(b|\b)"], [rb"[a-c]+$"], [rb"\Ba\B"], [rb"(\s*)\b([a-c]+)\B"]]
+    alphabets = [b"ab c\n_x.", b"foo \nab", b"aaa\n "]
+    n = 0
+    for pats in zoo:
+        with S.Pool() as pool:
+            re = S.parse(pool, pats)
+            prog = S.compile(pool, re)
+            for seg in (0, 64, 256):
+                sc = S.Scanner(pool, prog, S.HIP_PIKE_COUNT, S.ENGINE_SCAN)
+                if seg:
+                    sc.set_segment_bytes(seg)
+                datas = [bytes(rng.choice(a) for _ in range(size)) for a in alphabets for size in (0, 1, 77, 3000, 20000)]
+                bufs = [S.DeviceBuffer.from_bytes(d) for d in datas]
+                got = sc.scan([b.ptr for b in bufs], [len(d) for d in datas])
+                for d, g in zip(datas, got):
+                    _, cnt = _expect(ora, prog, re.ncaps, d)
+                    assert g == cnt, (pats, seg, len(d), g, cnt)
+                    n += 1
+                for b in bufs:
+                    b.free()
+    assert n == len(zoo) * 3 * 15
+
+
 def test_many_ragged_streams_one_call(gpu):
     """Independent streams of different lengths (incl. empty) in one batch."""
     ora = harness.OracleEngine()
@@ -373,6 +406,12 @@ def test_compat_api_large_buffers_take_the_scanner(gpu):
         ([rb"^abc"], (b"abccc" * 9000 + b"\n") * 3),
         ([rb"x*"], b"ab" * 20000),
         ([rb"(a+)(b+)?"], b"b a\nca" + b" " * 40000 + b"a\nc" + b"." * 40000),
+        # look-ahead assertions on a re-armed context: \b / \B go by its seen_word, $ ends a match
+        # in front of a byte the next search reads again
+        ([rb"\b(\w+)\b"], b"foo bar_1  baz\n" * 3000 + b"tail"),
+        ([rb"(a+)$"], (b"xaa\n" + b"b" * 300 + b"a\n\n") * 200 + b"aaa"),
+        ([rb"\B"], b"ab  c_d\n" * 2000),
+        ([rb"x*\b"], b"xx yx\nz " * 2500),
     ]
     for pats, data in cases:
         with S.Pool() as pool:

@@ -14,12 +14,14 @@ d=json.loads(sys.stdin.read()); r=d['roofline']
 print('step_ms %.4f kernel_ms %.4f frac %.4f kfrac %.4f seg %s' % (r['step_ms'], r['kernel_ms'], r['frac'], r['kernel_frac'], d['config']['segment_bytes']))")
   echo "$CFG $EXTRA | $name | $out"
 }
-C4=$PWD/sregex_amd/lib_c4/libsregex.so
-for CFG in cfg3 dense; do
+P2=$PWD/sregex_amd/lib_p2/libsregex.so
+for CFG in cfg2 cfg2m cfg4 cfg3 dense; do
 EXTRA=
-one "wide, 2 per CU (default)" A=1
-one "narrow, 3 per CU" SRE_HIP_NO_WIDE4=1 SRE_HIP_LDS_PAD=0
-one "narrow, 2 per CU" SRE_HIP_NO_WIDE4=1
-one "narrow, 4 per CU (66 spills)" SRE_HIP_NO_WIDE4=1 SRE_HIP_LDS_PAD=0 SREGEX_AMD_LIB=$C4
-one "wide, 2 per CU again" A=1
+one "one stage in flight (default)" A=1
+one "two stages in flight" SREGEX_AMD_LIB=$P2
+one "one stage in flight again" A=1
+one "two stages in flight again" SREGEX_AMD_LIB=$P2
 done
+CFG=cfg2 EXTRA=--many-streams
+one "one stage in flight (default)" A=1
+one "two stages in flight" SREGEX_AMD_LIB=$P2
