@@ -133,17 +133,20 @@ def workload_spec(name, S, nbytes, rank=0, world=1):
         elif name == "nfa":
             pats, tail = [NFA_PAT], b" abaabaabab@ "
             text = "declined by the step automaton: /(?:a|b)*a(?:a|b){7}@/ Pike first-match, NFA tier"
-        elif name in ("dense", "densef"):
+        elif name in ("dense", "densef", "densela"):
             # a match every MiB: the stream is one 1 MiB gen-data block with a matching tail, repeated
             block = S.gen_data_length(1 << 20, 10)
             nblk = max(1, nbytes // block)
-            mode = S.HIP_PIKE_COUNT if name == "dense" else S.HIP_PIKE_FIRST
-            text = ("configs[1] pattern, a match every MiB (%d x %d-byte gen-data blocks ending in ' a@abc.cc '), %s"
-                    % (nblk, block, "find-all count" if name == "dense" else "first match"))
+            mode = S.HIP_PIKE_FIRST if name == "densef" else S.HIP_PIKE_COUNT
+            if name == "densela":
+                pats = [rb"\b[a-z]+@[a-z]+\.[a-z]+\b"]       # look-ahead assertions in a find-all count
+            text = ("%s, a match every MiB (%d x %d-byte gen-data blocks ending in ' a@abc.cc '), %s"
+                    % ("configs[1] pattern" if name != "densela" else "/\\b[a-z]+@[a-z]+\\.[a-z]+\\b/",
+                       nblk, block, "first match" if name == "densef" else "find-all count"))
             return dict(name=name, pats=pats, mode=mode, lens=[nblk * block], tails=[b" a@abc.cc "], text=text,
                         block=block, check=(
                             (lambda recs, n=nblk * block, k=nblk: _assert_eq(recs[0], [0, k, n - 9, n - 1]))
-                            if name == "dense" else
+                            if name != "densef" else
                             (lambda recs, b=block: _assert_eq(recs[0], [0, 1, b - 9, b - 1]))))
         n = S.gen_data_length(nbytes, len(tail))
         lens, tails = [n], [tail]
@@ -295,7 +298,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true",
                     help="N=1: do not measure the other configurations beside the headline (config.variants)")
-    ap.add_argument("--config", default="cfg2", choices=["cfg1", "cfg2", "cfg2m", "cfg3", "cfg4", "nfa", "dense", "densef"],
+    ap.add_argument("--config", default="cfg2", choices=["cfg1", "cfg2", "cfg2m", "cfg3", "cfg4", "nfa", "dense", "densef", "densela"],
                     help="N=1 headline workload: cfg2 = BASELINE configs[1] (default); cfg2m = same with a "
                          "matching tail (captures span the whole stream); cfg3 = configs[2] multi-regex "
                          "find-all count; cfg4 = configs[3] URI, 4 groups; cfg1 = configs[0]'s pattern, "
@@ -400,7 +403,7 @@ def main():
             # time and whole-step fraction of the HBM peak (every kernel of the step), the
             # dominant kernel alone beside it
             variants = {}
-            for name in ("cfg2m", "cfg3", "cfg4", "nfa", "dense", "densef", "many"):
+            for name in ("cfg2m", "cfg3", "cfg4", "nfa", "dense", "densef", "densela", "many"):
                 try:
                     vs = workload_spec(name, S, 8 * GIB if name == "many" else args.bytes)
                     vm = measure(vs, S, torch, res, hstream, stream, min(args.steps, 6), 2, barrier)
