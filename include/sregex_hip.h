@@ -78,6 +78,11 @@ SRE_API int sre_hip_scanner_last_fixups(sre_hip_scanner_t *sc);
  * segments' transition functions (FIRST / Thompson; an automaton that never forgets) */
 SRE_API int sre_hip_scanner_last_exact_passes(sre_hip_scanner_t *sc);
 
+/* diagnostics: how many sre_vm_pike_exec / sre_vm_thompson_exec calls of this process went
+ * where — out[0] one whole buffer through a throughput scanner, out[1] a chunk of a chunked
+ * stream through the table-driven scanner, out[2] the exact VM kernel */
+SRE_API void sre_hip_compat_route_counts(unsigned long long out[3]);
+
 /* diagnostics: 1 when the last scan had to build per-segment ancestor maps to
  * reconstruct the captures of a match spanning many segments */
 SRE_API int sre_hip_scanner_last_lineage_passes(sre_hip_scanner_t *sc);

@@ -61,6 +61,7 @@ API = {
     "sre_hip_scanner_last_fixups": (ctypes.c_int, [_vp]),
     "sre_hip_scanner_last_lineage_passes": (ctypes.c_int, [_vp]),
     "sre_hip_scanner_last_exact_passes": (ctypes.c_int, [_vp]),
+    "sre_hip_compat_route_counts": (None, [ctypes.POINTER(ctypes.c_ulonglong)]),
     "sre_hip_scanner_class_bits": (ctypes.c_int, [_vp]),
     "sre_hip_scanner_kernel_name": (ctypes.c_char_p, [_vp]),
     "sre_hip_scanner_last_kernel_ms": (ctypes.c_double, [_vp]),
@@ -372,6 +373,13 @@ class DeviceBuffer:
         if self.ptr:
             self.lib.sre_hip_free(self.ptr)
             self.ptr = None
+
+
+def compat_route_counts():
+    """(whole buffer on a scanner, chunk on the table-driven scanner, exact VM) exec calls so far"""
+    out = (ctypes.c_ulonglong * 3)()
+    load_library().sre_hip_compat_route_counts(out)
+    return tuple(out)
 
 
 def gen_data_length(n, tail_len):

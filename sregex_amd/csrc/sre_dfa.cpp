@@ -43,7 +43,12 @@ struct Builder {
     std::map<std::vector<uint32_t>, uint32_t> ids;     /* key: pcs..., flags [, prev, visited pcs...] */
     std::vector<std::vector<uint32_t>> lists;          /* per state */
     std::vector<uint8_t>               sss, variant;   /* per state */
-    std::vector<uint8_t>               prevk;          /* per state: PREV_* of the byte in front */
+    std::vector<uint8_t>               prevk;          /* per state: PREV_* of the byte in front, as a SPLICE sees it
+                                                          (^ / \A in its closure, \b / \B threads it lists and
+                                                          decides in the same step) */
+    std::vector<uint8_t>               prevw;          /* per state: the byte in front is a word byte, as the LISTED
+                                                          \b / \B threads see it (their own seen_word).  Differs from
+                                                          prevk only in the states a chunk boundary makes (rekind) */
     std::vector<std::vector<uint8_t>>  fresh;          /* per state, per thread: a look-ahead assertion (or MATCH)
                                                           thread whose own closure path saved a group-0 start,
                                                           i.e. a match it completes at this position is empty */
@@ -154,8 +159,6 @@ struct Builder {
         }
     }
 
-    /* seen_start: 0 clear, 1 set (consumed by the next check), 2 set by a skip
-     * re-seed that is still travelling to its target byte (see step) */
     uint32_t intern(const std::vector<uint32_t> &pcs, bool matched, int seen_start, int var,
                     unsigned prev, const std::vector<uint64_t> &saves)
     {
@@ -164,13 +167,6 @@ struct Builder {
         for (size_t i = 0; i < pcs.size(); i++) {
             if ((is_lookahead(pcs[i]) || prog->insns[pcs[i]].opcode == SRE_OP_MATCH) && (saves[i] & slot0_mask)) fr[i] = 1;
         }
-        if (prog->nleading == 0) {       /* the skip does not exist: flags are inert */
-            seen_start = 0;
-            var = 0;
-        }
-        if (!d->has_caret) var = 0;      /* all three initial lists coincide */
-        std::vector<uint32_t> key(pcs);
-        key.push_back((matched ? 1u : 0u) | ((uint32_t) seen_start << 1) | ((uint32_t) var << 3));
         std::vector<uint32_t> vis;
         if (holds_lookahead(pcs)) {
             /* what a splice out of this list will see (:506-526): the marks of
@@ -180,8 +176,30 @@ struct Builder {
             for (uint32_t pc = 0; pc < prog->len; pc++) {
                 if (tags[pc] == gen) vis.push_back(pc);
             }
+        }
+        return intern_raw(pcs, matched, seen_start, var, prev, (prev & PREV_WORD) != 0, vis, fr);
+    }
+
+    /* seen_start: 0 clear, 1 set (consumed by the next check), 2 set by a skip
+     * re-seed that is still travelling to its target byte (see step) */
+    uint32_t intern_raw(const std::vector<uint32_t> &pcs, bool matched, int seen_start, int var,
+                        unsigned prev, bool listed_word, const std::vector<uint32_t> &vis_in,
+                        const std::vector<uint8_t> &fr)
+    {
+        if (pcs.empty()) return SRE_DFA_DEAD;
+        if (prog->nleading == 0) {       /* the skip does not exist: flags are inert */
+            seen_start = 0;
+            var = 0;
+        }
+        if (!d->has_caret) var = 0;      /* all three initial lists coincide */
+        std::vector<uint32_t> key(pcs);
+        key.push_back((matched ? 1u : 0u) | ((uint32_t) seen_start << 1) | ((uint32_t) var << 3));
+        std::vector<uint32_t> vis;
+        if (holds_lookahead(pcs)) {
+            vis = vis_in;
             prev &= prev_mask;
-            key.push_back(0x80000000u | prev);
+            if (!(prev_mask & PREV_WORD)) listed_word = false;
+            key.push_back(0x80000000u | prev | (listed_word ? 0x100u : 0u));
             key.insert(key.end(), vis.begin(), vis.end());
             key.push_back(0xc0000000u);
             for (size_t i = 0; i < fr.size(); i++) {
@@ -189,6 +207,7 @@ struct Builder {
             }
         } else {
             prev = 0;
+            listed_word = false;
         }
         auto it = ids.find(key);
         if (it != ids.end()) return it->second;
@@ -199,6 +218,7 @@ struct Builder {
         sss.push_back((uint8_t) seen_start);
         variant.push_back((uint8_t) var);
         prevk.push_back((uint8_t) prev);
+        prevw.push_back(listed_word ? 1 : 0);
         visited.push_back(vis);
         fresh.push_back(fr);
         return id;
@@ -225,6 +245,12 @@ sre_dfa_free(sre_dfa_t *dfa)
 
 extern "C" sre_dfa_t *
 sre_dfa_build(const sre_program_t *prog, uint32_t max_states, const char **why)
+{
+    return sre_dfa_build2(prog, max_states, 0, why);
+}
+
+extern "C" sre_dfa_t *
+sre_dfa_build2(const sre_program_t *prog, uint32_t max_states, int chunk_twins, const char **why)
 {
     const char *dummy;
     if (why == NULL) why = &dummy;
@@ -286,6 +312,7 @@ sre_dfa_build(const sre_program_t *prog, uint32_t max_states, const char **why)
     b.sss.push_back(0);
     b.variant.push_back(0);
     b.prevk.push_back(0);
+    b.prevw.push_back(0);
     b.visited.push_back(std::vector<uint32_t>());
     b.fresh.push_back(std::vector<uint8_t>());
     {
@@ -320,7 +347,7 @@ sre_dfa_build(const sre_program_t *prog, uint32_t max_states, const char **why)
 
     /* ---- breadth-first exploration ---- */
     const uint32_t nsym = d->ncls + 1;
-    std::vector<uint32_t> unskip_of;
+    std::vector<uint32_t> unskip_of, rekind_of;
     for (uint32_t s = 0; s < b.lists.size(); s++) {
         if (b.lists.size() > max_states) {
             *why = "state cap exceeded";
@@ -331,10 +358,28 @@ sre_dfa_build(const sre_program_t *prog, uint32_t max_states, const char **why)
          * that it is explored like any other state */
         if (unskip_of.size() <= s) unskip_of.resize(s + 1, 0);
         unskip_of[s] = s;
-        if (prog->nleading && prog->lookahead_asserts == 0 && b.sss[s] == 2) {      /* (chunked streams of look-ahead
-                                                                                      programs stay on the exact VM) */
-            const std::vector<uint32_t> Lc = b.lists[s];
-            unskip_of[s] = b.intern(Lc, d->matched[s] != 0, 1, b.variant[s], 0, std::vector<uint64_t>(Lc.size(), 0));
+        if (prog->nleading && (prog->lookahead_asserts == 0 || chunk_twins) && b.sss[s] == 2) {
+            /* (look-ahead programs: only in the automaton of a chunked stream) */
+            const std::vector<uint32_t> Lc = b.lists[s], vis = b.visited[s];
+            const std::vector<uint8_t>  fr = b.fresh[s];
+            unskip_of[s] = b.intern_raw(Lc, d->matched[s] != 0, 1, b.variant[s], b.prevk[s], b.prevw[s] != 0, vis, fr);
+        }
+        if (chunk_twins) {
+            /* what the context's flags make of the byte in front (sre_dfa.h `rekind`): a splice at
+             * the first byte of a chunk runs at pos == 0, where ^ goes by seen_newline (:851-860)
+             * and a \b / \B thread it lists starts from seen_word == 0 (:866-880); a LISTED \b / \B
+             * thread kept its own seen_word, and at sp == input the context's flag is OR-ed to
+             * either (:472-473, 492) */
+            if (rekind_of.size() < 3 * (size_t) (s + 1)) rekind_of.resize(3 * (size_t) (s + 1), 0);
+            const std::vector<uint32_t> Lc = b.lists[s], vis = b.visited[s];
+            const std::vector<uint8_t>  fr = b.fresh[s];
+            for (unsigned f = 0; f < 3; f++) {
+                rekind_of[3 * (size_t) s + f] =
+                    b.holds_lookahead(Lc) ? b.intern_raw(Lc, d->matched[s] != 0, b.sss[s], b.variant[s],
+                                                         f == 1 ? PREV_NL : f == 2 ? PREV_WORD : 0,
+                                                         b.prevw[s] != 0 || f == 2, vis, fr)
+                                          : s;
+            }
         }
         const std::vector<uint32_t> L = b.lists[s];
         const bool                  was_matched = d->matched[s] != 0;
@@ -396,9 +441,10 @@ sre_dfa_build(const sre_program_t *prog, uint32_t max_states, const char **why)
             } else {
                 /* the list as a work queue: a look-ahead assertion that holds
                  * puts the closure of its continuation in front (:506-526) */
-                struct Item { uint32_t pc; uint8_t src; uint64_t early; };
+                struct Item { uint32_t pc; uint8_t src; uint64_t early; bool spliced; };
                 std::deque<Item> work;
-                for (size_t idx = 0; idx < L.size(); idx++) work.push_back(Item{L[idx], (uint8_t) idx, 0});
+                for (size_t idx = 0; idx < L.size(); idx++) work.push_back(Item{L[idx], (uint8_t) idx, 0, false});
+                const bool listed_word = b.prevw[s] != 0;
                 /* A look-ahead assertion inside an empty loop can make the splice
                  * re-mark and re-list in a cycle; the reference VM then duplicates
                  * threads without bound (and crashes).  No automaton for that. */
@@ -428,8 +474,12 @@ sre_dfa_build(const sre_program_t *prog, uint32_t max_states, const char **why)
                         switch (in.ch) {
                         case SRE_ASSERT_SMALL_Z: hold = eof; break;
                         case SRE_ASSERT_DOLLAR:  hold = eof || c == '\n'; break;
-                        case SRE_ASSERT_SMALL_B: hold = ((prev_here & PREV_WORD) != 0) != word_here; break;
-                        case SRE_ASSERT_BIG_B:   hold = ((prev_here & PREV_WORD) != 0) == word_here; break;
+                        case SRE_ASSERT_SMALL_B:
+                            hold = (it.spliced ? (prev_here & PREV_WORD) != 0 : listed_word) != word_here;
+                            break;
+                        case SRE_ASSERT_BIG_B:
+                            hold = (it.spliced ? (prev_here & PREV_WORD) != 0 : listed_word) == word_here;
+                            break;
                         default: break;
                         }
                         if (!hold) continue;
@@ -444,7 +494,7 @@ sre_dfa_build(const sre_program_t *prog, uint32_t max_states, const char **why)
                                   sp_pc, sp_par, sp_sav, &ds, &dr, false);
                         b.gen = g_new;                                /* ctx->tag++ */
                         for (size_t k = sp_pc.size(); k-- > 0;) {
-                            work.push_front(Item{sp_pc[k], it.src, it.early | sp_sav[k]});
+                            work.push_front(Item{sp_pc[k], it.src, it.early | sp_sav[k], true});
                         }
                         continue;
                     }
@@ -483,6 +533,10 @@ sre_dfa_build(const sre_program_t *prog, uint32_t max_states, const char **why)
         if (unskip_of[s] == 0 && s != 0) unskip_of[s] = s;     /* states interned by the last explored ones */
     }
     d->unskip = unskip_of;
+    if (chunk_twins) {
+        rekind_of.resize(3 * (size_t) d->nstates, 0);
+        d->rekind = rekind_of;
+    }
     d->seen_start = b.sss;
     d->nthreads.resize(d->nstates);
     d->list_off.resize(d->nstates + 1);

@@ -88,6 +88,14 @@ struct sre_dfa_s {
                                                 initial-state check (sre_vm_pike.c:304-306, then :256-273 again):
                                                 same list, seen_start == 1.  Identity elsewhere. */
 
+    std::vector<uint32_t>        rekind;     /* [nstates][3], only when built with chunk twins: a look-ahead
+                                                splice at the FIRST byte of a chunk does not see the byte in
+                                                front of it but the context's flags (\b / \B: seen_word,
+                                                sre_vm_pike.c:472-473; ^ / \A inside the splice: seen_newline,
+                                                :851-860) — the state a chunk boundary turns this one into when
+                                                the context says 0: neither, 1: seen_newline, 2: seen_word.
+                                                Same list, same marks; identity for lists without look-ahead. */
+
     const sre_dfa_trans_t &t(uint32_t s, uint32_t sym) const { return trans[(size_t) s * (ncls + 1) + sym]; }
 };
 typedef struct sre_dfa_s sre_dfa_t;
@@ -100,6 +108,9 @@ typedef struct sre_dfa_s sre_dfa_t;
 /* Build the automaton, or return NULL when the program is not admitted
  * (more than `max_states` states, too many capture slots).  `why` (optional) receives a static reason string. */
 sre_dfa_t *sre_dfa_build(const sre_program_t *prog, uint32_t max_states, const char **why);
+/* chunk_twins != 0: also the states a chunk boundary makes of look-ahead lists (`rekind`, and
+ * `unskip` for such programs): the automaton of a stream that is fed in chunks */
+sre_dfa_t *sre_dfa_build2(const sre_program_t *prog, uint32_t max_states, int chunk_twins, const char **why);
 void sre_dfa_free(sre_dfa_t *dfa);
 
 #ifdef __cplusplus

@@ -174,8 +174,35 @@ sre_hip_set_device(int ordinal)
     return e == hipSuccess ? 0 : sre_hip_fail("hipSetDevice", e);
 }
 
+static sre_hip_scanner_t *scanner_create(sre_pool_t *pool, sre_program_t *prog, int mode, int engine, int chunk_twins);
+
 extern "C" SRE_API sre_hip_scanner_t *
 sre_hip_scanner_create(sre_pool_t *pool, sre_program_t *prog, int mode, int engine)
+{
+    return scanner_create(pool, prog, mode, engine, 0);
+}
+
+/* The scanner of a stream that is fed in CHUNKS (sre_vm_api.cpp): table-driven only, its
+ * automaton built with the states a chunk boundary makes of look-ahead lists
+ * (sre_dfa.h `rekind`).  NULL when the program is not admitted. */
+extern "C" sre_hip_scanner_t *
+sre_hip_scanner_create_chunked(sre_pool_t *pool, sre_program_t *prog, int mode)
+{
+    if (sre_hip_ready() != 0) return NULL;
+    return scanner_create(pool, prog, mode, SRE_HIP_ENGINE_AUTO, 1);
+}
+
+/* the entry state of the next chunk: `state` is what the previous chunk's tail reported,
+ * flags = the context's 0: neither, 1: seen_newline, 2: seen_word */
+extern "C" uint32_t
+sre_hip_scanner_chunk_entry(sre_hip_scanner_t *sc, uint32_t state, int flags)
+{
+    if (sc->dfa == NULL || sc->dfa->rekind.empty() || state >= sc->dfa->nstates || flags < 0 || flags > 2) return state;
+    return sc->dfa->rekind[3 * (size_t) state + (size_t) flags];
+}
+
+static sre_hip_scanner_t *
+scanner_create(sre_pool_t *pool, sre_program_t *prog, int mode, int engine, int chunk_twins)
 {
     if (mode < SRE_HIP_THOMPSON || mode > SRE_HIP_PIKE_COUNT) return NULL;
     sre_hip_program_s *dp = sre_hip_program_get(prog);
@@ -196,7 +223,7 @@ sre_hip_scanner_create(sre_pool_t *pool, sre_program_t *prog, int mode, int engi
     if (engine == SRE_HIP_ENGINE_AUTO || engine == SRE_HIP_ENGINE_SCAN) {
         /* compile step: step automaton + device tables (independent of any input) */
         const char *why = NULL;
-        sc->dfa = sre_dfa_build(prog, 4 * SRE_SCAN_MAX_STATES, &why);
+        sc->dfa = sre_dfa_build2(prog, 4 * SRE_SCAN_MAX_STATES, chunk_twins, &why);
         if (sc->dfa) sc->tab = sre_scan_tables_build(prog, sc->dfa, mode, &why);
         if (sc->tab) {
             sc->engine = SRE_HIP_ENGINE_SCAN;
@@ -206,6 +233,10 @@ sre_hip_scanner_create(sre_pool_t *pool, sre_program_t *prog, int mode, int engi
             scanner_release(sc);
             return NULL;
         }
+    }
+    if (chunk_twins && sc->engine != SRE_HIP_ENGINE_SCAN) {
+        scanner_release(sc);
+        return NULL;
     }
     if (sc->engine == SRE_HIP_ENGINE_VM && (engine == SRE_HIP_ENGINE_AUTO || engine == SRE_HIP_ENGINE_NFA)) {
         /* the ordered-list automaton is too large (or was not asked for): the

@@ -31,6 +31,8 @@ extern "C" int sre_hip_scan_stream_chunk(sre_hip_scanner_t *sc, const void *d_bu
     int init_variant, int continues, uint32_t entry_state, int eof, int64_t base, sre_stream_ctx_t *d_ctx,
     sre_stream_result_t *d_res, const sre_stream_result_t *h_res, uint32_t ovec_slots, hipStream_t stream);
 extern "C" int sre_hip_scanner_streams(sre_hip_scanner_t *sc);
+extern "C" sre_hip_scanner_t *sre_hip_scanner_create_chunked(sre_pool_t *pool, sre_program_t *prog, int mode);
+extern "C" uint32_t sre_hip_scanner_chunk_entry(sre_hip_scanner_t *sc, uint32_t state, int flags);
 
 /* whole-buffer calls at least this long go through a throughput engine (the
  * table-driven scanner, else the NFA tier) when the program admits one: below it
@@ -232,6 +234,8 @@ struct sre_vm_pike_ctx_s {
     int            scanner_tried;
     sre_int_t     *rec;
     /* a search that runs chunk by chunk on the scanner (pike_stream_route) */
+    sre_hip_scanner_t *stream_scanner;  /* look-ahead programs: the chunked automaton's scanner */
+    int            stream_scanner_tried;
     int            stream_mode;     /* the device holds the carried list of a search under way */
     uint32_t       stream_state;    /* host shadow of the automaton state in front of the next byte */
 };
@@ -305,18 +309,29 @@ stage_input(DeviceStream *ds, const sre_char *input, size_t len)
  * pool, shared by every context of the program — exec() is synchronous, so one call
  * is in flight at a time.  NULL when only the exact VM takes the program. */
 static sre_hip_scanner_t *
-compat_scanner(sre_program_t *prog, int mode)
+compat_scanner(sre_program_t *prog, int mode, int chunked = 0)
 {
     sre_hip_program_s *dp = sre_hip_program_get(prog);
     if (dp == NULL) return NULL;
-    const int slot = mode == SRE_HIP_THOMPSON ? 0 : 1;
+    /* chunked: the automaton of a look-ahead program whose stream arrives in chunks (other
+     * programs: the ordinary one) */
+    const int slot = chunked ? 2 : mode == SRE_HIP_THOMPSON ? 0 : 1;
     if (!dp->compat_tried[slot]) {
         dp->compat_tried[slot] = 1;
-        sre_hip_scanner_t *sc = sre_hip_scanner_create(prog->pool, prog, mode, SRE_HIP_ENGINE_AUTO);
+        sre_hip_scanner_t *sc = chunked ? sre_hip_scanner_create_chunked(prog->pool, prog, mode)
+                                        : sre_hip_scanner_create(prog->pool, prog, mode, SRE_HIP_ENGINE_AUTO);
         if (sc && sre_hip_scanner_engine(sc) == SRE_HIP_ENGINE_VM) sc = NULL;
         dp->compat_scanner[slot] = sc;
     }
     return dp->compat_scanner[slot];
+}
+
+static unsigned long long g_route_counts[3];
+
+extern "C" SRE_API void
+sre_hip_compat_route_counts(unsigned long long out[3])
+{
+    for (int i = 0; i < 3; i++) out[i] = g_route_counts[i];
 }
 
 static int
@@ -422,27 +437,35 @@ pike_stream_route(sre_vm_pike_ctx_t *ctx, sre_char *input, size_t len, unsigned 
             if (ctx->rec == NULL) ctx->scanner = NULL;
         }
     }
-    /* (look-ahead programs: a splice at the first byte of a chunk sees the context's
-     * seen_newline / seen_word, not the byte in front, sre_vm_pike.c:276-285, 492 — the
-     * whole-buffer automaton does not model that; they stay on the exact VM) */
-    if (ctx->scanner == NULL || !sre_hip_scanner_streams(ctx->scanner)
-        || ctx->ovec_slots > SRE_STREAM_MAX_SLOTS || ctx->prog->lookahead_asserts)
-    {
-        return 0;
+    /* look-ahead programs: a splice at the first byte of a chunk does not see the byte in
+     * front of it but the context's seen_newline / seen_word (sre_vm_pike.c:276-285, 492):
+     * their chunks run on an automaton that has the states a chunk boundary makes of a list
+     * (sre_dfa.h `rekind`) */
+    sre_hip_scanner_t *sc = ctx->scanner;
+    if (ctx->prog->lookahead_asserts) {
+        if (!ctx->stream_scanner_tried) {
+            ctx->stream_scanner_tried = 1;
+            ctx->stream_scanner = compat_scanner(ctx->prog, SRE_HIP_PIKE_FIRST, 1);
+        }
+        sc = ctx->stream_scanner;
     }
+    if (sc == NULL || !sre_hip_scanner_streams(sc) || ctx->ovec_slots > SRE_STREAM_MAX_SLOTS) return 0;
     DeviceStream *ds = ctx->ds;
     size_t        skip = 0;
     int           variant = 0;
+    uint32_t      entry = 0;
     if (!ctx->stream_mode) {
-        /* a search starts with this chunk (prologue of :165-233) */
-        if (ctx->prog->lookahead_asserts && (ctx->empty_capture || ctx->processed_bytes != 0)) return 0;
+        /* a search starts with this chunk (prologue of :165-233): which initial list —
+         * SRE_DFA_INIT_*, as in pike_scan_route */
         if (ctx->empty_capture) {                           /* :179-196 */
             if (len == 0) return 0;
             skip = 1;
-            variant = input[0] == '\n' ? 1 : 2;
+            variant = input[0] == '\n' ? 1 : sre_isword(input[0]) ? 3 : 2;
         } else if (ctx->processed_bytes != 0) {
-            variant = ctx->seen_newline ? 1 : 2;
+            variant = ctx->seen_newline ? 1 : ctx->seen_word ? 3 : 2;
         }
+    } else {
+        entry = sre_hip_scanner_chunk_entry(sc, ctx->stream_state, ctx->seen_newline ? 1 : ctx->seen_word ? 2 : 0);
     }
     if (ds->d_sctx == NULL) {
         if (hipMalloc(reinterpret_cast<void **>(&ds->d_sctx), sizeof(sre_stream_ctx_t)) != hipSuccess
@@ -460,8 +483,8 @@ pike_stream_route(sre_vm_pike_ctx_t *ctx, sre_char *input, size_t len, unsigned 
     }
     if (stage_input(ds, input, len) != 0) return 0;
     ds->h_sres->rc = SRE_STREAM_PENDING;
-    if (sre_hip_scan_stream_chunk(ctx->scanner, static_cast<const uint8_t *>(ds->d_in) + skip, len - skip, variant,
-                                  ctx->stream_mode, ctx->stream_state, eof ? 1 : 0,
+    if (sre_hip_scan_stream_chunk(sc, static_cast<const uint8_t *>(ds->d_in) + skip, len - skip, variant,
+                                  ctx->stream_mode, entry, eof ? 1 : 0,
                                   (int64_t) ctx->processed_bytes + (int64_t) skip, ds->d_sctx, ds->d_sres, ds->h_sres,
                                   (uint32_t) ctx->ovec_slots, ds->stream) != 0)
     {
@@ -549,14 +572,20 @@ sre_vm_pike_exec(sre_vm_pike_ctx_t *ctx, sre_char *input, size_t len, unsigned e
         && ctx->ovec_slots >= 2)
     {
         sre_int_t rc;
-        if (pike_scan_route(ctx, input, len, &rc)) return rc;
+        if (pike_scan_route(ctx, input, len, &rc)) {
+            g_route_counts[0]++;
+            return rc;
+        }
     }
     /* a stream fed in chunks: the scanner carries the thread list from chunk to chunk */
     if (!ctx->vm_touched && ctx->ovec_slots >= 2
         && (ctx->stream_mode || (ctx->at_boundary && !eof && len >= SRE_COMPAT_STREAM_MIN_BYTES)))
     {
         sre_int_t rc;
-        if (pike_stream_route(ctx, input, len, eof, pending_matched, &rc)) return rc;
+        if (pike_stream_route(ctx, input, len, eof, pending_matched, &rc)) {
+            g_route_counts[1]++;
+            return rc;
+        }
         if (ctx->stream_mode) return SRE_ERROR;     /* (not reached: a stream in scanner mode stays there) */
     }
     if (!ctx->vm_touched) {
@@ -571,6 +600,7 @@ sre_vm_pike_exec(sre_vm_pike_ctx_t *ctx, sre_char *input, size_t len, unsigned e
         }
     }
 
+    g_route_counts[2]++;
     if (device_stream_exec(ds, input, len, eof, pending_matched ? 1u : 0u, ctx->ovec_slots,
                            sre_launch_pike_exec) != 0)
     {
@@ -684,7 +714,10 @@ sre_vm_thompson_exec(sre_vm_thompson_ctx_t *ctx, sre_char *input, size_t len, un
     if (ctx->ds->failed) return SRE_ERROR;
     if (!ctx->finished && (ctx->stream_mode || (!ctx->started && !eof && len >= SRE_COMPAT_STREAM_MIN_BYTES))) {
         sre_int_t rc;
-        if (thompson_stream_route(ctx, input, len, eof, &rc)) return rc;
+        if (thompson_stream_route(ctx, input, len, eof, &rc)) {
+            g_route_counts[1]++;
+            return rc;
+        }
         if (ctx->stream_mode) return SRE_ERROR;
     }
     if (!ctx->started && eof && len >= SRE_COMPAT_SCAN_MIN_BYTES) {

@@ -455,9 +455,13 @@ def test_compat_api_chunked_streams_take_the_scanner(gpu):
     cfg3 = [b"a", b"ab", b"c", b"a(bc)", b"e(f)", b"gh", b"A", b"b", b"BLAH", rb"\s+", b"abcd", b"bc"]
     zoo = [[rb"[a-z]+@[a-z]+\.[a-z]+"], [rb"([a-z]+)://([^/ ]+)(/[^ ?]*)?(\?[^ ]*)?"], [rb"a?a?a?aaa"],
            [rb"(a+)(b+)?"], [rb"(?:a.*b|a)"], [rb"x(.*)y(.*)z"], [rb"(a|ab)(c|bcd)(d*)"], cfg3,
-           [rb"\Aab|\n^b"], [rb"(x+x+)+y"], [rb"^b+"], [rb"q(\w+)@"]]
+           [rb"\Aab|\n^b"], [rb"(x+x+)+y"], [rb"^b+"], [rb"q(\w+)@"],
+           # look-ahead assertions: a splice at the first byte of a chunk goes by the context's
+           # seen_newline / seen_word, not by the byte in front (sre_vm_pike.c:276-285, 492)
+           [rb"\bab\b"], [rb"(a+)$"], [rb"(\w+)\b(.)"], [rb"c\B(.)"], [rb"^(\w+) \b"], [rb"x*\b y"]]
     tails = [b"@abc.cc ", b" abc://abc.cc/ab/c?a=b ", b"aaabbccb", b" a\nca", b"xabyabz", b"q"]
     n = 0
+    on_vm = set()
     for pats in zoo:
         with S.Pool() as pool:
             re = S.parse(pool, pats)
@@ -472,11 +476,23 @@ def test_compat_api_chunked_streams_take_the_scanner(gpu):
                 first = rng.choice([4096, 5000, 8192, 30000])
                 sizes = [first] + [rng.choice([0, 1, 7, 64, 1000, 4096, 10000, 33333]) for _ in range(rng.randrange(0, 9))]
                 want = _feed(ora.pike(prog, re.ncaps), data, sizes, nov)
+                before = S.compat_route_counts()
                 got = _feed(eng.pike(prog, re.ncaps), data, sizes, nov)
+                after = S.compat_route_counts()
                 n += 1
                 assert got == want, (pats, len(data), sizes, got[-3:], want[-3:])
+                # ... and every one of these calls ran as a chunk on the table-driven scanner
+                # (or, for a program whose chunks it does not take, every one on the exact VM)
+                if after[2] != before[2]:
+                    assert after[1] == before[1], (pats, before, after)
+                    if len(got) > 1:
+                        on_vm.add(tuple(pats))
+                else:
+                    # (a subject that fits the first chunk is one whole-buffer call)
+                    assert (after[0] - before[0]) + (after[1] - before[1]) == len(got), (pats, before, after, len(got))
                 eng.recycle()
-    assert n == 72
+    assert n == 6 * len(zoo)
+    assert not on_vm, on_vm     # no multi-chunk stream of this zoo fell back to the exact VM
     # sre_vm_thompson_exec in chunks: the list travels as the automaton state alone
     n = 0
     for pats in zoo:
@@ -509,7 +525,7 @@ def test_compat_api_chunked_streams_take_the_scanner(gpu):
                 n += 1
                 assert res[0] == res[1], (pats, len(data), sizes, res)
                 eng.recycle()
-    assert n == 48
+    assert n == 4 * len(zoo)
     # chunks of the size that travels through the pinned staging buffer (64 KiB .. 2 MiB), a
     # different content every time: the buffer is reused from call to call
     with S.Pool() as pool:
