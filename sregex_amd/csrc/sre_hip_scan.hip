@@ -325,7 +325,9 @@ __device__ void slow_run(Walk &w, int64_t p, int64_t p_to, bool warm, uint32_t w
                 w.lm_astate = w.ev_astate;
             }
         }
-        w.st = tr.next;
+        /* Thompson (sre_vm_thompson.c:233-235) answers at the first MATCH thread it meets: the
+         * search ends with its first event */
+        w.st = (tr.kind && T.mode == 0 && !warm) ? 0u : tr.next;
         if (w.st != 0) {
             p++;
             continue;
@@ -2153,15 +2155,37 @@ sre_k_stream_tail(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
     if (T.mode == 0) {
         /* Thompson (sre_vm_thompson.c:63-270): SRE_OK at the first MATCH thread met, else
          * SRE_DECLINED at eof / SRE_AGAIN with the list (= the state) carried on */
-        if (st.ev_pos >= 0) {
+        /* A MATCH thread is met when the position it is listed at is RUN: one listed by the
+         * closure behind the chunk's last byte waits for the next call that runs a position
+         * (a byte, or the extra iteration at eof; :88, :265-269) */
+        const bool carried_match = continues && ctx->has_pending != 0;
+        bool       match_now = false, match_waits = false;
+        if (carried_match) {
+            match_now = n > 0 || eof;
+            match_waits = !match_now;
+        } else if (st.ev_pos >= 0) {
+            const uint32_t kind = T.trans[(size_t) st.ev_state * (T.ncls + 1) + st.ev_sym].kind;
+            const bool     listed_behind = (kind == EV_DONE || kind == SRE_DEV_EV_DONE_EMPTY);
+            match_waits = listed_behind && st.ev_pos == n - 1 && !eof;
+            match_now = !match_waits;
+        }
+        if (match_now) {
             rc_out = 0;
             ctx->state = 0;
+            ctx->has_pending = 0;
+        } else if (match_waits) {
+            ctx->has_pending = 1;
+            ctx->state = 1;                 /* (any live state: the next call does not get to use it) */
+            res->next_state = 1;
+            rc_out = -2;                    /* SRE_AGAIN */
         } else if (eof) {
             rc_out = RC_DECLINED;
             ctx->state = 0;
+            ctx->has_pending = 0;
         } else {
             const uint32_t sF = sum[nseg - 1].s_out & ~SRE_STATE_SKIP;
             ctx->state = tabp->unskip[sF];
+            ctx->has_pending = 0;
             res->next_state = ctx->state;
             rc_out = -2;                   /* SRE_AGAIN */
         }

@@ -526,6 +526,37 @@ def test_compat_api_chunked_streams_take_the_scanner(gpu):
                 assert res[0] == res[1], (pats, len(data), sizes, res)
                 eng.recycle()
     assert n == 4 * len(zoo)
+    # random patterns (all constructs, all assertions) over sparse subjects — filler bytes with
+    # short bursts of the patterns' alphabet, so that searches live across several chunks
+    taken = 0
+    for _ in range(60):
+        pats = [harness.random_regex(rng)]
+        with S.Pool() as pool:
+            re = S.parse(pool, pats)
+            prog = S.compile(pool, re)
+            nov = 2 * (re.ncaps + 1)
+            try:
+                S.Scanner(pool, prog, S.HIP_PIKE_FIRST, S.ENGINE_SCAN)
+            except RuntimeError:
+                if prog_has_lookahead(pats):
+                    continue        # the reference VM itself may diverge on these
+            for trial in range(2):
+                filler = rng.choice([b"#", b"c", b" ", b"\n"])
+                data = bytearray(filler * rng.choice([9000, 30000]))
+                for _ in range(rng.randrange(0, 12)):
+                    at = rng.randrange(0, len(data))
+                    burst = bytes(rng.choice(b"abcx \n_.") for _ in range(rng.randrange(1, 6)))
+                    data[at:at + len(burst)] = burst
+                data = bytes(data[:rng.choice([9000, 30000])])
+                sizes = [rng.choice([4096, 4097, 6000])] + [rng.choice([0, 1, 2, 64, 1000, 4096, 5000]) for _ in range(rng.randrange(0, 7))]
+                want = _feed(ora.pike(prog, re.ncaps), data, sizes, nov)
+                before = S.compat_route_counts()
+                got = _feed(eng.pike(prog, re.ncaps), data, sizes, nov)
+                after = S.compat_route_counts()
+                assert got == want, (pats, data.hex() if len(data) < 200 else len(data), sizes, got[-3:], want[-3:])
+                taken += after[1] - before[1]
+                eng.recycle()
+    assert taken > 100, taken
     # chunks of the size that travels through the pinned staging buffer (64 KiB .. 2 MiB), a
     # different content every time: the buffer is reused from call to call
     with S.Pool() as pool:
