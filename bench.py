@@ -224,10 +224,11 @@ def measure(spec, S, torch, res, hstream, stream, steps, warmup, barrier):
         raise RuntimeError("no throughput engine admits this program: the exact VM runs at MB/s, not benchmarked at this size")
     side = res.side_stream()
     hs = [hstream, ctypes.c_void_p(side.cuda_stream)]
-    if len(lens) > 1 or os.environ.get("SRE_BENCH_ONE_STREAM"):
-        # many streams per call: the tail kernels (one capture walker per stream) are heavy
-        # enough to slow the overlapped scan down by more than they hide (measured on one
-        # box, 128 x 64 MiB: 1.79 ms per step on two streams, 1.69 on one) — one stream
+    if os.environ.get("SRE_BENCH_ONE_STREAM"):
+        # (experiment knob.  With 128 streams per call the overlap used to cost more than it hid:
+        # the capture kernel walked its streams as 64 divergent lanes of one wave, 51 us; one
+        # workgroup per stream since — same box, 128 x 64 MiB: 1.68 ms per step on one HIP
+        # stream, 1.64-1.66 on two; profiles/r02_experiments.txt)
         hs[1] = hstream
 
     def run(nsteps):

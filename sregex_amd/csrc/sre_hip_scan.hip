@@ -1984,7 +1984,7 @@ stage_walk_tables(const sre_scan_tables_t *__restrict__ tabp, uint8_t *lds, sre_
     }
 }
 
-/* NT == 64: one lane per stream behind sre_launch_verify.  NT == 1024: ONE stream of at most
+/* NT == 64: one wave per stream behind sre_launch_verify.  NT == 1024: ONE stream of at most
  * SRE_VERIFY_ONE_SEGS segments, FIRST / Thompson — the workgroup runs the chain check itself
  * (verify_one_stream), then lane 0 walks: a small buffer costs two launches, not six. */
 template <int NT>
@@ -2004,8 +2004,11 @@ sre_k_captures(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
         __shared__ sre_stream_status_t sh_st;
         verify_one_stream<NT>(Ts, sum, geom_first(G, 1), status, &sh_acc, &sh_st);
     }
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= G.nstreams) return;
+    /* one WORKGROUP per stream, lane 0 walks: the walks of a batch run side by side on
+     * different CUs instead of as 64 divergent lanes of one wave (128 streams: 51 us -> see
+     * profiles/r02_experiments.txt) */
+    const uint32_t s = blockIdx.x;
+    if (s >= G.nstreams || threadIdx.x != 0) return;
     if (use_maps && !status[s].need_maps) return;   /* second pass: flagged streams only */
     const sre_scan_tables_t   &T = Ts;
     const sre_stream_status_t  st = status[s];
@@ -2461,7 +2464,7 @@ sre_launch_captures(const sre_scan_tables_t *d_tab, sre_scan_tables_t h_tab, sre
     if (verify && (geom.nstreams != 1 || geom.nsegs > SRE_VERIFY_ONE_SEGS || h_tab.mode == SRE_HIP_PIKE_COUNT || use_maps)) {
         return hipErrorInvalidValue;
     }
-    const uint32_t block = verify ? 1024 : 64, grid = (geom.nstreams + block - 1) / block;
+    const uint32_t block = verify ? 1024 : 64, grid = geom.nstreams;
     const size_t   shmem = (size_t) h_tab.fast_bytes + 256
                          + ((size_t) h_tab.nstates * (h_tab.ncls + 1) + SRE_SCAN_NINIT) * sizeof(sre_dev_trans_t)
                          + (size_t) h_tab.lin_total * 9 + ((size_t) h_tab.nstates + 1 + h_tab.list_total) * 4 + 16;

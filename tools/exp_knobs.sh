@@ -14,14 +14,8 @@ d=json.loads(sys.stdin.read()); r=d['roofline']
 print('step_ms %.4f kernel_ms %.4f frac %.4f kfrac %.4f seg %s' % (r['step_ms'], r['kernel_ms'], r['frac'], r['kernel_frac'], d['config']['segment_bytes']))")
   echo "$CFG $EXTRA | $name | $out"
 }
-P2=$PWD/sregex_amd/lib_p2/libsregex.so
-for CFG in cfg2 cfg2m cfg4 cfg3 dense; do
-EXTRA=
-one "one stage in flight (default)" A=1
-one "two stages in flight" SREGEX_AMD_LIB=$P2
-one "one stage in flight again" A=1
-one "two stages in flight again" SREGEX_AMD_LIB=$P2
-done
 CFG=cfg2 EXTRA=--many-streams
-one "one stage in flight (default)" A=1
-one "two stages in flight" SREGEX_AMD_LIB=$P2
+one "one wave per stream in the capture kernel, one HIP stream" A=1
+one "... two HIP streams" SRE_BENCH_TWO_STREAMS=1
+one "one HIP stream again" A=1
+one "two HIP streams again" SRE_BENCH_TWO_STREAMS=1
