@@ -223,19 +223,26 @@ def measure(spec, S, torch, res, hstream, stream, steps, warmup, barrier):
         pool.destroy()
         raise RuntimeError("no throughput engine admits this program: the exact VM runs at MB/s, not benchmarked at this size")
     side = res.side_stream()
-    hs = [hstream, ctypes.c_void_p(side.cuda_stream)]
-    if os.environ.get("SRE_BENCH_ONE_STREAM"):
-        # (experiment knob.  With 128 streams per call the overlap used to cost more than it hid:
-        # the capture kernel walked its streams as 64 divergent lanes of one wave, 51 us; one
-        # workgroup per stream since — same box, 128 x 64 MiB: 1.68 ms per step on one HIP
-        # stream, 1.64-1.66 on two; profiles/r02_experiments.txt)
-        hs[1] = hstream
+    # two scanners take turns, each on its own HIP stream, the scan kernels chained by an event
+    # (sre_hip_scanner_order_after_scan): what a step queues behind its scan (chain check,
+    # capture walk, the copy of the records) overlaps the next step's scan.
+    # SRE_BENCH_STREAMS (experiment knob): "tail" = every scan on ONE stream, the tails on a
+    # second (sre_hip_scanner_set_tail_stream) — no gap between two scans, but the next scan
+    # then takes the chip before the tail kernels get a slot and the step's results wait for
+    # it (same box: configs[1] 0.860 vs 0.846 ms, 128 streams 2.25 vs 1.64); "one" = no overlap.
+    scheme = os.environ.get("SRE_BENCH_STREAMS", "two")
+    hs = [hstream, hstream]
+    if scheme == "tail":
+        for x in scs:
+            x.set_tail_stream(ctypes.c_void_p(side.cuda_stream))
+    elif scheme != "one":
+        hs[1] = ctypes.c_void_p(side.cuda_stream)
 
     def run(nsteps):
         recs, kms, inflight = None, [], None
         for i in range(nsteps):
             cur = scs[i % 2]
-            if inflight is not None:
+            if inflight is not None and hs[0] is not hs[1]:
                 inflight.order_after_scan(hs[i % 2])    # scan kernels one after the other, tails overlapped
             cur.enqueue(ptrs, lens, hs[i % 2])
             if inflight is not None:

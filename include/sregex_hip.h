@@ -101,6 +101,12 @@ SRE_API const char *sre_hip_scanner_kernel_name(sre_hip_scanner_t *sc);
  * -1 when the exact VM engine ran.  Waits for the kernel. */
 SRE_API double sre_hip_scanner_last_kernel_ms(sre_hip_scanner_t *sc);
 
+/* Two scanners taking turns on ONE stream: with a tail stream set, everything a call queues
+ * behind its scan kernel (chain check, capture walk, the copy of the records) goes to that
+ * stream, ordered after the scan by an event; the next call's scan kernel then follows
+ * on the scan stream without a gap.  NULL: everything on the stream of the call. */
+SRE_API int sre_hip_scanner_set_tail_stream(sre_hip_scanner_t *sc, void *hip_stream);
+
 /*
  * Make `hip_stream` wait until the dominant (segment-scan) kernel of sc's last enqueued
  * scan has finished — not for the small kernels and copies behind it.  A driver that

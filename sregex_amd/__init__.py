@@ -62,6 +62,7 @@ API = {
     "sre_hip_scanner_last_lineage_passes": (ctypes.c_int, [_vp]),
     "sre_hip_scanner_last_exact_passes": (ctypes.c_int, [_vp]),
     "sre_hip_compat_route_counts": (None, [ctypes.POINTER(ctypes.c_ulonglong)]),
+    "sre_hip_scanner_set_tail_stream": (ctypes.c_int, [_vp, _vp]),
     "sre_hip_scanner_class_bits": (ctypes.c_int, [_vp]),
     "sre_hip_scanner_kernel_name": (ctypes.c_char_p, [_vp]),
     "sre_hip_scanner_last_kernel_ms": (ctypes.c_double, [_vp]),
@@ -318,6 +319,11 @@ class Scanner:
     @property
     def last_fixups(self):
         return self.lib.sre_hip_scanner_last_fixups(self.h)
+
+    def set_tail_stream(self, hip_stream):
+        """queue what follows the scan kernel of every later call on hip_stream (see sregex_hip.h)"""
+        if self.lib.sre_hip_scanner_set_tail_stream(self.h, hip_stream) != 0:
+            raise RuntimeError("sre_hip_scanner_set_tail_stream failed")
 
     def order_after_scan(self, hip_stream):
         """make hip_stream wait for this scanner's last scan kernel (see sregex_hip.h)"""

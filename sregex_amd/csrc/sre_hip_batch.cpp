@@ -65,6 +65,8 @@ struct sre_hip_scanner_s {
     int                       lineage_passes;   /* of the last scan (diagnostics) */
     uint32_t                  next_init_variant;    /* compat path: a re-armed context's search */
     int                       blocks_per_cu;
+    hipStream_t               tail_stream;      /* sre_hip_scanner_set_tail_stream */
+    bool                      tail_stream_set;
     uint32_t                  geom_one;         /* SRE_GEOM_ONE when the batch in flight is one stream in the kernel arguments */
     int                       fixup_rounds;     /* of the last scan (diagnostics) */
     hipEvent_t                ev0, ev1;         /* around the dominant scan kernel */
@@ -343,6 +345,14 @@ sre_hip_scanner_order_after_scan(sre_hip_scanner_t *sc, void *hip_stream)
     return e == hipSuccess ? 0 : sre_hip_fail("hipStreamWaitEvent", e);
 }
 
+extern "C" SRE_API int
+sre_hip_scanner_set_tail_stream(sre_hip_scanner_t *sc, void *hip_stream)
+{
+    sc->tail_stream = static_cast<hipStream_t>(hip_stream);
+    sc->tail_stream_set = hip_stream != NULL;
+    return 0;
+}
+
 extern "C" SRE_API size_t
 sre_hip_scanner_last_segment_bytes(sre_hip_scanner_t *sc)
 {
@@ -586,6 +596,10 @@ sre_hip_scan_enqueue(sre_hip_scanner_t *sc, const void *const *d_streams, const 
         SRE_HIP_TRY(sre_launch_nfa_scan(sc->mode, sc->ntab, sc->geom, sc->d_nsum, NULL, NULL, NULL, stream));
         SRE_HIP_TRY(hipEventRecord(sc->ev1, stream));
         sc->ev_valid = 1;
+        if (sc->tail_stream_set && sc->tail_stream != stream) {
+            SRE_HIP_TRY(hipStreamWaitEvent(sc->tail_stream, sc->ev1, 0));
+            stream = sc->tail_stream;
+        }
         if (nfa_finish(sc, NULL, stream) != 0) return -1;
     } else {
         if (scan_geometry(sc, nstreams) != 0) return -1;
@@ -603,6 +617,12 @@ sre_hip_scan_enqueue(sre_hip_scanner_t *sc, const void *const *d_streams, const 
         SRE_HIP_TRY(sre_launch_scan(sc->tab->d_tab, sc->tab->h, sc->geom, sc->d_sum, NULL, NULL, stream));
         SRE_HIP_TRY(hipEventRecord(sc->ev1, stream));
         sc->ev_valid = 1;
+        /* everything behind the scan kernel on the tail stream, if one is set: the caller's
+         * next scan follows this one on `stream` with no gap while these small kernels run */
+        if (sc->tail_stream_set && sc->tail_stream != stream) {
+            SRE_HIP_TRY(hipStreamWaitEvent(sc->tail_stream, sc->ev1, 0));
+            stream = sc->tail_stream;
+        }
         {
             /* one small buffer: chain check and captures in one workgroup */
             const int fused = sc->geom_one && sc->geom.nsegs <= SRE_VERIFY_ONE_SEGS && sc->mode != SRE_HIP_PIKE_COUNT;

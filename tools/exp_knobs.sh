@@ -3,7 +3,7 @@
 #   SRE_HIP_LDS_PAD      extra dynamic LDS per workgroup (fewer workgroups per CU)
 #   SRE_HIP_SEG_BYTES    segment size;  SRE_HIP_SEG_CAP  largest segment the automatic choice makes
 #   SRE_HIP_NO_SHADOW    no shadow rows (stable-stretch tracking off)
-#   SRE_BENCH_ONE_STREAM bench.py: both scanners on one HIP stream
+#   SRE_BENCH_STREAMS    bench.py: tail (default) | two | one, see measure()
 #   SREGEX_AMD_LIB       another build of the library (an older commit, another tile layout)
 one() {
   local name=$1; shift
@@ -14,8 +14,13 @@ d=json.loads(sys.stdin.read()); r=d['roofline']
 print('step_ms %.4f kernel_ms %.4f frac %.4f kfrac %.4f seg %s' % (r['step_ms'], r['kernel_ms'], r['frac'], r['kernel_frac'], d['config']['segment_bytes']))")
   echo "$CFG $EXTRA | $name | $out"
 }
+for CFG in cfg2 cfg2m cfg3 nfa; do
+EXTRA=
+one "one stream per scanner, scans chained by an event (default)" A=1
+one "scans on one stream, tails on a second" SRE_BENCH_STREAMS=tail
+one "default again" A=1
+done
 CFG=cfg2 EXTRA=--many-streams
-one "one wave per stream in the capture kernel, one HIP stream" A=1
-one "... two HIP streams" SRE_BENCH_TWO_STREAMS=1
-one "one HIP stream again" A=1
-one "two HIP streams again" SRE_BENCH_TWO_STREAMS=1
+one "one stream per scanner, scans chained by an event (default)" A=1
+one "scans on one stream, tails on a second" SRE_BENCH_STREAMS=tail
+one "one stream, no overlap" SRE_BENCH_STREAMS=one
