@@ -184,10 +184,12 @@ class Resident:
         self.torch, self.lib, self.hstream, self.bufs = torch, lib, hstream, []
         self._side = None
 
-    def side_stream(self):
+    def side_stream(self, k=0):
         if self._side is None:
-            self._side = self.torch.cuda.Stream()
-        return self._side
+            self._side = {}
+        if k not in self._side:
+            self._side[k] = self.torch.cuda.Stream()
+        return self._side[k]
 
     def fill(self, lens, tails, block=0):
         need = [max(n, 16) for n in lens]
@@ -217,7 +219,8 @@ def measure(spec, S, torch, res, hstream, stream, steps, warmup, barrier):
     # results of step i-1 are collected (they travel to pinned memory as part of the
     # queued work), and the small kernels behind a scan (chain check, captures, the copy
     # of the records) overlap with the next scan instead of sitting between two of them
-    scs = [S.Scanner(pool, prog, spec["mode"], S.ENGINE_AUTO) for _ in range(2)]
+    depth = max(2, int(os.environ.get("SRE_BENCH_DEPTH", "2")))       # scanners (steps) in flight
+    scs = [S.Scanner(pool, prog, spec["mode"], S.ENGINE_AUTO) for _ in range(depth)]
     sc = scs[0]
     if sc.engine == S.ENGINE_VM and sum(lens) > (64 << 20):
         pool.destroy()
@@ -231,31 +234,34 @@ def measure(spec, S, torch, res, hstream, stream, steps, warmup, barrier):
     # then takes the chip before the tail kernels get a slot and the step's results wait for
     # it (same box: configs[1] 0.860 vs 0.846 ms, 128 streams 2.25 vs 1.64); "one" = no overlap.
     scheme = os.environ.get("SRE_BENCH_STREAMS", "two")
-    hs = [hstream, hstream]
+    hs = [hstream] * depth
     if scheme == "tail":
         for x in scs:
             x.set_tail_stream(ctypes.c_void_p(side.cuda_stream))
     elif scheme != "one":
-        hs[1] = ctypes.c_void_p(side.cuda_stream)
+        hs = [hstream] + [ctypes.c_void_p(res.side_stream(k).cuda_stream) for k in range(depth - 1)]
 
     def run(nsteps):
-        recs, kms, inflight = None, [], None
+        # step i: scanner and stream i mod depth; its scan kernel follows step i - 1's (event),
+        # the results of step i - depth + 1 are collected once it is queued
+        recs, kms, inflight = None, [], []
         for i in range(nsteps):
-            cur = scs[i % 2]
-            if inflight is not None and hs[0] is not hs[1]:
-                inflight.order_after_scan(hs[i % 2])    # scan kernels one after the other, tails overlapped
-            cur.enqueue(ptrs, lens, hs[i % 2])
-            if inflight is not None:
-                recs = inflight.results()
-                kms.append(inflight.last_kernel_ms)
-            inflight = cur
-        if inflight is not None:
-            recs = inflight.results()
-            kms.append(inflight.last_kernel_ms)
+            cur = scs[i % depth]
+            if inflight and hs[0] is not hs[1]:
+                inflight[-1].order_after_scan(hs[i % depth])    # scan kernels one after the other, tails overlapped
+            cur.enqueue(ptrs, lens, hs[i % depth])
+            inflight.append(cur)
+            if len(inflight) == depth:
+                done = inflight.pop(0)
+                recs = done.results()
+                kms.append(done.last_kernel_ms)
+        for done in inflight:
+            recs = done.results()
+            kms.append(done.last_kernel_ms)
         return recs, kms
 
     torch.cuda.synchronize()            # the input was generated on the main stream
-    recs, _ = run(max(warmup, 2))       # both scanners allocate their buffers outside the timed region
+    recs, _ = run(max(warmup, depth))   # every scanner allocates its buffers outside the timed region
     spec["check"](recs)
     barrier()
     t0 = time.perf_counter()

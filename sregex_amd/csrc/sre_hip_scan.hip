@@ -457,6 +457,14 @@ byte_x4(uint32_t v, uint32_t sh)
     return r;
 }
 
+/* the kernels behind a scan (chain check, capture walk) are a few small waves that usually run
+ * while the NEXT scan holds the chip: first in line at the issue arbiter */
+#ifdef SRE_NO_TAIL_PRIO
+#define SRE_TAIL_PRIO() ((void) 0)
+#else
+#define SRE_TAIL_PRIO() __builtin_amdgcn_s_setprio(3)
+#endif
+
 #ifndef SRE_SCAN_PREFETCH
 #define SRE_SCAN_PREFETCH 1         /* stages of HBM loads in flight per lane (1 or 2), see sre_k_scan */
 #endif
@@ -1122,6 +1130,7 @@ __global__ __launch_bounds__(256) void
 sre_k_verify_a(sre_scan_geom_t G, const sre_seg_summary_t *__restrict__ sum, VerifyAcc *__restrict__ acc,
                int mode)
 {
+    SRE_TAIL_PRIO();
     const uint64_t g = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= G.nsegs) return;
     const uint32_t s = stream_of(G, g);
@@ -1147,6 +1156,7 @@ sre_k_verify_a(sre_scan_geom_t G, const sre_seg_summary_t *__restrict__ sum, Ver
 __global__ __launch_bounds__(1024) void
 sre_k_verify_b(sre_scan_geom_t G, const sre_seg_summary_t *__restrict__ sum, VerifyAcc *__restrict__ acc)
 {
+    SRE_TAIL_PRIO();
     __shared__ unsigned long long sh_count, sh_ev, sh_sp;
     const uint64_t g0 = (uint64_t) blockIdx.x * blockDim.x;
     const uint64_t g = g0 + threadIdx.x;
@@ -1210,6 +1220,7 @@ sre_k_verify_b(sre_scan_geom_t G, const sre_seg_summary_t *__restrict__ sum, Ver
 __global__ __launch_bounds__(1024) void
 sre_k_verify_b2(sre_scan_geom_t G, const sre_seg_summary_t *__restrict__ sum, VerifyAcc *__restrict__ acc)
 {
+    SRE_TAIL_PRIO();
     __shared__ unsigned long long sh_max, sh_max_end;
     const uint64_t g0 = (uint64_t) blockIdx.x * blockDim.x;
     const uint64_t g = g0 + threadIdx.x;
@@ -1322,6 +1333,7 @@ __global__ void
 sre_k_verify_c(sre_scan_tables_t T, sre_scan_geom_t G, const sre_seg_summary_t *__restrict__ sum,
                VerifyAcc *__restrict__ accs, sre_stream_status_t *__restrict__ status)
 {
+    SRE_TAIL_PRIO();
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= G.nstreams) return;
     /* take this stream's accumulator and leave it reset for the next pass */
@@ -1996,6 +2008,7 @@ sre_k_captures(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
                const sre_seg_lineage_t *__restrict__ maps,
                const sre_seg_lineage_t *__restrict__ blocks, int use_maps)
 {
+    SRE_TAIL_PRIO();
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     __shared__ sre_scan_tables_t Ts;
     stage_walk_tables(tabp, lds, &Ts);
@@ -2129,6 +2142,7 @@ sre_k_stream_tail(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
                   uint16_t *__restrict__ scratch, sre_stream_ctx_t *__restrict__ ctx,
                   sre_stream_result_t *__restrict__ res, int64_t base, int eof, uint32_t ovec_slots, int verify)
 {
+    SRE_TAIL_PRIO();
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     __shared__ sre_scan_tables_t Ts;
     __shared__ VerifyAcc sh_acc;

@@ -14,13 +14,13 @@ d=json.loads(sys.stdin.read()); r=d['roofline']
 print('step_ms %.4f kernel_ms %.4f frac %.4f kfrac %.4f seg %s' % (r['step_ms'], r['kernel_ms'], r['frac'], r['kernel_frac'], d['config']['segment_bytes']))")
   echo "$CFG $EXTRA | $name | $out"
 }
-for CFG in cfg2 cfg2m cfg3 nfa; do
+OLD=$PWD/sregex_amd/lib_old/libsregex.so
+for CFG in cfg2m cfg2 cfg4; do
 EXTRA=
-one "one stream per scanner, scans chained by an event (default)" A=1
-one "scans on one stream, tails on a second" SRE_BENCH_STREAMS=tail
-one "default again" A=1
+one "tail kernels at wave priority 3" A=1
+one "no priority (previous build)" SREGEX_AMD_LIB=$OLD
+one "tail kernels at wave priority 3 again" A=1
 done
 CFG=cfg2 EXTRA=--many-streams
-one "one stream per scanner, scans chained by an event (default)" A=1
-one "scans on one stream, tails on a second" SRE_BENCH_STREAMS=tail
-one "one stream, no overlap" SRE_BENCH_STREAMS=one
+one "tail kernels at wave priority 3" A=1
+one "no priority (previous build)" SREGEX_AMD_LIB=$OLD
