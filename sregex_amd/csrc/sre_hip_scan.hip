@@ -1488,6 +1488,8 @@ first_valid_segment(const sre_seg_summary_t *sum, int64_t sp, int64_t seg_bytes,
  * a thread re-seeded by the leading-byte skip, at the start of the search, or
  * when every slot is known.
  */
+/* (every method is force-inlined: the walker is one lane, and a Tracer whose address escapes into
+ * a call lives in scratch memory — a microsecond per field access) */
 struct Tracer {
     const sre_scan_tables_t *T;         /* cls / trans / fast point into LDS */
     const sre_seg_summary_t *sum;       /* this stream's summaries */
@@ -1497,21 +1499,62 @@ struct Tracer {
     int64_t                  apos;      /* anchor: state `astate` holds before position apos (-1 none) */
     uint32_t                 astate;
     uint16_t                *ck;        /* checkpoint states of the loaded segment, every 64 bytes */
-    uint16_t                *trace;     /* states before each position of the loaded 64-byte block */
+    __attribute__((address_space(3))) uint16_t *trace;  /* states before each position of the loaded 64-byte block (LDS) */
+    __attribute__((address_space(3))) uint8_t  *syms;   /* ... and the byte classes at them: a walk step reads no global memory */
     int64_t                  seg_lo, seg_hi;    /* loaded segment: [seg_lo, seg_hi], -1 none */
     int64_t                  blk_lo, blk_hi;
     int64_t                  valid_from;        /* see entry_state */
     bool                     use_stable;        /* the summaries' stable stretches may be used (FIRST) */
     uint32_t                 seg_entry;         /* state before seg_lo */
+    int64_t                  su_k = -1, su_lo = 0, su_hi = 0;   /* segment [su_lo, su_hi) whose stable prefix is cached below */
+    uint32_t                 su_until = 0, su_s_in = 0;
 
-    __device__ inline uint32_t step(uint32_t st, int64_t q) const
+#ifdef SRE_DEBUG_WALK
+    unsigned long long dbg_seg_ticks = 0, dbg_blk_ticks = 0, dbg_entry_ticks = 0, dbg_top = 0, dbg_sb = 0, dbg_rest = 0;
+    uint32_t           dbg_seg_calls = 0, dbg_blk_calls = 0, dbg_steps = 0;
+#endif
+    /* the hot tables as LDS-typed pointers in registers (bind() after T is set; see LineageWalk::run) */
+    const __attribute__((address_space(3))) sre_dev_trans_t *ltrans;
+    const __attribute__((address_space(3))) uint8_t         *lcls;
+    uint32_t                                                  nsym;
+    __device__ inline void bind()
     {
-        return T->trans[(size_t) st * (T->ncls + 1) + T->cls[data[q]]].next;
+        ltrans = (const __attribute__((address_space(3))) sre_dev_trans_t *) (uintptr_t) T->trans;
+        lcls = (const __attribute__((address_space(3))) uint8_t *) (uintptr_t) T->cls;
+        nsym = T->ncls + 1;
+    }
+
+    __device__ __forceinline__ uint32_t step(uint32_t st, int64_t q) const
+    {
+        return ltrans[(size_t) st * nsym + lcls[data[q]]].next;
+    }
+
+    /* the state chain over [lo, lo + cnt), cnt <= 64, in two passes: first the byte classes
+     * (independent loads from global memory: they overlap), then the chain through LDS only
+     * — one lane: a load inside the chain costs its whole latency per byte.  Uses `syms` (and,
+     * with record, `trace`: the state before every position, and behind the last). */
+    __device__ __forceinline__ uint32_t run_block(uint32_t cur, int64_t lo, uint32_t cnt, bool record)
+    {
+#ifdef SRE_DEBUG_WALK
+        const unsigned long long dbg_t = wall_clock64();
+        dbg_blk_calls++;
+#endif
+#pragma unroll 8
+        for (uint32_t x = 0; x < cnt; x++) syms[x] = lcls[data[lo + x]];
+        for (uint32_t x = 0; x < cnt; x++) {
+            if (record) trace[x] = (uint16_t) cur;
+            cur = ltrans[(size_t) cur * nsym + syms[x]].next;
+        }
+        if (record) trace[cnt] = (uint16_t) cur;
+#ifdef SRE_DEBUG_WALK
+        dbg_blk_ticks += wall_clock64() - dbg_t;
+#endif
+        return cur;
     }
 
     /* 16 bytes at a 16-byte aligned position through the packed-class fast
      * table; groups holding an event fall back to byte steps */
-    __device__ uint32_t step16(uint32_t st, int64_t q) const
+    __device__ __forceinline__ uint32_t step16(uint32_t st, int64_t q) const
     {
         const uint32_t bits = T->class_bits, stride = T->stride;
         const uint4    v = *reinterpret_cast<const uint4 *>(data + q);
@@ -1547,7 +1590,7 @@ struct Tracer {
      * first segment whose s_in can be taken; in front of it the state is
      * replayed from sp.
      */
-    __device__ uint32_t entry_state(int64_t kq) const
+    __device__ __forceinline__ uint32_t entry_state(int64_t kq) const
     {
         if (kq >= valid_from) return sum[kq].s_in & ~SRE_STATE_SKIP;
         uint32_t cur = init_state;
@@ -1556,8 +1599,12 @@ struct Tracer {
     }
 
     /* checkpoint segment kq up to (and including the block of) position upto */
-    __device__ void load_segment(int64_t kq, int64_t upto)
+    __device__ __forceinline__ void load_segment(int64_t kq, int64_t upto)
     {
+#ifdef SRE_DEBUG_WALK
+        const unsigned long long dbg_t = wall_clock64();
+        dbg_seg_calls++;
+#endif
         int64_t  lo = kq * (int64_t) seg_bytes, hi = lo + seg_bytes;
         uint32_t cur;
         if (hi > n) hi = n;
@@ -1566,7 +1613,13 @@ struct Tracer {
             lo = sp;
             cur = init_state;
         } else {
+#ifdef SRE_DEBUG_WALK
+            const unsigned long long dbg_te = wall_clock64();
+#endif
             cur = entry_state(kq);
+#ifdef SRE_DEBUG_WALK
+            dbg_entry_ticks += wall_clock64() - dbg_te;
+#endif
             if (use_stable && kq >= valid_from) {
                 /* the state does not move over the stable prefix: replay from its end */
                 int64_t skip = (int64_t) (sum[kq].stable_until & ~63u);
@@ -1581,43 +1634,55 @@ struct Tracer {
         const int64_t c0 = (lo + 63) & ~(int64_t) 63;
         int64_t       q = lo;
         const bool    aligned = (reinterpret_cast<uintptr_t>(data) & 15) == 0;
-        for (; q < c0 && q < hi; q++) cur = step(cur, q);
+        if (q < c0 && q < hi) {
+            const int64_t stop = c0 < hi ? c0 : hi;
+            cur = run_block(cur, q, (uint32_t) (stop - q), false);
+            q = stop;
+        }
         uint32_t i = 0;
         while (q < hi) {
             ck[i++] = (uint16_t) cur;
             const int64_t stop = q + 64 < hi ? q + 64 : hi;
-            if (aligned && stop - q == 64) {
+            if (aligned && stop - q == 64 && hi - q > 256) {
+                /* (long replays: the packed fast table, 16 bytes a load) */
                 for (int g4 = 0; g4 < 4; g4++) cur = step16(cur, q + 16 * g4);
-                q = stop;
             } else {
-                for (; q < stop; q++) cur = step(cur, q);
+                cur = run_block(cur, q, (uint32_t) (stop - q), false);
             }
+            q = stop;
         }
         ck[i] = (uint16_t) cur;
         blk_lo = 1;
         blk_hi = 0;
+#ifdef SRE_DEBUG_WALK
+        dbg_seg_ticks += wall_clock64() - dbg_t;
+#endif
     }
 
     /* state before position q (sp <= q <= n) */
-    __device__ uint32_t state_before(int64_t q)
+    __device__ __forceinline__ uint32_t state_before(int64_t q)
     {
         if (q == sp) return init_state;
         if (use_stable && q > sp) {
             /* inside the stable prefix of its segment the state is the entry state */
-            const int64_t kq = (q - 1) / seg_bytes, sbase = kq * (int64_t) seg_bytes;
-            if (sbase >= sp && kq >= valid_from && q - sbase <= (int64_t) sum[kq].stable_until) {
-                return sum[kq].s_in & ~SRE_STATE_SKIP;
+            if (q - 1 < su_lo || q - 1 >= su_hi) {
+                /* (a 64-bit division and two reads of global memory: once per segment, not per
+                 * step — the walk is one lane, every instruction of it is latency) */
+                su_k = (q - 1) / seg_bytes;
+                su_lo = su_k * (int64_t) seg_bytes;
+                su_hi = su_lo + seg_bytes;
+                su_until = sum[su_k].stable_until;
+                su_s_in = sum[su_k].s_in;
+            }
+            const int64_t kq = su_k, sbase = su_lo;
+            if (sbase >= sp && kq >= valid_from && q - sbase <= (int64_t) su_until) {
+                return su_s_in & ~SRE_STATE_SKIP;
             }
         }
         if ((q < blk_lo || q > blk_hi) && apos >= 0 && q > apos && q <= apos + 64) {
             /* the block right behind the anchor: no segment replay needed */
-            int64_t  hi = apos + 64 < n ? apos + 64 : n;
-            uint32_t cur = astate;
-            for (int64_t x = apos; x < hi; x++) {
-                trace[x - apos] = (uint16_t) cur;
-                cur = step(cur, x);
-            }
-            trace[hi - apos] = (uint16_t) cur;
+            const int64_t hi = apos + 64 < n ? apos + 64 : n;
+            run_block(astate, apos, (uint32_t) (hi - apos), true);
             blk_lo = apos;
             blk_hi = hi;
         }
@@ -1636,15 +1701,18 @@ struct Tracer {
                 cur = ck[(lo - c0) / 64];
                 hi = lo + 64 < seg_hi ? lo + 64 : seg_hi;
             }
-            for (int64_t x = lo; x < hi; x++) {
-                trace[x - lo] = (uint16_t) cur;
-                cur = step(cur, x);
-            }
-            trace[hi - lo] = (uint16_t) cur;
+            run_block(cur, lo, (uint32_t) (hi - lo), true);
             blk_lo = lo;
             blk_hi = hi;
         }
         return trace[q - blk_lo];
+    }
+
+    /* class of the byte at position q (the loaded block knows it) */
+    __device__ __forceinline__ uint32_t sym_at(int64_t q) const
+    {
+        if (q >= blk_lo && q < blk_hi) return syms[q - blk_lo];
+        return lcls[data[q]];
     }
 };
 
@@ -1828,11 +1896,24 @@ struct LineageWalk {
     int64_t                  base;
     int64_t                  walk_budget;   /* positions of plain walk before the maps are asked for */
 
-    __device__ int run(int64_t p0, uint32_t j, uint32_t state_at_p0, uint64_t &unresolved, int64_t *vec)
+    __device__ __forceinline__ int run(int64_t p0, uint32_t j, uint32_t state_at_p0, uint64_t &unresolved, int64_t *vec)
     {
         const sre_scan_tables_t &T = *this->T;
         Tracer                  &tr = *this->tr;
         const uint32_t           nsym = T.ncls + 1;
+        /* The walk is ONE lane: every load is pure latency.  The tables are in LDS
+         * (stage_walk_tables) but reached through generic pointers kept in a struct that is in
+         * LDS itself — two dependent flat loads per access, ~1.5 us per step; as LDS-typed
+         * pointers in registers a step is a handful of ds_reads. */
+        typedef const __attribute__((address_space(3))) uint32_t        *l_u32;
+        typedef const __attribute__((address_space(3))) uint64_t        *l_u64;
+        typedef const __attribute__((address_space(3))) uint8_t         *l_u8;
+        typedef const __attribute__((address_space(3))) sre_dev_trans_t *l_tr;
+        const l_u32    L_list_off = (l_u32) (uintptr_t) T.list_off, L_list_pcs = (l_u32) (uintptr_t) T.list_pcs;
+        const l_u64    L_lin_saves = (l_u64) (uintptr_t) T.lin_saves;
+        const l_u8     L_lin_parent = (l_u8) (uintptr_t) T.lin_parent;
+        const l_tr     L_trans = (l_tr) (uintptr_t) T.trans;
+        const uint32_t nslots = T.nslots, nstates = T.nstates;
         const uint64_t *const lin_early = tabp->lin_early;      /* global memory; rare */
         const int64_t  seg = (int64_t) tr.seg_bytes;
     const int64_t  k_sp = tr.sp / seg;
@@ -1842,16 +1923,32 @@ struct LineageWalk {
     /* stable stretches (sre_hip_scan.h SRE_FAST_STABLE): one search from offset 0 */
     const uint16_t *const neutral = (T.mode == 1 && T.nshadow) ? tabp->neutral : nullptr;
 
+    struct { uint32_t flags, s_in, s_out, stable_until, stable_from; } S = {0, 0, 0, 0, 0};
+    int64_t S_k = -1, S_lo = -((int64_t) 1 << 40);     /* nothing cached */
+
     /* thread j lives in the list at position p */
     for (int64_t p = p0; unresolved; p--) {
+#ifdef SRE_DEBUG_WALK
+        const unsigned long long dbg_a = wall_clock64();
+#endif
         if (neutral != nullptr) {
             /* cross, in O(1), every stretch in which the automaton sat in one state and
              * thread j descended from itself without saving: the stable prefix of the
              * segment in front of p, whole runs of stable segments, a stable suffix */
             for (;;) {
                 if (p <= tr.sp) break;
-                const int64_t kq = (p - 1) / seg, sbase = kq * seg;
-                const sre_seg_summary_t &S = tr.sum[kq];
+                if (p - 1 < S_lo || p - 1 >= S_lo + seg) {
+                    /* (a division and the summary in global memory: once per segment, not per step) */
+                    S_k = (p - 1) / seg;
+                    S_lo = S_k * seg;
+                    const sre_seg_summary_t &G = tr.sum[S_k];
+                    S.flags = G.flags;
+                    S.s_in = G.s_in;
+                    S.s_out = G.s_out;
+                    S.stable_until = G.stable_until;
+                    S.stable_from = G.stable_from;
+                }
+                const int64_t kq = S_k, sbase = S_lo;
                 if (p == sbase + seg && kq > unst_end && (S.flags & SRE_SUM_STABLE)) {
                     /* ... up to the end of the buffer (walks that start there) */
                     if (!((neutral[S.s_in & ~SRE_STATE_SKIP] >> j) & 1u)) break;
@@ -1906,46 +2003,64 @@ struct LineageWalk {
         if (!can_jump && --budget < 0 && T.max_threads <= 16) {
             return 1;                       /* come back with the ancestor maps */
         }
+#ifdef SRE_DEBUG_WALK
+        const unsigned long long dbg_b = wall_clock64();
+        tr.dbg_top += dbg_b - dbg_a;
+#endif
         const uint32_t s_here = (p == p0) ? state_at_p0 : tr.state_before(p);
 #ifdef SRE_DEBUG_WALK
+        const unsigned long long dbg_c = wall_clock64();
+        tr.dbg_sb += dbg_c - dbg_b;
+#endif
+#ifdef SRE_DEBUG_WALK
+        tr.dbg_steps++;
+#endif
+#ifdef SRE_DEBUG_WALK_STEPS
         printf("walk p %lld s_here %u j %u pc %u unresolved %llx\n", (long long) p, s_here, j,
                T.list_pcs[T.list_off[s_here] + j], (unsigned long long) unresolved);
 #endif
-        if (T.list_pcs[T.list_off[s_here] + j] == 1) break;      /* the ".*?" ANY thread */
-        const sre_dev_trans_t *t;
-        int64_t                val;
+        if (L_list_pcs[L_list_off[s_here] + j] == 1) break;      /* the ".*?" ANY thread */
+        l_tr    t;
+        int64_t val;
         if (p == tr.sp && carried != nullptr) {
             /* the search came in from the previous chunk: the rest is what the context
              * carries for this thread */
-            for (uint32_t q = 0; q < T.nslots; q++) {
+            for (uint32_t q = 0; q < nslots; q++) {
                 if ((unresolved >> q) & 1) vec[q] = carried[(size_t) j * SRE_STREAM_MAX_SLOTS + q];
             }
             unresolved = 0;
             break;
         }
         if (p == tr.sp) {
-            t = &T.trans[(size_t) T.nstates * nsym + variant];   /* initial closure */
+            t = &L_trans[(size_t) nstates * nsym + variant];   /* initial closure */
             val = tr.sp;
         } else {
-            t = &T.trans[(size_t) tr.state_before(p - 1) * nsym + T.cls[tr.data[p - 1]]];
+            const uint32_t s_prev = tr.state_before(p - 1);     /* (may load another block: first) */
+            t = &L_trans[(size_t) s_prev * nsym + tr.sym_at(p - 1)];
             val = p;
         }
-        const uint64_t m = T.lin_saves[t->lin_off + j] & unresolved;
-        for (uint32_t q = 0; q < T.nslots; q++) {
-            if ((m >> q) & 1) vec[q] = val + base;
+        const uint32_t lin = t->lin_off + j;
+        const uint64_t m = L_lin_saves[lin] & unresolved;
+        if (m) {
+            for (uint32_t q = 0; q < nslots; q++) {
+                if ((m >> q) & 1) vec[q] = val + base;
+            }
+            unresolved &= ~m;
         }
-        unresolved &= ~m;
         if (lin_early != nullptr) {
             /* written by a look-ahead splice before the byte was consumed */
-            const uint64_t m2 = lin_early[t->lin_off + j] & unresolved;
-            for (uint32_t q = 0; q < T.nslots; q++) {
+            const uint64_t m2 = lin_early[lin] & unresolved;
+            for (uint32_t q = 0; q < nslots; q++) {
                 if ((m2 >> q) & 1) vec[q] = val - 1 + base;
             }
             unresolved &= ~m2;
         }
         if (p == tr.sp) break;
-        j = T.lin_parent[t->lin_off + j];
+        j = L_lin_parent[lin];
         if (j == 0xffu) break;              /* re-seeded by the leading-byte skip */
+#ifdef SRE_DEBUG_WALK
+        tr.dbg_rest += wall_clock64() - dbg_c;
+#endif
     }
 
         return 0;
@@ -2011,6 +2126,11 @@ sre_k_captures(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
     SRE_TAIL_PRIO();
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     __shared__ sre_scan_tables_t Ts;
+    __shared__ uint16_t sh_trace[72];       /* the walker's current 64-byte block (Tracer) */
+    __shared__ uint8_t  sh_syms[72];
+#ifdef SRE_DEBUG_WALK
+    const unsigned long long dbg_t0 = wall_clock64();
+#endif
     stage_walk_tables(tabp, lds, &Ts);
     if (NT != 64) {
         __shared__ VerifyAcc sh_acc;
@@ -2023,6 +2143,10 @@ sre_k_captures(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
     const uint32_t s = blockIdx.x;
     if (s >= G.nstreams || threadIdx.x != 0) return;
     if (use_maps && !status[s].need_maps) return;   /* second pass: flagged streams only */
+#ifdef SRE_DEBUG_WALK
+    const unsigned long long dbg_ts = wall_clock64();
+    unsigned long long       dbg_tw0 = 0, dbg_tw1 = 0;
+#endif
     const sre_scan_tables_t   &T = Ts;
     const sre_stream_status_t  st = status[s];
     int64_t                   *rec = records + (size_t) s * (2 + ovec_slots);
@@ -2055,7 +2179,9 @@ sre_k_captures(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
     tr.apos = (st.ev_apos >= st.ev_sp) ? st.ev_apos : -1;
     tr.astate = st.ev_astate;
     tr.ck = scratch + (size_t) s * (G.seg_bytes + 16);
-    tr.trace = tr.ck + G.seg_bytes / 64 + 4;
+    tr.trace = (__attribute__((address_space(3))) uint16_t *) sh_trace;
+    tr.syms = (__attribute__((address_space(3))) uint8_t *) sh_syms;
+    tr.bind();
     tr.seg_lo = tr.seg_hi = -1;
     tr.blk_lo = 1;
     tr.blk_hi = 0;
@@ -2102,7 +2228,14 @@ sre_k_captures(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
         lw.carried = nullptr;
         lw.base = 0;
         lw.walk_budget = SRE_WALK_BUDGET;
-        if (lw.run(st.ev_pos, j, st.ev_state, unresolved, vec)) {
+#ifdef SRE_DEBUG_WALK
+        dbg_tw0 = wall_clock64();
+#endif
+        const int need = lw.run(st.ev_pos, j, st.ev_state, unresolved, vec);
+#ifdef SRE_DEBUG_WALK
+        dbg_tw1 = wall_clock64();
+#endif
+        if (need) {
             status[s].need_maps = 1;         /* come back with the ancestor maps */
             return;
         }
@@ -2115,6 +2248,12 @@ sre_k_captures(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
     const uint64_t ncopy = 2ull * (T.multi_ncaps[st.rc] + 1);
     for (uint64_t q = 0; q < ovec_slots; q++) rec[2 + q] = q < ncopy ? vec[ofs + q] : -1;
     rec[0] = (st.error && T.mode == SRE_HIP_PIKE_COUNT) ? RC_ERROR : st.rc;
+#ifdef SRE_DEBUG_WALK
+    printf("captures: stream %u (10 ns ticks) staging %llu, to the walk %llu, walk %llu, rest %llu; steps %u, load_segment %u calls %llu ticks "
+           "(entry_state %llu), run_block %u calls %llu ticks; per step: top %llu, state_before(p) %llu, rest %llu\n", s,
+           dbg_ts - dbg_t0, dbg_tw0 - dbg_ts, dbg_tw1 - dbg_tw0, wall_clock64() - dbg_tw1, tr.dbg_steps, tr.dbg_seg_calls,
+           tr.dbg_seg_ticks, tr.dbg_entry_ticks, tr.dbg_blk_calls, tr.dbg_blk_ticks, tr.dbg_top, tr.dbg_sb, tr.dbg_rest);
+#endif
 }
 
 
@@ -2145,6 +2284,8 @@ sre_k_stream_tail(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
     SRE_TAIL_PRIO();
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     __shared__ sre_scan_tables_t Ts;
+    __shared__ uint16_t sh_trace[72];       /* the walker's current 64-byte block (Tracer) */
+    __shared__ uint8_t  sh_syms[72];
     __shared__ VerifyAcc sh_acc;
     __shared__ sre_stream_status_t sh_st;
     stage_walk_tables(tabp, lds, &Ts);
@@ -2221,7 +2362,9 @@ sre_k_stream_tail(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
     tr.apos = st.ev_apos >= 0 ? st.ev_apos : -1;
     tr.astate = st.ev_astate;
     tr.ck = scratch;
-    tr.trace = tr.ck + G.seg_bytes / 64 + 4;
+    tr.trace = (__attribute__((address_space(3))) uint16_t *) sh_trace;
+    tr.syms = (__attribute__((address_space(3))) uint8_t *) sh_syms;
+    tr.bind();
     tr.seg_lo = tr.seg_hi = -1;
     tr.blk_lo = 1;
     tr.blk_hi = 0;

@@ -15,12 +15,9 @@ print('step_ms %.4f kernel_ms %.4f frac %.4f kfrac %.4f seg %s' % (r['step_ms'],
   echo "$CFG $EXTRA | $name | $out"
 }
 OLD=$PWD/sregex_amd/lib_old/libsregex.so
-for CFG in cfg2m cfg2 cfg4; do
+for CFG in cfg2m cfg4; do
 EXTRA=
-one "tail kernels at wave priority 3" A=1
-one "no priority (previous build)" SREGEX_AMD_LIB=$OLD
-one "tail kernels at wave priority 3 again" A=1
+one "walker: block trace in LDS, summaries cached" A=1
+one "previous build" SREGEX_AMD_LIB=$OLD
+one "walker: block trace in LDS again" A=1
 done
-CFG=cfg2 EXTRA=--many-streams
-one "tail kernels at wave priority 3" A=1
-one "no priority (previous build)" SREGEX_AMD_LIB=$OLD
