@@ -391,30 +391,35 @@ sre_k_nfa_verify_a(sre_scan_geom_t G, const sre_nfa_summary_t *__restrict__ sum,
     if (sum[g].first_ev >= 0) atomicMin(&acc[s].end, (unsigned long long) k);
 }
 
-__global__ __launch_bounds__(1024) void
+__global__ __launch_bounds__(256) void
 sre_k_nfa_verify_b(sre_scan_geom_t G, const sre_nfa_summary_t *__restrict__ sum, NfaAcc *__restrict__ acc)
 {
     /* nearly every segment has a clean position, and they all go to one address per
-     * stream: reduce in the wave, then in the workgroup (1024 segments), then one atomic */
+     * stream: reduce in the wave, then in the workgroup, then one atomic per 1024 segments
+     * (256 threads x 4: a workgroup small enough for a spare slot beside the next scan) */
     __shared__ unsigned long long sh_max;
-    const uint64_t g0 = (uint64_t) blockIdx.x * blockDim.x;
-    const uint64_t g = g0 + threadIdx.x;
-    const uint64_t glast = (g0 + blockDim.x - 1 < G.nsegs) ? g0 + blockDim.x - 1 : G.nsegs - 1;
+    const uint64_t g0 = (uint64_t) blockIdx.x * 1024u;
+    const uint64_t glast = (g0 + 1023 < G.nsegs) ? g0 + 1023 : G.nsegs - 1;
     const uint32_t s_first = nfa_stream_of(G, g0), s_last = nfa_stream_of(G, glast);
     const bool     uniform = (s_first == s_last);
     if (threadIdx.x == 0) sh_max = 0;
     __syncthreads();
     unsigned long long mine = 0;
-    uint32_t           s = s_first;
-    if (g < G.nsegs) {
-        if (!uniform) s = nfa_stream_of(G, g);
+    for (uint32_t it = 0; it < 4; it++) {
+        const uint64_t g = g0 + it * 256u + threadIdx.x;
+        if (g >= G.nsegs) break;
+        const uint32_t s = uniform ? s_first : nfa_stream_of(G, g);
         const uint64_t k = g - geom_first(G, s);
         const uint64_t nseg = geom_first(G, s + 1) - geom_first(G, s);
         uint64_t       bad = acc[s].bad, end = acc[s].end;
         if (bad > nseg) bad = nseg;
         if (end > nseg) end = nseg;
         const uint64_t limit = end < bad ? end + 1 : bad;
-        if (k < limit && sum[g].last_clean >= 0) mine = (unsigned long long) sum[g].last_clean + 1;    /* position * 2 + mode */
+        if (k < limit && sum[g].last_clean >= 0) {
+            const unsigned long long v = (unsigned long long) sum[g].last_clean + 1;    /* position * 2 + mode */
+            if (uniform) mine = v > mine ? v : mine;
+            else atomicMax(&acc[s].clean, v);
+        }
     }
     if (uniform) {
         for (int d = 32; d >= 1; d >>= 1) {
@@ -424,8 +429,6 @@ sre_k_nfa_verify_b(sre_scan_geom_t G, const sre_nfa_summary_t *__restrict__ sum,
         if ((threadIdx.x & 63u) == 0 && mine) atomicMax(&sh_max, mine);
         __syncthreads();
         if (threadIdx.x == 0 && sh_max) atomicMax(&acc[s_first].clean, sh_max);
-    } else if (mine) {
-        atomicMax(&acc[s].clean, mine);
     }
 }
 
@@ -580,7 +583,7 @@ sre_launch_nfa_verify(int mode, sre_scan_geom_t geom, const sre_nfa_summary_t *d
     NfaAcc        *acc = static_cast<NfaAcc *>(d_acc);
     const uint32_t gseg = (uint32_t) ((geom.nsegs + 255) / 256);
     hipLaunchKernelGGL(sre_k_nfa_verify_a, dim3(gseg), dim3(256), 0, stream, geom, d_sum, acc, d_belief, d_bvalid);
-    hipLaunchKernelGGL(sre_k_nfa_verify_b, dim3((uint32_t) ((geom.nsegs + 1023) / 1024)), dim3(1024), 0, stream,
+    hipLaunchKernelGGL(sre_k_nfa_verify_b, dim3((uint32_t) ((geom.nsegs + 1023) / 1024)), dim3(256), 0, stream,
                        geom, d_sum, acc);
     hipLaunchKernelGGL(sre_k_nfa_verify_c, dim3((geom.nstreams + 63) / 64), dim3(64), 0, stream, mode, geom,
                        d_sum, acc, d_status, d_records, ovec_slots, d_lo);

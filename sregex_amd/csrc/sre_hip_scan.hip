@@ -1153,26 +1153,33 @@ sre_k_verify_a(sre_scan_geom_t G, const sre_seg_summary_t *__restrict__ sum, Ver
     if (sum[g].flags & SRE_SUM_TERM) atomicMin(&acc[s].end, (unsigned long long) k);
 }
 
-__global__ __launch_bounds__(1024) void
+/* (256 threads cover SRE_VERIFY_SPAN = 1024 segments: one global atomic per 1024 segments
+ * and stream — they all land on one address, a 4 GiB stream is 258K segments — from a
+ * workgroup small enough for a spare slot while the next scan holds the chip: as 1024-thread
+ * workgroups these kernels waited ~0.45 ms for a CU to drain, profiles/r02_kernel_stats.csv) */
+#define SRE_VERIFY_SPAN 1024u
+
+__global__ __launch_bounds__(256) void
 sre_k_verify_b(sre_scan_geom_t G, const sre_seg_summary_t *__restrict__ sum, VerifyAcc *__restrict__ acc)
 {
     SRE_TAIL_PRIO();
     __shared__ unsigned long long sh_count, sh_ev, sh_sp;
-    const uint64_t g0 = (uint64_t) blockIdx.x * blockDim.x;
-    const uint64_t g = g0 + threadIdx.x;
-    const uint64_t glast = (g0 + blockDim.x - 1 < G.nsegs) ? g0 + blockDim.x - 1 : G.nsegs - 1;
+    const uint64_t g0 = (uint64_t) blockIdx.x * SRE_VERIFY_SPAN;
+    const uint64_t glast = (g0 + SRE_VERIFY_SPAN - 1 < G.nsegs) ? g0 + SRE_VERIFY_SPAN - 1 : G.nsegs - 1;
     const uint32_t s_first = stream_of(G, g0), s_last = stream_of(G, glast);
-    const bool     uniform = (s_first == s_last);       /* whole block inside one stream */
+    const bool     uniform = (s_first == s_last);       /* whole span inside one stream */
     if (threadIdx.x == 0) {
         sh_count = 0;
         sh_ev = 0;
         sh_sp = 0;
     }
     __syncthreads();
-    /* whole block inside one stream (the usual case): reduce in the wave first — a
+    /* whole span inside one stream (the usual case): reduce in the wave first — a
      * shared-memory atomic per lane serialises 256 ways when every segment counts */
     unsigned long long my_count = 0, my_ev = 0, my_sp = 0;
-    if (g < G.nsegs) {
+    for (uint32_t it = 0; it < SRE_VERIFY_SPAN / 256; it++) {
+        const uint64_t g = g0 + it * 256u + threadIdx.x;
+        if (g >= G.nsegs) break;
         const uint32_t s = uniform ? s_first : stream_of(G, g);
         const uint64_t k = g - geom_first(G, s);
         const uint64_t nseg = geom_first(G, s + 1) - geom_first(G, s);
@@ -1183,7 +1190,7 @@ sre_k_verify_b(sre_scan_geom_t G, const sre_seg_summary_t *__restrict__ sum, Ver
         if (k < limit) {
             const sre_seg_summary_t &c = sum[g];
             if (uniform) {
-                my_count = (unsigned long long) c.count;
+                my_count += (unsigned long long) c.count;
                 if (c.flags & SRE_SUM_LASTEV) my_ev = (unsigned long long) k + 1;
                 if (c.cur_sp >= 0) my_sp = (unsigned long long) k + 1;     /* latest segment at whose end a search start is known */
             } else {
@@ -1217,30 +1224,38 @@ sre_k_verify_b(sre_scan_geom_t G, const sre_seg_summary_t *__restrict__ sum, Ver
 /* FIRST: the last segment in front of the event's that is not SRE_SUM_STABLE — between
  * the two the automaton sat in one state whose neutral threads looped in place, and the
  * capture walker crosses all of them in one jump */
-__global__ __launch_bounds__(1024) void
+__global__ __launch_bounds__(256) void
 sre_k_verify_b2(sre_scan_geom_t G, const sre_seg_summary_t *__restrict__ sum, VerifyAcc *__restrict__ acc)
 {
     SRE_TAIL_PRIO();
     __shared__ unsigned long long sh_max, sh_max_end;
-    const uint64_t g0 = (uint64_t) blockIdx.x * blockDim.x;
-    const uint64_t g = g0 + threadIdx.x;
-    const uint64_t glast = (g0 + blockDim.x - 1 < G.nsegs) ? g0 + blockDim.x - 1 : G.nsegs - 1;
+    const uint64_t g0 = (uint64_t) blockIdx.x * SRE_VERIFY_SPAN;
+    const uint64_t glast = (g0 + SRE_VERIFY_SPAN - 1 < G.nsegs) ? g0 + SRE_VERIFY_SPAN - 1 : G.nsegs - 1;
     const uint32_t s_first = stream_of(G, g0), s_last = stream_of(G, glast);
-    const bool     uniform = (s_first == s_last);       /* whole block inside one stream */
+    const bool     uniform = (s_first == s_last);       /* whole span inside one stream */
     if (threadIdx.x == 0) sh_max = sh_max_end = 0;
     __syncthreads();
     unsigned long long mine = 0, mine_end = 0;
-    uint32_t           s = s_first;
-    if (g < G.nsegs) {
-        if (!uniform) s = stream_of(G, g);
+    for (uint32_t it = 0; it < SRE_VERIFY_SPAN / 256; it++) {
+        const uint64_t g = g0 + it * 256u + threadIdx.x;
+        if (g >= G.nsegs) break;
+        const uint32_t s = uniform ? s_first : stream_of(G, g);
         const uint64_t k = g - geom_first(G, s);
         const uint64_t evseg = acc[s].evseg;        /* 1 + the event's segment, 0 none */
         const uint64_t nseg = geom_first(G, s + 1) - geom_first(G, s);
         if (!(sum[g].flags & SRE_SUM_STABLE)) {
-            if (evseg != 0 && k + 1 < evseg) mine = k + 1;
+            unsigned long long m1 = 0, m2 = 0;
+            if (evseg != 0 && k + 1 < evseg) m1 = k + 1;
             /* (streaming: the walks that start at the end of a chunk; its last segment is
              * never flagged stable and is crossed by its own stable prefix / suffix) */
-            if (k + 1 < nseg) mine_end = k + 1;
+            if (k + 1 < nseg) m2 = k + 1;
+            if (uniform) {
+                mine = m1 > mine ? m1 : mine;
+                mine_end = m2 > mine_end ? m2 : mine_end;
+            } else {
+                if (m1) atomicMax(&acc[s].unst, m1);
+                if (m2) atomicMax(&acc[s].unst_end, m2);
+            }
         }
     }
     if (uniform) {
@@ -1258,9 +1273,6 @@ sre_k_verify_b2(sre_scan_geom_t G, const sre_seg_summary_t *__restrict__ sum, Ve
             if (sh_max) atomicMax(&acc[s_first].unst, sh_max);
             if (sh_max_end) atomicMax(&acc[s_first].unst_end, sh_max_end);
         }
-    } else {
-        if (mine) atomicMax(&acc[s].unst, mine);
-        if (mine_end) atomicMax(&acc[s].unst_end, mine_end);
     }
 }
 
@@ -2598,12 +2610,10 @@ sre_launch_verify(sre_scan_tables_t h_tab, sre_scan_geom_t geom, const sre_seg_s
     VerifyAcc *acc = static_cast<VerifyAcc *>(d_acc);
     const uint32_t gseg = (uint32_t) ((geom.nsegs + 255) / 256);
     hipLaunchKernelGGL(sre_k_verify_a, dim3(gseg), dim3(256), 0, stream, geom, d_sum, acc, (int) h_tab.mode);
-    /* 1024 segments per workgroup: one global atomic per workgroup and stream, and these
-     * all land on one address (a 4 GiB stream is 258K segments) */
-    const uint32_t gseg4 = (uint32_t) ((geom.nsegs + 1023) / 1024);
-    hipLaunchKernelGGL(sre_k_verify_b, dim3(gseg4), dim3(1024), 0, stream, geom, d_sum, acc);
+    const uint32_t gseg4 = (uint32_t) ((geom.nsegs + SRE_VERIFY_SPAN - 1) / SRE_VERIFY_SPAN);
+    hipLaunchKernelGGL(sre_k_verify_b, dim3(gseg4), dim3(256), 0, stream, geom, d_sum, acc);
     if (h_tab.mode == 1 /* SRE_HIP_PIKE_FIRST */ && h_tab.nshadow) {
-        hipLaunchKernelGGL(sre_k_verify_b2, dim3(gseg4), dim3(1024), 0, stream, geom, d_sum, acc);
+        hipLaunchKernelGGL(sre_k_verify_b2, dim3(gseg4), dim3(256), 0, stream, geom, d_sum, acc);
     }
     hipLaunchKernelGGL(sre_k_verify_c, dim3((geom.nstreams + 63) / 64), dim3(64), 0, stream, h_tab,
                        geom, d_sum, acc, d_status);

@@ -15,9 +15,12 @@ print('step_ms %.4f kernel_ms %.4f frac %.4f kfrac %.4f seg %s' % (r['step_ms'],
   echo "$CFG $EXTRA | $name | $out"
 }
 OLD=$PWD/sregex_amd/lib_old/libsregex.so
-for CFG in cfg2m cfg4; do
+for CFG in cfg2 cfg2m cfg4 nfa; do
 EXTRA=
-one "walker: block trace in LDS, summaries cached" A=1
-one "previous build" SREGEX_AMD_LIB=$OLD
-one "walker: block trace in LDS again" A=1
+one "chain-check kernels in 256-thread workgroups" A=1
+one "1024-thread workgroups (previous build)" SREGEX_AMD_LIB=$OLD
+one "256-thread workgroups again" A=1
 done
+CFG=cfg2 EXTRA=--many-streams
+one "chain-check kernels in 256-thread workgroups" A=1
+one "1024-thread workgroups (previous build)" SREGEX_AMD_LIB=$OLD
