@@ -233,7 +233,11 @@ def measure(spec, S, torch, res, hstream, stream, steps, warmup, barrier):
     # second (sre_hip_scanner_set_tail_stream) — no gap between two scans, but the next scan
     # then takes the chip before the tail kernels get a slot and the step's results wait for
     # it (same box: configs[1] 0.860 vs 0.846 ms, 128 streams 2.25 vs 1.64); "one" = no overlap.
-    scheme = os.environ.get("SRE_BENCH_STREAMS", "two")
+    # Batches of many streams stay on ONE stream: their capture kernel (one single-lane walk
+    # per stream) takes 1.2 ms when it shares the chip with the next scan (50 us alone), which
+    # the steady state hides (1.61 vs 1.68 ms per step) but the first steps of every run do
+    # not (+3.6 ms per run: profiles/r02_experiments.txt) — a short run would measure worse.
+    scheme = os.environ.get("SRE_BENCH_STREAMS", "two" if len(lens) == 1 else "one")
     hs = [hstream] * depth
     if scheme == "tail":
         for x in scs:
@@ -245,6 +249,8 @@ def measure(spec, S, torch, res, hstream, stream, steps, warmup, barrier):
         # step i: scanner and stream i mod depth; its scan kernel follows step i - 1's (event),
         # the results of step i - depth + 1 are collected once it is queued
         recs, kms, inflight = None, [], []
+        trace = [] if os.environ.get("SRE_BENCH_TRACE") else None      # per-step wall times to stderr
+        t_run = time.perf_counter()
         for i in range(nsteps):
             cur = scs[i % depth]
             if inflight and hs[0] is not hs[1]:
@@ -255,9 +261,16 @@ def measure(spec, S, torch, res, hstream, stream, steps, warmup, barrier):
                 done = inflight.pop(0)
                 recs = done.results()
                 kms.append(done.last_kernel_ms)
+                if trace is not None:
+                    trace.append((time.perf_counter(), done.last_kernel_ms, done.last_fixups))
         for done in inflight:
             recs = done.results()
             kms.append(done.last_kernel_ms)
+        if trace:
+            print("[bench trace] first results after %.2f ms, all after %.2f ms;" % ((trace[0][0] - t_run) * 1e3, (time.perf_counter() - t_run) * 1e3),
+                  file=sys.stderr)
+            print("[bench trace] " + " ".join("%.2f/%.2f/%d" % ((b[0] - a[0]) * 1e3, b[1], b[2]) for a, b in zip(trace, trace[1:])),
+                  file=sys.stderr)
         return recs, kms
 
     torch.cuda.synchronize()            # the input was generated on the main stream

@@ -604,8 +604,13 @@ sre_hip_scan_enqueue(sre_hip_scanner_t *sc, const void *const *d_streams, const 
     } else {
         if (scan_geometry(sc, nstreams) != 0) return -1;
         if (!sc->geom_one) {
-            SRE_HIP_TRY(hipMemcpyAsync(sc->d_in, sc->h_in, (3 * nstreams + 1) * sizeof(uint64_t),
-                                       hipMemcpyHostToDevice, stream));
+            static const bool dma = getenv("SRE_HIP_DMA_UPLOAD") != NULL;      /* experiment knob: the old way */
+            if (dma) {
+                SRE_HIP_TRY(hipMemcpyAsync(sc->d_in, sc->h_in, (3 * nstreams + 1) * sizeof(uint64_t),
+                                           hipMemcpyHostToDevice, stream));
+            } else {
+                SRE_HIP_TRY(sre_launch_upload_words(sc->h_in, sc->d_in, (uint32_t) (3 * nstreams + 1), stream));
+            }
         }
         /* speculative pass, chain check, captures — all queued; results() only
          * has to look at the status words */

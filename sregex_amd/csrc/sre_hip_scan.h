@@ -295,6 +295,8 @@ hipError_t sre_launch_stream_tail(const sre_scan_tables_t *d_tab, sre_scan_table
     sre_scan_geom_t geom, const sre_seg_summary_t *d_sum, sre_stream_status_t *d_status,
     uint16_t *d_scratch, sre_stream_ctx_t *d_ctx, sre_stream_result_t *result, int64_t base, int eof,
     uint32_t ovec_slots, int verify, hipStream_t stream);
+/* copy nwords 64-bit words from pinned, device-mapped host memory to the device with a kernel */
+hipError_t sre_launch_upload_words(const uint64_t *h_src_mapped, uint64_t *d_dst, uint32_t nwords, hipStream_t stream);
 size_t sre_scan_verify_acc_bytes(uint32_t nstreams);
 hipError_t sre_scan_verify_acc_init(void *d_acc, uint32_t nstreams, hipStream_t stream);
 hipError_t sre_launch_verify(sre_scan_tables_t h_tab, sre_scan_geom_t geom,

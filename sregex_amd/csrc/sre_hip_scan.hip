@@ -2583,6 +2583,25 @@ sre_launch_scan(const sre_scan_tables_t *d_tab, sre_scan_tables_t h_tab, sre_sca
     return hipGetLastError();
 }
 
+/* the stream descriptors of a batch (pointers, lengths, first segments: 24 bytes a stream)
+ * from pinned host memory to the device by a KERNEL: a DMA-engine copy in front of every
+ * scan has to be synchronised with the compute queue, and on two alternating HIP streams
+ * the first steps of a run stalled for milliseconds behind it */
+__global__ __launch_bounds__(256) void
+sre_k_upload_words(const uint64_t *__restrict__ src, uint64_t *__restrict__ dst, uint32_t n)
+{
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) dst[i] = src[i];
+}
+
+extern "C" hipError_t
+sre_launch_upload_words(const uint64_t *h_src_mapped, uint64_t *d_dst, uint32_t nwords, hipStream_t stream)
+{
+    if (nwords == 0) return hipSuccess;
+    const uint32_t grid = (nwords + 255) / 256 < 64 ? (nwords + 255) / 256 : 64;
+    hipLaunchKernelGGL(sre_k_upload_words, dim3(grid), dim3(256), 0, stream, h_src_mapped, d_dst, nwords);
+    return hipGetLastError();
+}
+
 extern "C" size_t
 sre_scan_verify_acc_bytes(uint32_t nstreams)
 {
