@@ -1551,8 +1551,24 @@ struct Tracer {
         const unsigned long long dbg_t = wall_clock64();
         dbg_blk_calls++;
 #endif
+        /* GLOBAL loads (not flat ones: those also count on the LDS counter and would be
+         * waited for one by one): a whole aligned block as four 16-byte loads in flight
+         * together, else eight byte loads at a time.  Beside a resident scan a round trip to
+         * HBM takes microseconds; the walk should make a handful, not one per byte. */
+        const __attribute__((address_space(1))) uint8_t *g =
+            (const __attribute__((address_space(1))) uint8_t *) (uintptr_t) (data + lo);
+        if (cnt == 64 && (reinterpret_cast<uintptr_t>(data + lo) & 15) == 0) {
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            const __attribute__((address_space(1))) u32x4 *gv = (const __attribute__((address_space(1))) u32x4 *) g;
+            const u32x4 v0 = gv[0], v1 = gv[1], v2 = gv[2], v3 = gv[3];
+            const uint32_t w[16] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w,
+                                    v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
+#pragma unroll
+            for (uint32_t x = 0; x < 64; x++) syms[x] = lcls[(w[x >> 2] >> ((x & 3) * 8)) & 0xffu];
+        } else {
 #pragma unroll 8
-        for (uint32_t x = 0; x < cnt; x++) syms[x] = lcls[data[lo + x]];
+            for (uint32_t x = 0; x < cnt; x++) syms[x] = lcls[g[x]];
+        }
         for (uint32_t x = 0; x < cnt; x++) {
             if (record) trace[x] = (uint16_t) cur;
             cur = ltrans[(size_t) cur * nsym + syms[x]].next;

@@ -14,13 +14,9 @@ d=json.loads(sys.stdin.read()); r=d['roofline']
 print('step_ms %.4f kernel_ms %.4f frac %.4f kfrac %.4f seg %s' % (r['step_ms'], r['kernel_ms'], r['frac'], r['kernel_frac'], d['config']['segment_bytes']))")
   echo "$CFG $EXTRA | $name | $out"
 }
-OLD=$PWD/sregex_amd/lib_old/libsregex.so
-for CFG in cfg2 cfg2m cfg4 nfa; do
-EXTRA=
-one "chain-check kernels in 256-thread workgroups" A=1
-one "1024-thread workgroups (previous build)" SREGEX_AMD_LIB=$OLD
-one "256-thread workgroups again" A=1
-done
+CFG=cfg2m EXTRA=
+one "default" A=1
+one "default again" A=1
 CFG=cfg2 EXTRA=--many-streams
-one "chain-check kernels in 256-thread workgroups" A=1
-one "1024-thread workgroups (previous build)" SREGEX_AMD_LIB=$OLD
+one "one HIP stream (default)" A=1
+one "two HIP streams" SRE_BENCH_STREAMS=two
