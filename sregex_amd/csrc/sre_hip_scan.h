@@ -103,7 +103,7 @@ typedef struct {
     uint32_t nshadow;                   /* shadow rows in the LDS fast table (FIRST / Thompson tables) */
     uint32_t fast_rows;                 /* rows of the scan kernel's LDS copy: nstates + 1 (trap) + nshadow */
     uint32_t wide;                      /* the staging tile holds 16-bit pre-scaled indices (sre_hip_tile.h): always with
-                                           <= 2 class bits; with 4 in COUNT mode when two workgroups per CU still fit */
+                                           <= 2 class bits; with 4 in COUNT mode when three workgroups per CU still fit */
     uint8_t  shadow_state[SRE_SCAN_MAX_SHADOWS];    /* the state each of them copies */
     const uint8_t         *unskip;      /* [nstates] sre_dfa_t.unskip: what a chunk boundary makes of a state */
     const uint16_t        *neutral;     /* [nstates] bit j: thread j of the state's list descends from itself,

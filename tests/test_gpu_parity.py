@@ -859,9 +859,20 @@ def test_scanner_random_patterns_vs_oracle(gpu, seg):
     modes = (S.HIP_THOMPSON, S.HIP_PIKE_FIRST, S.HIP_PIKE_COUNT)
     tested = admitted = nfa_admitted = 0
     bad = []
+    import time
+    slow_log = os.environ.get("SRE_FUZZ_SLOW")          # seconds: patterns slower than that go to gpurun_out/fuzz_slow.jsonl
     for _ in range(600):
         nre = 1 if rng.random() < 0.8 else rng.randrange(2, 4)
         pats = [harness.random_regex(rng) for _ in range(nre)]
+        t_pat = time.perf_counter()
+        if slow_log and bad is not None and getattr(test_scanner_random_patterns_vs_oracle, "_last", None):
+            last_pats, last_t = test_scanner_random_patterns_vs_oracle._last
+            if t_pat - last_t > float(slow_log):
+                os.makedirs(os.path.join(harness.ROOT, "gpurun_out"), exist_ok=True)
+                with open(os.path.join(harness.ROOT, "gpurun_out", "fuzz_slow.jsonl"), "a") as f:
+                    f.write(json.dumps({"seg": seg, "seconds": t_pat - last_t, "re": [p.hex() for p in last_pats],
+                                        "text": [p.decode("latin-1") for p in last_pats]}) + "\n")
+        test_scanner_random_patterns_vs_oracle._last = (pats, t_pat)
         with S.Pool() as pool:
             try:
                 re = S.parse(pool, pats)

@@ -14,9 +14,9 @@ d=json.loads(sys.stdin.read()); r=d['roofline']
 print('step_ms %.4f kernel_ms %.4f frac %.4f kfrac %.4f seg %s' % (r['step_ms'], r['kernel_ms'], r['frac'], r['kernel_frac'], d['config']['segment_bytes']))")
   echo "$CFG $EXTRA | $name | $out"
 }
-CFG=cfg2m EXTRA=
-one "default" A=1
-one "default again" A=1
-CFG=cfg2 EXTRA=--many-streams
-one "one HIP stream (default)" A=1
-one "two HIP streams" SRE_BENCH_STREAMS=two
+OLD=$PWD/sregex_amd/lib_old/libsregex.so
+CFG=nfa EXTRA=
+one "row descriptors in registers (4 workgroups per CU?)" A=1
+one "row descriptors in LDS (3 per CU, previous build)" SREGEX_AMD_LIB=$OLD
+one "row descriptors in registers again" A=1
+one "previous build again" SREGEX_AMD_LIB=$OLD
