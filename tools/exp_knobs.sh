@@ -14,9 +14,10 @@ d=json.loads(sys.stdin.read()); r=d['roofline']
 print('step_ms %.4f kernel_ms %.4f frac %.4f kfrac %.4f seg %s' % (r['step_ms'], r['kernel_ms'], r['frac'], r['kernel_frac'], d['config']['segment_bytes']))")
   echo "$CFG $EXTRA | $name | $out"
 }
-OLD=$PWD/sregex_amd/lib_old/libsregex.so
-CFG=nfa EXTRA=
-one "row descriptors in registers (4 workgroups per CU?)" A=1
-one "row descriptors in LDS (3 per CU, previous build)" SREGEX_AMD_LIB=$OLD
-one "row descriptors in registers again" A=1
-one "previous build again" SREGEX_AMD_LIB=$OLD
+for CFG in cfg2 cfg2m cfg4 cfg3; do
+EXTRA=
+one "one stream per scanner, scans chained by an event (default)" A=1
+one "scans on one stream, tails on a second" SRE_BENCH_STREAMS=tail
+one "... and three steps in flight" SRE_BENCH_STREAMS=tail SRE_BENCH_DEPTH=3
+one "default again" A=1
+done
