@@ -116,7 +116,8 @@ def workload_spec(name, S, nbytes, rank=0, world=1):
         tails = [(b" a@abc.cc " if g % 2 == 0 else b"aaabbccb") for g in mine]
         lens = [S.gen_data_length(per, len(t)) for t in tails]
         text = ("configs[4] shape: %d streams x 64 MiB per GPU (round-robin over %d GPUs), "
-                "/[a-z]+@[a-z]+\\.[a-z]+/ Pike, RCCL all-reduce of match counts" % (nstreams, world))
+                "/[a-z]+@[a-z]+\\.[a-z]+/ Pike, %s all-reduce of match counts"
+                % (nstreams, world, "RCCL" if os.environ.get("SRE_BENCH_BACKEND", "nccl") == "nccl" else os.environ["SRE_BENCH_BACKEND"]))
     else:
         tail = b"aaabbccb"
         text = "configs[1]: /[a-z]+@[a-z]+\\.[a-z]+/ Pike first-match + captures"
