@@ -5,6 +5,11 @@
 #   SRE_HIP_NO_SHADOW    no shadow rows (stable-stretch tracking off)
 #   SRE_BENCH_STREAMS    bench.py: tail (default) | two | one, see measure()
 #   SREGEX_AMD_LIB       another build of the library (an older commit, another tile layout)
+#   SRE_BENCH_DEPTH      bench.py: scanners (steps) in flight, default 2
+#   SRE_BENCH_TRACE      bench.py: per-step wall times of every run to stderr
+#   SRE_HIP_DMA_UPLOAD   stream descriptors of a batch by hipMemcpyAsync instead of a kernel
+#   SRE_HIP_NO_PULL      compat API: pinned staging buffer copied by the DMA engine, not pulled by a kernel
+#   SRE_HIP_NO_WIDE4     COUNT with 4 class bits: 8-bit tile indices
 one() {
   local name=$1; shift
   local out
