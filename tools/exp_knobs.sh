@@ -3,7 +3,7 @@
 #   SRE_HIP_LDS_PAD      extra dynamic LDS per workgroup (fewer workgroups per CU)
 #   SRE_HIP_SEG_BYTES    segment size;  SRE_HIP_SEG_CAP  largest segment the automatic choice makes
 #   SRE_HIP_NO_SHADOW    no shadow rows (stable-stretch tracking off)
-#   SRE_BENCH_STREAMS    bench.py: tail (default) | two | one, see measure()
+#   SRE_BENCH_STREAMS    bench.py: two (default for one stream) | one (default for many) | tail, see measure()
 #   SREGEX_AMD_LIB       another build of the library (an older commit, another tile layout)
 #   SRE_BENCH_DEPTH      bench.py: scanners (steps) in flight, default 2
 #   SRE_BENCH_TRACE      bench.py: per-step wall times of every run to stderr
