@@ -197,7 +197,8 @@ typedef struct {
     int64_t  ev_in_chunk;       /* a match event happened inside this chunk (sre_vm_pike.c:586-601) */
     int64_t  poisoned;          /* match returned with threads still listed at eof (:616-622) */
     int64_t  next_state;        /* host shadow of sre_stream_ctx_t.state */
-    int64_t  pad;
+    int64_t  ev_slot1;          /* ev_in_chunk: slot 1 of that match's internal vector (the end of a match of
+                                   regex 0, else -1): what last_matched_pos holds when the call returns */
     int64_t  ov[SRE_STREAM_MAX_SLOTS];
 } sre_stream_result_t;
 

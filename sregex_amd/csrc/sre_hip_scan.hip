@@ -2332,6 +2332,7 @@ sre_k_stream_tail(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
 
     res->has_pending = 0;
     res->ev_in_chunk = 0;
+    res->ev_slot1 = -1;
     res->poisoned = 0;
     res->next_state = 0;
     if (!st.done) {
@@ -2443,6 +2444,7 @@ sre_k_stream_tail(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
         ctx->pending_regex = st.rc;
         for (uint32_t q = 0; q < T.nslots; q++) ctx->pending_vec[q] = vec[q];
         res->ev_in_chunk = 1;
+        res->ev_slot1 = vec[1];
     }
 
     /* ---- is the search over? */

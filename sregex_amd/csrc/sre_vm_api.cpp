@@ -496,6 +496,18 @@ pike_stream_route(sre_vm_pike_ctx_t *ctx, sre_char *input, size_t len, unsigned 
     const sre_int_t            rc = (sre_int_t) res->rc;
     ctx->empty_capture = 0;
     ctx->at_boundary = 0;
+    /* What EVERY call does on its way out (sre_vm_pike.c:586-601), SRE_AGAIN included: a MATCH
+     * reached during this call — pending or final — that ends behind the call's first byte
+     * refreshes seen_newline / seen_word from the byte in front of its end (last_matched_pos =
+     * slot 1 of the internal vector: a match of regex 0 only).  The next chunk's look-ahead
+     * threads go by these flags (sre_dfa.h `rekind`). */
+    if (res->ev_in_chunk && res->ev_slot1 >= 0) {
+        const sre_int_t p = (sre_int_t) res->ev_slot1 - ctx->processed_bytes;      /* chunk-relative end */
+        if (p > 0 && (size_t) p <= len) {
+            ctx->seen_newline = input[p - 1] == '\n';
+            ctx->seen_word = sre_isword(input[p - 1]);
+        }
+    }
     if (rc == SRE_AGAIN) {
         for (size_t k = 0; k < ctx->ovec_slots && k < 2; k++) ctx->ovector[k] = (sre_int_t) res->ov[k];
         if (pending_matched) {
@@ -521,13 +533,6 @@ pike_stream_route(sre_vm_pike_ctx_t *ctx, sre_char *input, size_t len, unsigned 
         return 1;
     }
     for (size_t k = 0; k < ctx->ovec_slots; k++) ctx->ovector[k] = (sre_int_t) res->ov[k];
-    if (rc == 0 && res->ev_in_chunk) {                      /* :586-601 */
-        const sre_int_t p = ctx->ovector[1] - ctx->processed_bytes;
-        if (p > 0) {
-            ctx->seen_newline = input[p - 1] == '\n';
-            ctx->seen_word = sre_isword(input[p - 1]);
-        }
-    }
     if (res->poisoned) ctx->eof = 1;                         /* :616-622 */
     ctx->processed_bytes = ctx->ovector[1];                  /* :624-628 */
     ctx->empty_capture = (ctx->ovector[0] == ctx->ovector[1]);

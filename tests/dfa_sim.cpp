@@ -30,13 +30,48 @@ struct Search {
 /* one reference exec(): from `sp` (first byte processed) with initial list
  * `variant`, until the list dies or end of input; records the state before
  * every position in `trace` (trace[p - sp]). */
+/* What every exec() call does before it returns (sre_vm_pike.c:586-601): if a MATCH was reached
+ * during THIS call — pending or final — and it ends behind the call's first byte, the context's
+ * seen_newline / seen_word become the kinds of the byte in front of that end (slot 1 of the
+ * internal vector: a match of regex 0 only). */
+struct CtxFlags {
+    bool seen_newline = false, seen_word = false;
+    void end_of_call(const uint8_t *data, int64_t call_start, int64_t ev_end)
+    {
+        if (ev_end > call_start) {
+            const uint8_t c = data[ev_end - 1];
+            seen_newline = c == '\n';
+            seen_word = (c >= '0' && c <= '9') || (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z') || c == '_';
+        }
+    }
+    int kinds() const { return seen_newline ? 1 : seen_word ? 2 : 0; }
+};
+
+/* one search: from `sp` (first byte processed) with initial list `variant`, until the list dies
+ * or end of input; records the state before every position in `trace` (trace[p - sp]).
+ * feed > 0: the stream arrives in exec() calls of `feed` bytes, the first of them starting at
+ * `first` (<= sp): in front of the first byte of every later call the list becomes what a chunk
+ * boundary makes of it — a travelling skip ends (sre_dfa.h `unskip`), and look-ahead threads
+ * see the context's flags (`rekind`), which every call refreshes on its way out. */
 Search run_search(const sre_dfa_t *d, const uint8_t *data, int64_t n, int64_t sp, int variant,
-                  std::vector<uint32_t> *trace)
+                  std::vector<uint32_t> *trace, int64_t first, int64_t feed, CtxFlags *flags,
+                  bool init_lists_match0 = false)
 {
     Search   r = {false, -5, sp, -1, 0, 0};
     uint32_t s = d->init[variant];
+    /* (a MATCH thread that the initial closure merely LISTS already counts as reached, :889-899:
+     * it matters when the first call ends behind the byte an empty match made it skip) */
+    int64_t  call_start = first, ev_end = init_lists_match0 ? sp : -1;
     if (trace) trace->clear();
     for (int64_t p = sp; p <= n; p++) {
+        if (feed > 0 && p > first && p < n && (p - first) % feed == 0 && s != SRE_DFA_DEAD) {
+            flags->end_of_call(data, call_start, ev_end);
+            call_start = p;
+            ev_end = -1;
+            s = d->unskip[s];
+            if (!d->rekind.empty()) s = d->rekind[3 * (size_t) s + (size_t) flags->kinds()];
+            r.poisoned = false;     /* the skip ended with the chunk: the next call runs its own check */
+        }
         if (s == SRE_DFA_DEAD) break;
         if (p == n && r.poisoned) break;       /* "if (sp == last) break" at :304-306 */
         uint32_t sym = p < n ? d->cls_map[data[p]] : d->ncls;
@@ -48,10 +83,12 @@ Search run_search(const sre_dfa_t *d, const uint8_t *data, int64_t n, int64_t sp
             r.ev_pos = p;
             r.ev_state = s;
             r.ev_sym = sym;
+            ev_end = t.ev_regex == 0 ? (t.ev_kind == SRE_DFA_EV_DONE ? p + 1 : p) : -1;
         }
         s = t.next;
         r.term = p;
     }
+    flags->end_of_call(data, call_start, ev_end);      /* the call that returns the result */
     return r;
 }
 
@@ -119,6 +156,12 @@ void *dfa_sim_build(const sre_program_t *prog, uint32_t max_states, const char *
     return sre_dfa_build(prog, max_states, why);
 }
 
+/* ... with the states a chunk boundary makes of look-ahead lists (sre_dfa_build2) */
+void *dfa_sim_build_chunked(const sre_program_t *prog, uint32_t max_states, const char **why)
+{
+    return sre_dfa_build2(prog, max_states, 1, why);
+}
+
 void dfa_sim_free(void *d) { sre_dfa_free(static_cast<sre_dfa_t *>(d)); }
 
 uint32_t dfa_sim_nstates(void *d) { return static_cast<sre_dfa_t *>(d)->nstates; }
@@ -131,14 +174,32 @@ int dfa_sim_has_lookahead(void *d) { return static_cast<sre_dfa_t *>(d)->has_loo
  * logical context.  Writes per match: regex id + ovector[nov] (caller slices of
  * the internal vector, as sre_vm_pike.c:945-989).  Returns the match count.
  */
+static int64_t findall_impl(void *dv, const sre_program_t *prog, const uint8_t *data, int64_t n,
+                            int64_t *out, int64_t nov, int64_t max_matches, int64_t feed);
+
 int64_t dfa_sim_findall(void *dv, const sre_program_t *prog, const uint8_t *data, int64_t n,
                         int64_t *out, int64_t nov, int64_t max_matches)
+{
+    return findall_impl(dv, prog, data, n, out, nov, max_matches, 0);
+}
+
+/* the same iteration with every search fed in exec() calls of `feed` bytes (the caller re-feeds
+ * from the match end, so the calls of a later search start there) */
+int64_t dfa_sim_findall_chunked(void *dv, const sre_program_t *prog, const uint8_t *data, int64_t n,
+                                int64_t *out, int64_t nov, int64_t max_matches, int64_t feed)
+{
+    return findall_impl(dv, prog, data, n, out, nov, max_matches, feed);
+}
+
+static int64_t findall_impl(void *dv, const sre_program_t *prog, const uint8_t *data, int64_t n,
+                            int64_t *out, int64_t nov, int64_t max_matches, int64_t feed)
 {
     const sre_dfa_t      *d = static_cast<sre_dfa_t *>(dv);
     std::vector<uint32_t> trace;
     std::vector<int64_t>  vec(d->nslots + 1);
     int64_t               count = 0, chunk = 0;
-    bool                  empty_capture = false, seen_newline = false, seen_word = false, ctx_eof = false;
+    bool                  empty_capture = false, ctx_eof = false;
+    CtxFlags              flags;
     auto isword = [](uint8_t c) { return (c >= '0' && c <= '9') || (c >= 'a' && c <= 'z') || (c >= 'A' && c <= 'Z') || c == '_'; };
     /* a re-armed search: ^ from seen_newline, \b / \B from seen_word (sre_vm_pike.c:472-473, 586-601) */
     auto rearmed = [&](bool nl, bool word) {
@@ -156,9 +217,17 @@ int64_t dfa_sim_findall(void *dv, const sre_program_t *prog, const uint8_t *data
         } else if (chunk == 0) {
             variant = SRE_DFA_INIT_START;
         } else {
-            variant = rearmed(seen_newline, seen_word);
+            variant = rearmed(flags.seen_newline, flags.seen_word);
         }
-        Search r = run_search(d, data, n, sp, variant, &trace);
+        bool init_match0 = false;
+        {
+            const uint32_t s0 = d->init[variant];
+            for (uint32_t q = d->list_off[s0]; q < d->list_off[s0 + 1]; q++) {
+                const sre_insn_t &in = prog->insns[d->list_pcs[q]];
+                if (in.opcode == SRE_OP_MATCH && in.arg == 0) init_match0 = true;
+            }
+        }
+        Search r = run_search(d, data, n, sp, variant, &trace, chunk, feed, &flags, init_match0);
         if (r.rc < 0) break;
         captures(d, data, sp, variant, r, trace, vec.data());
 
@@ -170,11 +239,7 @@ int64_t dfa_sim_findall(void *dv, const sre_program_t *prog, const uint8_t *data
         rec[0] = r.rc;
         for (int64_t k = 0; k < nov; k++) rec[1 + k] = k < ncopy ? vec[ofs + k] : -1;
 
-        /* :586-601 — flags for the next search come from slot 1 of the match */
-        if (vec[1] >= 0 && vec[1] > chunk) {
-            seen_newline = data[vec[1] - 1] == '\n';
-            seen_word = isword(data[vec[1] - 1]);
-        }
+        /* (:586-601: the flags for the next search were refreshed by the returning call, run_search) */
         int64_t start = vec[ofs], end = vec[ofs + 1];
         empty_capture = (start == end);
         /* what the COUNT scan goes by instead of captures: the event transition's own flag */
@@ -190,7 +255,8 @@ int64_t dfa_sim_findall(void *dv, const sre_program_t *prog, const uint8_t *data
 int64_t dfa_sim_thompson(void *dv, const uint8_t *data, int64_t n)
 {
     const sre_dfa_t *d = static_cast<sre_dfa_t *>(dv);
-    Search           r = run_search(d, data, n, 0, SRE_DFA_INIT_START, NULL);
+    CtxFlags         fl;
+    Search           r = run_search(d, data, n, 0, SRE_DFA_INIT_START, NULL, 0, 0, &fl);
     return r.rc >= 0 ? 0 : -5;
 }
 

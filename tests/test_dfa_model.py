@@ -39,6 +39,10 @@ def sim(lib):
     L.dfa_sim_has_lookahead.restype = ctypes.c_int
     L.dfa_sim_findall.restype = _i64
     L.dfa_sim_findall.argtypes = [_vp, _vp, ctypes.c_char_p, _i64, ctypes.POINTER(_i64), _i64, _i64]
+    L.dfa_sim_build_chunked.restype = _vp
+    L.dfa_sim_build_chunked.argtypes = [_vp, ctypes.c_uint32, ctypes.POINTER(ctypes.c_char_p)]
+    L.dfa_sim_findall_chunked.restype = _i64
+    L.dfa_sim_findall_chunked.argtypes = [_vp, _vp, ctypes.c_char_p, _i64, ctypes.POINTER(_i64), _i64, _i64, _i64]
     L.dfa_sim_thompson.restype = _i64
     L.dfa_sim_thompson.argtypes = [_vp, ctypes.c_char_p, _i64]
     return L
@@ -206,6 +210,70 @@ def test_model_random_patterns_vs_oracle(sim):
                     assert sim.dfa_sim_thompson(d, data, len(data)) == th, (pats, data)
             sim.dfa_sim_free(d)
     assert built > 300, built
+
+
+def _oracle_fed_in_chunks(ora, prog, ncaps, data, feed, limit=400):
+    """the find-all iteration with every exec() call at most `feed` bytes long, as a caller of
+    the streaming API makes it: on a match, re-feed from the match end"""
+    nov = 2 * (ncaps + 1)
+    ctx, off, found = ora.pike(prog, ncaps), 0, []
+    while len(found) < limit:
+        end = min(off + feed, len(data))
+        rc = ctx.exec(data[off:end], end == len(data), want_pending=False)
+        if rc == S.SRE_AGAIN:
+            off = end
+            continue
+        if rc < 0:
+            if rc == S.SRE_ERROR:
+                found.append([S.SRE_ERROR])
+            break
+        found.append([rc] + list(ctx.ovector[:nov]))
+        off = ctx.ovector[1]
+    ctx.close()
+    return found
+
+
+def test_model_chunked_feeding_vs_oracle(sim):
+    """A stream that arrives in chunks: at a chunk boundary a travelling leading-byte skip ends
+    and the look-ahead threads of the list see the context's seen_newline / seen_word instead
+    of the byte in front (sre_vm_pike.c:472-473, 492, 851-860, 866-880) — `unskip` and `rekind`
+    of the chunked automaton (sre_dfa_build2), against the oracle fed the same way, down to
+    one byte per call."""
+    ora = harness.OracleEngine()
+    rng = random.Random(int(os.environ.get("SRE_FUZZ_SEED", "77")))
+    zoo = [[rb"\bab\b"], [rb"(a+)$"], [rb"(\w+)\b(.)"], [rb"c\B(.)"], [rb"^(\w+) \b"], [rb"x*\b y"], [rb"\b"], [rb"\B"],
+           [rb"(a|\b)(\B|b)c?"], [rb"$\n^a"], [rb"(\s*)\b([a-c]+)\B"], [rb"\b\b(a)"], [rb"(?:$|a)(b|\b)"], [rb"a.*?\bb"],
+           [rb"[a-z]+@[a-z]+"], [rb"(a+)(b+)?"], [rb"^b+"], [rb"x(.*)y"]]
+    zoo += [[harness.random_regex(rng)] for _ in range(150)]
+    alphabet = b"ab c\n_x.y@"
+    built = compared = 0
+    for pats in zoo:
+        with S.Pool() as pool:
+            try:
+                re = S.parse(pool, pats)
+            except Exception:
+                continue
+            prog = S.compile(pool, re)
+            why = ctypes.c_char_p()
+            d = sim.dfa_sim_build_chunked(prog.h, 4096, ctypes.byref(why))
+            if not d:
+                continue
+            built += 1
+            nov = 2 * (re.ncaps + 1)
+            for _ in range(6):
+                data = bytes(rng.choice(alphabet) for _ in range(rng.choice([0, 1, 2, 9, 30, 70])))
+                feed = rng.choice([1, 2, 3, 7, 20])
+                want = _oracle_fed_in_chunks(ora, prog, re.ncaps, data, feed)
+                if want and want[-1] == [S.SRE_ERROR]:
+                    continue            # (a poisoned context: the iteration protocol ends differently)
+                cap = len(data) + 2
+                out = (_i64 * (cap * (nov + 1)))()
+                n = sim.dfa_sim_findall_chunked(d, prog.h, data, len(data), out, nov, cap, feed)
+                got = [list(out[i * (nov + 1):(i + 1) * (nov + 1)]) for i in range(max(n, 0))]
+                assert n >= 0 and got == want, (pats, data, feed, got[:4], want[:4])
+                compared += 1
+            sim.dfa_sim_free(d)
+    assert built > 120 and compared > 500, (built, compared)
 
 
 def test_builder_declines_what_it_cannot_model(sim):

@@ -526,6 +526,22 @@ def test_compat_api_chunked_streams_take_the_scanner(gpu):
                 assert res[0] == res[1], (pats, len(data), sizes, res)
                 eng.recycle()
     assert n == 4 * len(zoo)
+    # every call refreshes seen_newline / seen_word from a match reached DURING it, a pending one
+    # too (sre_vm_pike.c:586-601): here the pending "a" ends one byte before the end of the first
+    # chunk, and the \B / \b thread listed behind the blank is decided by the next chunk's first byte
+    for pats in ([rb"a(\s\B.)?"], [rb"a(\s\b.)?"], [rb"a(\n^b|\s\B\B.)?"]):
+        with S.Pool() as pool:
+            re = S.parse(pool, pats)
+            prog = S.compile(pool, re)
+            nov = 2 * (re.ncaps + 1)
+            for nxt in (b"b", b".", b"\n"):
+                for blank in (b" ", b"\n"):
+                    data = b"#" * 4094 + b"a" + blank + nxt + b"b# a b"
+                    for sizes in ([4096], [4096, 1], [4095, 1, 1], [4097]):
+                        want = _feed(ora.pike(prog, re.ncaps), data, sizes, nov)
+                        got = _feed(eng.pike(prog, re.ncaps), data, sizes, nov)
+                        assert got == want, (pats, nxt, blank, sizes, got, want)
+                        eng.recycle()
     # random patterns (all constructs, all assertions) over sparse subjects — filler bytes with
     # short bursts of the patterns' alphabet, so that searches live across several chunks
     taken = 0
