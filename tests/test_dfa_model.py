@@ -245,6 +245,9 @@ def test_model_chunked_feeding_vs_oracle(sim):
            [rb"(a|\b)(\B|b)c?"], [rb"$\n^a"], [rb"(\s*)\b([a-c]+)\B"], [rb"\b\b(a)"], [rb"(?:$|a)(b|\b)"], [rb"a.*?\bb"],
            [rb"[a-z]+@[a-z]+"], [rb"(a+)(b+)?"], [rb"^b+"], [rb"x(.*)y"]]
     zoo += [[harness.random_regex(rng)] for _ in range(150)]
+    # several regexes: the flags follow slot 1 of the internal vector, i.e. matches of regex 0 only
+    zoo += [[harness.random_regex(rng) for _ in range(rng.randrange(2, 4))] for _ in range(50)]
+    zoo += [[rb"a$", rb"\bb"], [rb"x", rb"\Bb\B"], [rb"^b", rb"a\n"], [rb"(a$)|(\n^b)", rb"\b."]]
     alphabet = b"ab c\n_x.y@"
     built = compared = 0
     for pats in zoo:
@@ -273,7 +276,7 @@ def test_model_chunked_feeding_vs_oracle(sim):
                 assert n >= 0 and got == want, (pats, data, feed, got[:4], want[:4])
                 compared += 1
             sim.dfa_sim_free(d)
-    assert built > 120 and compared > 500, (built, compared)
+    assert built > 150 and compared > 650, (built, compared)
 
 
 def test_builder_declines_what_it_cannot_model(sim):
