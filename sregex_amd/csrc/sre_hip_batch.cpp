@@ -923,7 +923,7 @@ hip_failed:
     return -1;
 }
 
-/* can chunks of a stream go through this scanner?  (the carried state has room for 16
+/* can chunks of a stream go through this scanner?  (the carried state has room for 64
  * threads of 64 capture slots) */
 extern "C" int
 sre_hip_scanner_streams(sre_hip_scanner_t *sc)

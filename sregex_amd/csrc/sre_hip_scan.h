@@ -173,7 +173,7 @@ typedef struct {
  * list is the automaton state, and every listed thread's capture vector is carried by
  * value, resolved at the end of each chunk by the backward lineage walk.
  */
-#define SRE_STREAM_MAX_THREADS 16u
+#define SRE_STREAM_MAX_THREADS 64u      /* threads of the carried list (BASELINE configs[2]: 37) */
 #define SRE_STREAM_MAX_SLOTS   64u
 typedef struct {
     uint32_t state;             /* automaton state in front of the next byte; 0: no search under way */

@@ -526,6 +526,22 @@ def test_compat_api_chunked_streams_take_the_scanner(gpu):
                 assert res[0] == res[1], (pats, len(data), sizes, res)
                 eng.recycle()
     assert n == 4 * len(zoo)
+    # a long thread list carried from chunk to chunk: BASELINE configs[2] (12 regexes, 37 list-able
+    # threads) over a subject that keeps the search alive across several chunks
+    with S.Pool() as pool:
+        re = S.parse(pool, cfg3)
+        prog = S.compile(pool, re)
+        nov = 2 * (re.ncaps + 1)
+        for data in (b"#" * 9000 + b"e" + b"#" * 3000 + b"ef#gh BLAH", b"#" * 5000 + b"g" + b"#" * 4500 + b"BLA" + b"#" * 100 + b"abcd",
+                     b"#" * 13000):
+            for sizes in ([4096, 4096, 1000, 1, 4096], [5000, 7000], [4096] * 6):
+                want = _feed(ora.pike(prog, re.ncaps), data, sizes, nov)
+                before = S.compat_route_counts()
+                got = _feed(eng.pike(prog, re.ncaps), data, sizes, nov)
+                after = S.compat_route_counts()
+                assert got == want, (len(data), sizes, got[-2:], want[-2:])
+                assert after[2] == before[2], (before, after)       # none of it on the exact VM
+                eng.recycle()
     # every call refreshes seen_newline / seen_word from a match reached DURING it, a pending one
     # too (sre_vm_pike.c:586-601): here the pending "a" ends one byte before the end of the first
     # chunk, and the \B / \b thread listed behind the blank is decided by the next chunk's first byte
