@@ -370,13 +370,15 @@ sre_dfa_build2(const sre_program_t *prog, uint32_t max_states, int chunk_twins, 
              * and a \b / \B thread it lists starts from seen_word == 0 (:866-880); a LISTED \b / \B
              * thread kept its own seen_word, and at sp == input the context's flag is OR-ed to
              * either (:472-473, 492) */
-            if (rekind_of.size() < 3 * (size_t) (s + 1)) rekind_of.resize(3 * (size_t) (s + 1), 0);
+            if (rekind_of.size() < 4 * (size_t) (s + 1)) rekind_of.resize(4 * (size_t) (s + 1), 0);
             const std::vector<uint32_t> Lc = b.lists[s], vis = b.visited[s];
             const std::vector<uint8_t>  fr = b.fresh[s];
-            for (unsigned f = 0; f < 3; f++) {
-                rekind_of[3 * (size_t) s + f] =
+            for (unsigned f = 0; f < 4; f++) {
+                /* f == 3: the Thompson VM, whose \A / ^ / \b hold "at the start of the buffer" of
+                 * every call (sre_vm_thompson.c:302-317, 320-325) and which has no context flags */
+                rekind_of[4 * (size_t) s + f] =
                     b.holds_lookahead(Lc) ? b.intern_raw(Lc, d->matched[s] != 0, b.sss[s], b.variant[s],
-                                                         f == 1 ? PREV_NL : f == 2 ? PREV_WORD : 0,
+                                                         f == 1 ? PREV_NL : f == 2 ? PREV_WORD : f == 3 ? PREV_START : 0,
                                                          b.prevw[s] != 0 || f == 2, vis, fr)
                                           : s;
             }
@@ -534,7 +536,7 @@ sre_dfa_build2(const sre_program_t *prog, uint32_t max_states, int chunk_twins, 
     }
     d->unskip = unskip_of;
     if (chunk_twins) {
-        rekind_of.resize(3 * (size_t) d->nstates, 0);
+        rekind_of.resize(4 * (size_t) d->nstates, 0);
         d->rekind = rekind_of;
     }
     d->seen_start = b.sss;

@@ -88,12 +88,13 @@ struct sre_dfa_s {
                                                 initial-state check (sre_vm_pike.c:304-306, then :256-273 again):
                                                 same list, seen_start == 1.  Identity elsewhere. */
 
-    std::vector<uint32_t>        rekind;     /* [nstates][3], only when built with chunk twins: a look-ahead
+    std::vector<uint32_t>        rekind;     /* [nstates][4], only when built with chunk twins: a look-ahead
                                                 splice at the FIRST byte of a chunk does not see the byte in
                                                 front of it but the context's flags (\b / \B: seen_word,
                                                 sre_vm_pike.c:472-473; ^ / \A inside the splice: seen_newline,
                                                 :851-860) — the state a chunk boundary turns this one into when
-                                                the context says 0: neither, 1: seen_newline, 2: seen_word.
+                                                the context says 0: neither, 1: seen_newline, 2: seen_word; 3: the
+                                                Thompson VM (no flags: "start of the buffer" at every call).
                                                 Same list, same marks; identity for lists without look-ahead. */
 
     const sre_dfa_trans_t &t(uint32_t s, uint32_t sym) const { return trans[(size_t) s * (ncls + 1) + sym]; }

@@ -195,12 +195,12 @@ sre_hip_scanner_create_chunked(sre_pool_t *pool, sre_program_t *prog, int mode)
 }
 
 /* the entry state of the next chunk: `state` is what the previous chunk's tail reported,
- * flags = the context's 0: neither, 1: seen_newline, 2: seen_word */
+ * flags = the context's 0: neither, 1: seen_newline, 2: seen_word; 3: sre_vm_thompson_exec */
 extern "C" uint32_t
 sre_hip_scanner_chunk_entry(sre_hip_scanner_t *sc, uint32_t state, int flags)
 {
-    if (sc->dfa == NULL || sc->dfa->rekind.empty() || state >= sc->dfa->nstates || flags < 0 || flags > 2) return state;
-    return sc->dfa->rekind[3 * (size_t) state + (size_t) flags];
+    if (sc->dfa == NULL || sc->dfa->rekind.empty() || state >= sc->dfa->nstates || flags < 0 || flags > 3) return state;
+    return sc->dfa->rekind[4 * (size_t) state + (size_t) flags];
 }
 
 static sre_hip_scanner_t *

@@ -25,8 +25,8 @@ struct sre_hip_program_s {
     struct sre_dfa_s *dfa_thompson;
     int         dfa_pike_tried, dfa_thompson_tried;
     /* throughput scanners of the compat path (sre_vm_api.cpp), [0] Thompson [1] Pike first match */
-    struct sre_hip_scanner_s *compat_scanner[3];     /* Thompson, Pike first match, Pike chunked (look-ahead programs) */
-    int         compat_tried[3];
+    struct sre_hip_scanner_s *compat_scanner[4];     /* Thompson, Pike first match, and their chunked forms (look-ahead programs) */
+    int         compat_tried[4];
 };
 
 #ifdef __cplusplus

@@ -315,7 +315,7 @@ compat_scanner(sre_program_t *prog, int mode, int chunked = 0)
     if (dp == NULL) return NULL;
     /* chunked: the automaton of a look-ahead program whose stream arrives in chunks (other
      * programs: the ordinary one) */
-    const int slot = chunked ? 2 : mode == SRE_HIP_THOMPSON ? 0 : 1;
+    const int slot = (chunked ? 2 : 0) + (mode == SRE_HIP_THOMPSON ? 0 : 1);
     if (!dp->compat_tried[slot]) {
         dp->compat_tried[slot] = 1;
         sre_hip_scanner_t *sc = chunked ? sre_hip_scanner_create_chunked(prog->pool, prog, mode)
@@ -650,12 +650,14 @@ struct sre_vm_thompson_ctx_s {
     /* a stream fed in chunks on the scanner: the list travels as the automaton state */
     int            stream_mode, finished;
     uint32_t       stream_state;
+    sre_hip_scanner_t *stream_scanner;  /* look-ahead programs: the chunked automaton's scanner */
+    int            stream_scanner_tried;
 };
 
 /* One chunk of a chunked stream (sre_vm_thompson.c:63-270) on the scanner.  Without
  * look-ahead assertions no closure runs at the first byte of a later chunk, so the
  * chunk-local \A / ^ of this VM (:302-317) cannot be observed and the whole-buffer
- * automaton is exact; look-ahead programs stay on the exact VM kernel. */
+ * automaton is exact; with them the chunked automaton is (see below). */
 static int
 thompson_stream_route(sre_vm_thompson_ctx_t *ctx, sre_char *input, size_t len, unsigned eof, sre_int_t *prc)
 {
@@ -663,7 +665,18 @@ thompson_stream_route(sre_vm_thompson_ctx_t *ctx, sre_char *input, size_t len, u
         ctx->scanner_tried = 1;
         ctx->scanner = compat_scanner(ctx->prog, SRE_HIP_THOMPSON);
     }
-    if (ctx->scanner == NULL || !sre_hip_scanner_streams(ctx->scanner) || ctx->prog->lookahead_asserts) return 0;
+    /* look-ahead programs: \A, ^ and the word flag of \b / \B are local to the buffer of a call in
+     * this VM (sre_vm_thompson.c:302-325): their chunks run on the chunked automaton, entered
+     * through its "start of the buffer" boundary kind (sre_dfa.h `rekind`, 3) */
+    sre_hip_scanner_t *sc = ctx->scanner;
+    if (ctx->prog->lookahead_asserts) {
+        if (!ctx->stream_scanner_tried) {
+            ctx->stream_scanner_tried = 1;
+            ctx->stream_scanner = compat_scanner(ctx->prog, SRE_HIP_THOMPSON, 1);
+        }
+        sc = ctx->stream_scanner;
+    }
+    if (sc == NULL || !sre_hip_scanner_streams(sc)) return 0;
     DeviceStream *ds = ctx->ds;
     if (ds->d_sctx == NULL) {
         if (hipMalloc(reinterpret_cast<void **>(&ds->d_sctx), sizeof(sre_stream_ctx_t)) != hipSuccess
@@ -676,7 +689,8 @@ thompson_stream_route(sre_vm_thompson_ctx_t *ctx, sre_char *input, size_t len, u
     }
     if (stage_input(ds, input, len) != 0) return 0;
     ds->h_sres->rc = SRE_STREAM_PENDING;
-    if (sre_hip_scan_stream_chunk(ctx->scanner, ds->d_in, len, 0, ctx->stream_mode, ctx->stream_state, eof ? 1 : 0, 0,
+    if (sre_hip_scan_stream_chunk(sc, ds->d_in, len, 0, ctx->stream_mode,
+                                  ctx->stream_mode ? sre_hip_scanner_chunk_entry(sc, ctx->stream_state, 3) : 0u, eof ? 1 : 0, 0,
                                   ds->d_sctx, ds->d_sres, ds->h_sres, 0, ds->stream) != 0)
     {
         ds->failed = 1;

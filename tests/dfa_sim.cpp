@@ -55,7 +55,7 @@ struct CtxFlags {
  * see the context's flags (`rekind`), which every call refreshes on its way out. */
 Search run_search(const sre_dfa_t *d, const uint8_t *data, int64_t n, int64_t sp, int variant,
                   std::vector<uint32_t> *trace, int64_t first, int64_t feed, CtxFlags *flags,
-                  bool init_lists_match0 = false)
+                  bool init_lists_match0 = false, bool thompson = false)
 {
     Search   r = {false, -5, sp, -1, 0, 0};
     uint32_t s = d->init[variant];
@@ -69,7 +69,7 @@ Search run_search(const sre_dfa_t *d, const uint8_t *data, int64_t n, int64_t sp
             call_start = p;
             ev_end = -1;
             s = d->unskip[s];
-            if (!d->rekind.empty()) s = d->rekind[3 * (size_t) s + (size_t) flags->kinds()];
+            if (!d->rekind.empty()) s = d->rekind[4 * (size_t) s + (size_t) (thompson ? 3 : flags->kinds())];
             r.poisoned = false;     /* the skip ended with the chunk: the next call runs its own check */
         }
         if (s == SRE_DFA_DEAD) break;
@@ -257,6 +257,15 @@ int64_t dfa_sim_thompson(void *dv, const uint8_t *data, int64_t n)
     const sre_dfa_t *d = static_cast<sre_dfa_t *>(dv);
     CtxFlags         fl;
     Search           r = run_search(d, data, n, 0, SRE_DFA_INIT_START, NULL, 0, 0, &fl);
+    return r.rc >= 0 ? 0 : -5;
+}
+
+/* ... fed in calls of `feed` bytes: this VM's \A / ^ / \b are local to the buffer of a call */
+int64_t dfa_sim_thompson_chunked(void *dv, const uint8_t *data, int64_t n, int64_t feed)
+{
+    const sre_dfa_t *d = static_cast<sre_dfa_t *>(dv);
+    CtxFlags         fl;
+    Search           r = run_search(d, data, n, 0, SRE_DFA_INIT_START, NULL, 0, feed, &fl, false, true);
     return r.rc >= 0 ? 0 : -5;
 }
 

@@ -43,6 +43,8 @@ def sim(lib):
     L.dfa_sim_build_chunked.argtypes = [_vp, ctypes.c_uint32, ctypes.POINTER(ctypes.c_char_p)]
     L.dfa_sim_findall_chunked.restype = _i64
     L.dfa_sim_findall_chunked.argtypes = [_vp, _vp, ctypes.c_char_p, _i64, ctypes.POINTER(_i64), _i64, _i64, _i64]
+    L.dfa_sim_thompson_chunked.restype = _i64
+    L.dfa_sim_thompson_chunked.argtypes = [_vp, ctypes.c_char_p, _i64, _i64]
     L.dfa_sim_thompson.restype = _i64
     L.dfa_sim_thompson.argtypes = [_vp, ctypes.c_char_p, _i64]
     return L
@@ -277,6 +279,51 @@ def test_model_chunked_feeding_vs_oracle(sim):
                 compared += 1
             sim.dfa_sim_free(d)
     assert built > 150 and compared > 650, (built, compared)
+
+
+def test_model_thompson_chunked_feeding_vs_oracle(sim):
+    """sre_vm_thompson_exec in chunks: \\A, ^ and the word flag of \\b / \\B are local to the buffer
+    of a call (sre_vm_thompson.c:302-325) — a splice at the first byte of a later call sees "the
+    start of the buffer".  The chunked automaton's fourth boundary kind, against the oracle."""
+    ora = harness.OracleEngine()
+    rng = random.Random(int(os.environ.get("SRE_FUZZ_SEED", "78")))
+    zoo = [[rb"\bab\b"], [rb"(a+)$"], [rb"c\B(.)"], [rb"$\Aa"], [rb"$^b"], [rb"\b\Ab"], [rb"a\b\Bc"], [rb"x*\b y"],
+           [rb"(?:$|a)(b|\b)"], [rb"\B\Ax"], [rb"a$\n^b"], [rb"\Aab|\n^b"]]
+    zoo += [[harness.random_regex(rng)] for _ in range(200)]
+    alphabet = b"ab c\n_x.y"
+    built = compared = differ = 0
+    for pats in zoo:
+        with S.Pool() as pool:
+            try:
+                re = S.parse(pool, pats)
+            except Exception:
+                continue
+            prog = S.compile(pool, re)
+            why = ctypes.c_char_p()
+            d = sim.dfa_sim_build_chunked(prog.h, 4096, ctypes.byref(why))
+            if not d:
+                continue
+            built += 1
+            for _ in range(6):
+                data = bytes(rng.choice(alphabet) for _ in range(rng.choice([0, 1, 2, 9, 30])))
+                feed = rng.choice([1, 2, 3, 7])
+                t, off, rc = ora.thompson(prog), 0, S.SRE_AGAIN
+                while rc == S.SRE_AGAIN:
+                    end = min(off + feed, len(data))
+                    rc = t.exec(data[off:end], end == len(data))
+                    off = end
+                whole = ora.thompson(prog)
+                rc_whole = whole.exec(data, True)
+                whole.close()
+                t.close()
+                if rc == S.SRE_ERROR:
+                    continue            # the reference's list overflows here (oracle guard)
+                got = sim.dfa_sim_thompson_chunked(d, data, len(data), feed)
+                assert got == rc, (pats, data, feed, got, rc)
+                compared += 1
+                differ += rc != rc_whole
+            sim.dfa_sim_free(d)
+    assert built > 150 and compared > 700 and differ > 0, (built, compared, differ)
 
 
 def test_builder_declines_what_it_cannot_model(sim):

@@ -526,6 +526,30 @@ def test_compat_api_chunked_streams_take_the_scanner(gpu):
                 assert res[0] == res[1], (pats, len(data), sizes, res)
                 eng.recycle()
     assert n == 4 * len(zoo)
+    # ... where chunking changes this VM's answer: its \A / ^ / \b are local to the buffer of a call
+    before = S.compat_route_counts()
+    for pats, data, sizes in (([rb"$\A\nb"], b"#" * 5000 + b"\nb", [5000]), ([rb"\B\Ax"], b"_" * 4097 + b"x", [4097]),
+                              ([rb"a\B\bc"], b"#" * 4095 + b"ac", [4096]), ([rb"$^\nb"], b"#" * 4200 + b"\nb", [4200])):
+        with S.Pool() as pool:
+            re = S.parse(pool, pats)
+            prog = S.compile(pool, re)
+            res = []
+            for e in (ora, eng):
+                ctx, off, rcs, todo = e.thompson(prog), 0, [], list(sizes)
+                while True:
+                    k = min(todo.pop(0) if todo else len(data) - off, len(data) - off)
+                    rc = ctx.exec(data[off:off + k], off + k >= len(data) and not todo)
+                    rc = rc[0] if isinstance(rc, (list, tuple)) else rc
+                    rcs.append(rc)
+                    off += k
+                    if rc != S.SRE_AGAIN:
+                        break
+                res.append(rcs)
+            whole = ora.thompson(prog).exec(data, True)
+            assert res[0] == res[1] and res[0][-1] != whole, (pats, res, whole)
+            eng.recycle()
+    after = S.compat_route_counts()
+    assert after[2] == before[2] and after[1] > before[1], (before, after)      # on the scanner, none on the VM
     # a long thread list carried from chunk to chunk: BASELINE configs[2] (12 regexes, 37 list-able
     # threads) over a subject that keeps the search alive across several chunks
     with S.Pool() as pool:
