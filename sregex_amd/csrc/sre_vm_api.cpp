@@ -39,9 +39,11 @@ extern "C" uint32_t sre_hip_scanner_chunk_entry(sre_hip_scanner_t *sc, uint32_t 
  * the exact VM's ~1 us per byte is cheaper than the scanners' fixed launch cost
  * (profiles/r02_crossover.json) */
 #define SRE_COMPAT_SCAN_MIN_BYTES  16u
-/* a chunked stream starts on the scanner when its first chunk is at least this long
- * (byte-at-a-time feeding stays on the exact VM kernel) */
-#define SRE_COMPAT_STREAM_MIN_BYTES 4096u
+/* a chunked stream starts on the scanner when its first chunk is at least this long: a chunk
+ * costs the scanner ~60-110 us whatever its size, the exact VM kernel ~1 us per byte — and a
+ * stream that starts on the VM stays there.  (Byte-at-a-time feeding stays on the VM; the
+ * chunk-boundary model itself is exact down to one byte per call, tests/test_dfa_model.py.) */
+#define SRE_COMPAT_STREAM_MIN_BYTES 256u
 
 namespace {
 

@@ -473,7 +473,7 @@ def test_compat_api_chunked_streams_take_the_scanner(gpu):
                 else:
                     alpha = [b"abc", b"ab c\n.x@:/?y", b"aaaaab xy\nz"][trial - 3]
                     data = bytes(rng.choice(alpha) for _ in range(rng.choice([5000, 20000, 70000])))
-                first = rng.choice([4096, 5000, 8192, 30000])
+                first = rng.choice([256, 300, 1000, 4096, 5000, 8192, 30000])
                 sizes = [first] + [rng.choice([0, 1, 7, 64, 1000, 4096, 10000, 33333]) for _ in range(rng.randrange(0, 9))]
                 want = _feed(ora.pike(prog, re.ncaps), data, sizes, nov)
                 before = S.compat_route_counts()
@@ -507,7 +507,7 @@ def test_compat_api_chunked_streams_take_the_scanner(gpu):
                     data = bytes(rng.choice(alpha) for _ in range(rng.choice([5000, 20000, 70000])))
                     if trial == 3:
                         data = data.replace(b"a", b"d")     # mostly no match: AGAIN ... DECLINED
-                first = rng.choice([4096, 5000, 8192, 30000])
+                first = rng.choice([256, 1000, 4096, 5000, 8192, 30000])
                 sizes = [first] + [rng.choice([0, 1, 7, 64, 1000, 4096, 10000, 33333]) for _ in range(rng.randrange(0, 9))]
                 res = []
                 for e in (ora, eng):
@@ -604,7 +604,7 @@ def test_compat_api_chunked_streams_take_the_scanner(gpu):
                     burst = bytes(rng.choice(b"abcx \n_.") for _ in range(rng.randrange(1, 6)))
                     data[at:at + len(burst)] = burst
                 data = bytes(data[:rng.choice([9000, 30000])])
-                sizes = [rng.choice([4096, 4097, 6000])] + [rng.choice([0, 1, 2, 64, 1000, 4096, 5000]) for _ in range(rng.randrange(0, 7))]
+                sizes = [rng.choice([256, 257, 700, 4096, 4097, 6000])] + [rng.choice([0, 1, 2, 64, 1000, 4096, 5000]) for _ in range(rng.randrange(0, 7))]
                 want = _feed(ora.pike(prog, re.ncaps), data, sizes, nov)
                 before = S.compat_route_counts()
                 got = _feed(eng.pike(prog, re.ncaps), data, sizes, nov)
