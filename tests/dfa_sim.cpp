@@ -222,9 +222,11 @@ static int64_t findall_impl(void *dv, const sre_program_t *prog, const uint8_t *
         bool init_match0 = false;
         {
             const uint32_t s0 = d->init[variant];
+            /* (last_matched_pos is overwritten by every MATCH the closure lists, with slot 1 of
+             * that thread's vector: -1 unless it is regex 0's — the LAST one listed counts) */
             for (uint32_t q = d->list_off[s0]; q < d->list_off[s0 + 1]; q++) {
                 const sre_insn_t &in = prog->insns[d->list_pcs[q]];
-                if (in.opcode == SRE_OP_MATCH && in.arg == 0) init_match0 = true;
+                if (in.opcode == SRE_OP_MATCH) init_match0 = (in.arg == 0);
             }
         }
         Search r = run_search(d, data, n, sp, variant, &trace, chunk, feed, &flags, init_match0);
