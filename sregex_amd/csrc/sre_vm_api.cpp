@@ -652,14 +652,12 @@ struct sre_vm_thompson_ctx_s {
     /* a stream fed in chunks on the scanner: the list travels as the automaton state */
     int            stream_mode, finished;
     uint32_t       stream_state;
-    sre_hip_scanner_t *stream_scanner;  /* look-ahead programs: the chunked automaton's scanner */
-    int            stream_scanner_tried;
 };
 
 /* One chunk of a chunked stream (sre_vm_thompson.c:63-270) on the scanner.  Without
  * look-ahead assertions no closure runs at the first byte of a later chunk, so the
  * chunk-local \A / ^ of this VM (:302-317) cannot be observed and the whole-buffer
- * automaton is exact; with them the chunked automaton is (see below). */
+ * automaton is exact. */
 static int
 thompson_stream_route(sre_vm_thompson_ctx_t *ctx, sre_char *input, size_t len, unsigned eof, sre_int_t *prc)
 {
@@ -667,18 +665,16 @@ thompson_stream_route(sre_vm_thompson_ctx_t *ctx, sre_char *input, size_t len, u
         ctx->scanner_tried = 1;
         ctx->scanner = compat_scanner(ctx->prog, SRE_HIP_THOMPSON);
     }
-    /* look-ahead programs: \A, ^ and the word flag of \b / \B are local to the buffer of a call in
-     * this VM (sre_vm_thompson.c:302-325): their chunks run on the chunked automaton, entered
-     * through its "start of the buffer" boundary kind (sre_dfa.h `rekind`, 3) */
+    /* Look-ahead programs stay on the exact VM kernel: \A, ^ and the word flag of \b / \B are
+     * local to the buffer of a call in this VM (sre_vm_thompson.c:302-325), so a splice at the
+     * first byte of a later chunk lets threads through that the whole-buffer run never lists —
+     * and exactly there this VM's plain de-duplication (no SPLIT re-descent, splices appended
+     * at the END of the list, :226-230, :280-284) parts from the Pike automaton's: the chunked
+     * automaton's "start of the buffer" boundary kind (sre_dfa.h `rekind`, 3) reproduces the
+     * assertions but not that, found by the CPU model on a random pattern
+     * (tests/test_dfa_model.py).  Without look-ahead no closure runs at a chunk's first byte. */
     sre_hip_scanner_t *sc = ctx->scanner;
-    if (ctx->prog->lookahead_asserts) {
-        if (!ctx->stream_scanner_tried) {
-            ctx->stream_scanner_tried = 1;
-            ctx->stream_scanner = compat_scanner(ctx->prog, SRE_HIP_THOMPSON, 1);
-        }
-        sc = ctx->stream_scanner;
-    }
-    if (sc == NULL || !sre_hip_scanner_streams(sc)) return 0;
+    if (sc == NULL || !sre_hip_scanner_streams(sc) || ctx->prog->lookahead_asserts) return 0;
     DeviceStream *ds = ctx->ds;
     if (ds->d_sctx == NULL) {
         if (hipMalloc(reinterpret_cast<void **>(&ds->d_sctx), sizeof(sre_stream_ctx_t)) != hipSuccess
@@ -691,8 +687,7 @@ thompson_stream_route(sre_vm_thompson_ctx_t *ctx, sre_char *input, size_t len, u
     }
     if (stage_input(ds, input, len) != 0) return 0;
     ds->h_sres->rc = SRE_STREAM_PENDING;
-    if (sre_hip_scan_stream_chunk(sc, ds->d_in, len, 0, ctx->stream_mode,
-                                  ctx->stream_mode ? sre_hip_scanner_chunk_entry(sc, ctx->stream_state, 3) : 0u, eof ? 1 : 0, 0,
+    if (sre_hip_scan_stream_chunk(sc, ds->d_in, len, 0, ctx->stream_mode, ctx->stream_state, eof ? 1 : 0, 0,
                                   ds->d_sctx, ds->d_sres, ds->h_sres, 0, ds->stream) != 0)
     {
         ds->failed = 1;

@@ -284,54 +284,53 @@ def test_model_chunked_feeding_vs_oracle(sim):
 def test_model_thompson_chunked_feeding_vs_oracle(sim):
     """sre_vm_thompson_exec in chunks: \\A, ^ and the word flag of \\b / \\B are local to the buffer
     of a call (sre_vm_thompson.c:302-325) — a splice at the first byte of a later call sees "the
-    start of the buffer".  The chunked automaton's fourth boundary kind, against the oracle."""
+    start of the buffer".  The chunked automaton's fourth boundary kind reproduces that on a zoo of
+    assertion patterns, down to one byte per call.  It is NOT the whole story, which is why the
+    product keeps chunked Thompson streams of look-ahead programs on the exact VM kernel: where
+    those buffer-local assertions let a splice through, the Thompson VM's plain de-duplication
+    (no SPLIT re-descent, splices appended at the end of the list, :226-230, :280-284) lists
+    other threads than the Pike-ordered automaton — the last case below, found by running this
+    comparison over random patterns."""
     ora = harness.OracleEngine()
     rng = random.Random(int(os.environ.get("SRE_FUZZ_SEED", "78")))
     zoo = [[rb"\bab\b"], [rb"(a+)$"], [rb"c\B(.)"], [rb"$\Aa"], [rb"$^b"], [rb"\b\Ab"], [rb"a\b\Bc"], [rb"x*\b y"],
-           [rb"(?:$|a)(b|\b)"], [rb"\B\Ax"], [rb"a$\n^b"], [rb"\Aab|\n^b"]]
-    zoo += [[harness.random_regex(rng)] for _ in range(200)]
+           [rb"(?:$|a)(b|\b)"], [rb"\B\Ax"], [rb"a$\n^b"], [rb"\Aab|\n^b"], [rb"a\B^"], [rb"a\B\bc"], [rb"$\A\nb"]]
     alphabet = b"ab c\n_x.y"
-    built = compared = 0
+
+    def fed(prog, data, feed):
+        t, off, rc = ora.thompson(prog), 0, S.SRE_AGAIN
+        while rc == S.SRE_AGAIN:
+            end = min(off + feed, len(data))
+            rc = t.exec(data[off:end], end == len(data))
+            off = end
+        t.close()
+        return rc
+
+    compared = differ = 0
     for pats in zoo:
         with S.Pool() as pool:
-            try:
-                re = S.parse(pool, pats)
-            except Exception:
-                continue
-            prog = S.compile(pool, re)
+            prog = S.compile(pool, S.parse(pool, pats))
             why = ctypes.c_char_p()
             d = sim.dfa_sim_build_chunked(prog.h, 4096, ctypes.byref(why))
-            if not d:
-                continue
-            built += 1
-            for _ in range(6):
-                data = bytes(rng.choice(alphabet) for _ in range(rng.choice([0, 1, 2, 9, 30])))
+            assert d, (pats, why.value)
+            for _ in range(60):
+                data = bytes(rng.choice(alphabet) for _ in range(rng.choice([0, 1, 2, 5, 9, 30])))
                 feed = rng.choice([1, 2, 3, 7])
-                t, off, rc = ora.thompson(prog), 0, S.SRE_AGAIN
-                while rc == S.SRE_AGAIN:
-                    end = min(off + feed, len(data))
-                    rc = t.exec(data[off:end], end == len(data))
-                    off = end
-                t.close()
-                if rc == S.SRE_ERROR:
-                    continue            # the reference's list overflows here (oracle guard)
-                got = sim.dfa_sim_thompson_chunked(d, data, len(data), feed)
-                assert got == rc, (pats, data, feed, got, rc)
+                rc = fed(prog, data, feed)
+                assert sim.dfa_sim_thompson_chunked(d, data, len(data), feed) == rc, (pats, data, feed, rc)
                 compared += 1
+                differ += rc != fed(prog, data, len(data) + 1)
             sim.dfa_sim_free(d)
-    assert built > 150 and compared > 700, (built, compared)
-    # ... and chunking does change this VM's answer: \A at the first byte of the second call
+    assert compared == 60 * len(zoo) and differ > 0, (compared, differ)     # chunking does change this VM's answers
+    # the known divergence (see the docstring): oracle == reference: no match however it is fed
+    pats, data = [rb"[a-c](\B|(?:[^a]c*?|\n{2}\s){0,2}?\w?(\B^\w)*)^[^a]??"], b"\n\nxybaaa "
     with S.Pool() as pool:
-        prog = S.compile(pool, S.parse(pool, [rb"\B\Ax"]))
+        prog = S.compile(pool, S.parse(pool, pats))
         why = ctypes.c_char_p()
         d = sim.dfa_sim_build_chunked(prog.h, 4096, ctypes.byref(why))
-        t = ora.thompson(prog)
-        assert t.exec(b"_", False) == S.SRE_AGAIN and t.exec(b"x", True) == 0
-        t.close()
-        whole = ora.thompson(prog)
-        assert whole.exec(b"_x", True) == S.SRE_DECLINED
-        whole.close()
-        assert sim.dfa_sim_thompson_chunked(d, b"_x", 2, 1) == 0 and sim.dfa_sim_thompson_chunked(d, b"_x", 2, 2) == S.SRE_DECLINED
+        assert [fed(prog, data, f) for f in (1, 7, 100)] == [S.SRE_DECLINED] * 3
+        assert sim.dfa_sim_thompson_chunked(d, data, len(data), 100) == S.SRE_DECLINED
+        assert sim.dfa_sim_thompson_chunked(d, data, len(data), 7) == 0       # the automaton lists a thread the VM does not
         sim.dfa_sim_free(d)
 
 

