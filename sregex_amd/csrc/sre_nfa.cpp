@@ -107,6 +107,41 @@ sre_nfa_build(const sre_program_t *prog, const char **why)
         }
     }
 
+    /* A look-ahead assertion inside a LOOP: what a splice lists there is decided by the VM's
+     * generation tags (a splice later in the same step walks through instructions an earlier
+     * one has marked, sre_vm_pike.c:506-526, :770-792) — sets have no such memory, the
+     * expansion tables would list threads the VM drops (found by the CPU model on random
+     * patterns: `$(?:x*\n?|\B)*?x`, `(?:b*?c?|\B)+?\s??\z.`).  Such programs keep the exact VM. */
+    for (uint32_t a : asserts) {
+        std::vector<uint8_t>  seen(prog->len + 1, 0);
+        std::vector<uint32_t> stack(1, a + 1);
+        bool                  loops = false;
+        while (!stack.empty() && !loops) {
+            const uint32_t pc = stack.back();
+            stack.pop_back();
+            if (pc >= prog->len || seen[pc]) continue;
+            seen[pc] = 1;
+            if (pc == a) {
+                loops = true;
+                break;
+            }
+            const sre_insn_t &in = prog->insns[pc];
+            if (in.opcode == SRE_OP_MATCH) continue;
+            if (in.opcode == SRE_OP_JMP) {
+                stack.push_back(in.x);
+            } else if (in.opcode == SRE_OP_SPLIT) {
+                stack.push_back(in.x);
+                stack.push_back(in.y);
+            } else {
+                stack.push_back(pc + 1);
+            }
+        }
+        if (loops) {
+            *why = "a look-ahead assertion inside a loop (the VM's generation tags decide what its splice lists)";
+            return NULL;
+        }
+    }
+
     /* bit numbering: pc 1 (the ".*?" ANY thread) first, then program order; a
      * thread that can consume '\n' and whose closure differs with ^ true gets a
      * twin bit right behind its own */

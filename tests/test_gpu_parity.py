@@ -233,7 +233,9 @@ def test_scanner_segments_vs_oracle(gpu, seg):
         # ^ in find-all counting: the initial list of every re-armed search depends on the byte in front
         [rb"^a|^c|c"], [rb"^b+"], [rb"^x*"], [rb"(^|a)b"],
         # look-ahead assertions, decided inside the automaton step (FIRST / Thompson only)
-        [rb"(\w+)\b(.)"], [rb"c$"], [rb"^(.*)$"], [rb"(a+)\b(?:\s|$)"], [rb"(\B.)*?\b(x)"], [rb"(b)\z"],
+        # (not inside a loop — `(\B.)*?\b(x)`: there the VM's generation tags decide what a splice lists and
+    # the tier declines, see test_nfa_tier_segments_vs_oracle)
+    [rb"(\w+)\b(.)"], [rb"c$"], [rb"^(.*)$"], [rb"(a+)\b(?:\s|$)"], [rb"(b)\z"],
         [rb"a$", rb"\bb"], [rb"(?:$|a)(b|\b)"],
     ]
     alphabets = [b"abc", b"ab c\n.x@:/?y", b"aaaaab"]
@@ -788,7 +790,9 @@ NFA_ZOO = [
     [rb"(a+)(b+)?"], [rb"(?:a.*b|a)"], [rb"\Aab|\n^b"], [rb"^b+"], [rb"(^|a)b"], [rb"(x+x+)+y"],
     [b"a", b"ab", b"c", b"a(bc)", b"e(f)", b"gh", b"A", b"b", b"BLAH", rb"\s+", b"abcd", b"bc"],
     # look-ahead assertions: decided by the next byte inside the set step (expansion tables)
-    [rb"(\w+)\b(.)"], [rb"c$"], [rb"^(.*)$"], [rb"(a+)\b(?:\s|$)"], [rb"(\B.)*?\b(x)"], [rb"(b)\z"],
+    # (not inside a loop — `(\B.)*?\b(x)`: there the VM's generation tags decide what a splice lists and
+    # the tier declines, see test_nfa_tier_segments_vs_oracle)
+    [rb"(\w+)\b(.)"], [rb"c$"], [rb"^(.*)$"], [rb"(a+)\b(?:\s|$)"], [rb"(b)\z"],
     [rb"a$", rb"\bb"], [rb"(?:$|a)(b|\b)"], [rb"\bab\b"], [rb"x\B[ab]{2,8}\b"], [rb"^\xe7\xab\xa0$", rb"(a|b)*a(a|b){5}c"],
 ]
 
@@ -803,6 +807,11 @@ def test_nfa_tier_segments_vs_oracle(gpu, seg):
     ora = harness.OracleEngine()
     rng = random.Random(99 + seg)
     alphabets = [b"abc", b"ab c\n.x@:/?y,d", b"aaaaab", b"ab"]
+    with S.Pool() as pool:
+        # a look-ahead assertion inside a loop has no set form (sre_nfa.cpp): declined, the exact VM takes it
+        prog = S.compile(pool, S.parse(pool, [rb"(\B.)*?\b(x)"]))
+        with pytest.raises(RuntimeError):
+            S.Scanner(pool, prog, S.HIP_PIKE_FIRST, S.ENGINE_NFA)
     for pats in NFA_ZOO:
         with S.Pool() as pool:
             re = S.parse(pool, pats)
