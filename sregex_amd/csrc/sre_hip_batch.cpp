@@ -30,7 +30,7 @@ struct sre_hip_scanner_s {
     sre_program_t     *prog;
     sre_hip_program_s *dp;
     int                mode, engine;
-    char               kernel_name[48];
+    char               kernel_name[64];
     uint32_t           ovec_slots;      /* 2 * (max_ncaps + 1) */
     /* per-call staging, grown on demand */
     size_t             cap_streams;
@@ -84,6 +84,8 @@ struct sre_hip_scanner_s {
     /* ENGINE_NFA */
     sre_nfa_t                *nfa;
     sre_nfa_tables_t          ntab;             /* device pointers inside */
+    sre_nfa_sa_tables_t       satab;            /* the shift-and form (sre_nfa.h), when the program has one */
+    bool                      use_sa;
     sre_nfa_summary_t        *d_nsum;
     size_t                    nsum_cap;
     uint64_t                 *d_belief;
@@ -120,6 +122,8 @@ scanner_release(void *data)
     if (sc->ntab.follow) (void) hipFree(const_cast<uint64_t *>(sc->ntab.follow));
     if (sc->ntab.expand) (void) hipFree(const_cast<uint64_t *>(sc->ntab.expand));
     if (sc->ntab.kind) (void) hipFree(const_cast<uint8_t *>(sc->ntab.kind));
+    if (sc->satab.accept) (void) hipFree(const_cast<uint64_t *>(sc->satab.accept));
+    if (sc->satab.lut) (void) hipFree(const_cast<uint64_t *>(sc->satab.lut));
     sre_nfa_free(sc->nfa);
     sre_scan_tables_release(sc->tab);
     sre_dfa_free(sc->dfa);
@@ -156,9 +160,50 @@ nfa_upload(sre_hip_scanner_t *sc)
     for (int v = 0; v < 3; v++) sc->ntab.init[v] = n->init[v];
     sc->ntab.any_bits = n->any_bits;
     sc->ntab.match_bits = n->match_bits;
+    if (n->sa) {
+        /* the shift-and form: its own accept table and the exception lookups */
+        const sre_nfa_sa_t *a = n->sa;
+        sre_nfa_sa_tables_t &t = sc->satab;
+        uint64_t *d_sacc = NULL, *d_lut = NULL;
+        SRE_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_sacc), 256 * sizeof(uint64_t)));
+        t.accept = d_sacc;
+        SRE_HIP_TRY(hipMemcpy(d_sacc, a->accept, 256 * sizeof(uint64_t), hipMemcpyHostToDevice));
+        if (a->nlut) {
+            SRE_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_lut), a->lut.size() * sizeof(uint64_t)));
+            t.lut = d_lut;
+            SRE_HIP_TRY(hipMemcpy(d_lut, a->lut.data(), a->lut.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+        }
+        t.w64 = a->w64;
+        t.carry = a->carry;
+        t.masked = a->masked;
+        t.evacc = a->evacc;
+        t.nlut = a->nlut;
+        /* v_perm_b32 selector: result byte k = byte hot[k] of the 64-bit mask {hi, lo}; selector
+         * values 0..3 pick a byte of the second source (lo), 4..7 of the first (hi) */
+        t.perm = 0;
+        for (uint32_t k = 0; k < 4; k++) t.perm |= (k < a->nlut ? a->hot[k] : 0u) << (8 * k);
+        for (int v = 0; v < 3; v++) t.init[v] = a->init[v];
+        t.seed = a->seed;
+        t.any_bits = a->any_bits;
+        t.match_bits = a->match_bits;
+        t.msrc = a->msrc;
+        t.valid = a->valid;
+        t.self = a->self;
+        t.shift_src = a->shift_src;
+        sc->use_sa = true;
+    }
     return 0;
 hip_failed:
     return -1;
+}
+
+/* one pass of the set kernel the scanner's program runs on */
+static hipError_t
+nfa_launch_scan(sre_hip_scanner_t *sc, const int64_t *d_lo, const uint64_t *d_belief, const uint8_t *d_bvalid,
+                hipStream_t stream)
+{
+    if (sc->use_sa) return sre_launch_nfa_sa_scan(sc->satab, sc->geom, sc->d_nsum, d_lo, d_belief, d_bvalid, stream);
+    return sre_launch_nfa_scan(sc->mode, sc->ntab, sc->geom, sc->d_nsum, d_lo, d_belief, d_bvalid, stream);
 }
 
 extern "C" SRE_API int
@@ -311,8 +356,9 @@ sre_hip_scanner_kernel_name(sre_hip_scanner_t *sc)
                      sc->mode == SRE_HIP_PIKE_COUNT ? 2 : 1, (int) sc->tab->h.class_bits,
                      sc->tab->h.wide ? "true" : "false");
         } else if (sc->engine == SRE_HIP_ENGINE_NFA) {
-            sre_nfa_kernel_name(sc->mode, sc->ntab.nslices, sc->ntab.nassert != 0, sc->kernel_name,
-                                sizeof(sc->kernel_name));
+            if (sc->use_sa) sre_nfa_sa_kernel_name(&sc->satab, sc->kernel_name, sizeof(sc->kernel_name));
+            else sre_nfa_kernel_name(sc->mode, sc->ntab.nslices, sc->ntab.nassert != 0, sc->kernel_name,
+                                     sizeof(sc->kernel_name));
         } else {
             snprintf(sc->kernel_name, sizeof(sc->kernel_name), "%s",
                      sc->mode == SRE_HIP_THOMPSON ? "sre_k_thompson_scan" : "sre_k_pike_scan");
@@ -452,10 +498,11 @@ scan_geometry(sre_hip_scanner_t *sc, size_t nstreams)
          * shorter ones keep every CU busy on small batches */
         if (sc->blocks_per_cu == 0) {
             sc->blocks_per_cu = sc->engine == SRE_HIP_ENGINE_NFA
-                                    ? sre_nfa_blocks_per_cu(sc->mode, sc->ntab.nslices, sc->ntab.nassert != 0)
+                                    ? (sc->use_sa ? sre_nfa_sa_blocks_per_cu(&sc->satab)
+                                                  : sre_nfa_blocks_per_cu(sc->mode, sc->ntab.nslices, sc->ntab.nassert != 0))
                                                                  : sre_scan_blocks_per_cu(&sc->tab->h);
         }
-        const uint64_t resident = 256ull * (uint64_t) sc->blocks_per_cu * SRE_SCAN_BLOCK;
+        const uint64_t resident = (uint64_t) sre_hip_cu_count() * (uint64_t) sc->blocks_per_cu * SRE_SCAN_BLOCK;
         /* (measured, one box, 4 GiB: the COUNT kernel at two workgroups per CU takes 1.33 ms
          * with 16 640-byte segments = two rounds of resident workgroups, 1.25 ms with 33 280 =
          * one round, and 1.67 ms with 21 760 = one and a half: a whole number of rounds
@@ -593,7 +640,7 @@ sre_hip_scan_enqueue(sre_hip_scanner_t *sc, const void *const *d_streams, const 
         }
         /* set pass, chain check, and (Pike) the exact VM over each stream's window */
         SRE_HIP_TRY(hipEventRecord(sc->ev0, stream));
-        SRE_HIP_TRY(sre_launch_nfa_scan(sc->mode, sc->ntab, sc->geom, sc->d_nsum, NULL, NULL, NULL, stream));
+        SRE_HIP_TRY(nfa_launch_scan(sc, NULL, NULL, NULL, stream));
         SRE_HIP_TRY(hipEventRecord(sc->ev1, stream));
         sc->ev_valid = 1;
         if (sc->tail_stream_set && sc->tail_stream != stream) {
@@ -754,8 +801,7 @@ sre_hip_scan_results(sre_hip_scanner_t *sc, sre_int_t *results)
                 return -1;
             }
             SRE_HIP_TRY(hipMemcpyAsync(sc->d_lo, sc->h_lo, n * sizeof(int64_t), hipMemcpyHostToDevice, stream));
-            SRE_HIP_TRY(sre_launch_nfa_scan(sc->mode, sc->ntab, sc->geom, sc->d_nsum, sc->d_lo, sc->d_belief,
-                                            sc->d_bvalid, stream));
+            SRE_HIP_TRY(nfa_launch_scan(sc, sc->d_lo, sc->d_belief, sc->d_bvalid, stream));
             if (nfa_finish(sc, sc->d_lo, stream) != 0) return -1;
         }
     }

@@ -21,6 +21,16 @@ typedef struct {
     const uint8_t  *kind;           /* [256]           device */
 } sre_nfa_tables_t;
 
+/* the shift-and form (sre_nfa.h sre_nfa_sa_t) as the kernel takes it */
+typedef struct {
+    uint32_t w64, carry, masked, evacc, nlut;
+    uint32_t perm;                  /* v_perm_b32 selector: byte k = the byte of the mask that indexes lut[k] */
+    uint64_t init[3];
+    uint64_t seed, any_bits, match_bits, msrc, valid, self, shift_src;
+    const uint64_t *accept;         /* [256]        device */
+    const uint64_t *lut;            /* [nlut][256]  device (NULL when nlut == 0) */
+} sre_nfa_sa_tables_t;
+
 /* what one lane learnt about its segment */
 typedef struct {
     uint64_t s_in;          /* thread set assumed at the segment start */
@@ -54,6 +64,13 @@ const char *sre_nfa_kernel_name(int mode, uint32_t nslices, int la, char *buf, s
 hipError_t sre_launch_nfa_scan(int mode, sre_nfa_tables_t tab, sre_scan_geom_t geom,
     sre_nfa_summary_t *d_sum, const int64_t *d_lo, const uint64_t *d_belief,
     const uint8_t *d_bvalid, hipStream_t stream);
+/* the same pass by the shift-and kernel (sre_k_nfa_sa): summaries, beliefs and the chain check are
+ * shared, the masks are in the numbering of the shift-and form */
+hipError_t sre_launch_nfa_sa_scan(sre_nfa_sa_tables_t tab, sre_scan_geom_t geom,
+    sre_nfa_summary_t *d_sum, const int64_t *d_lo, const uint64_t *d_belief,
+    const uint8_t *d_bvalid, hipStream_t stream);
+int sre_nfa_sa_blocks_per_cu(const sre_nfa_sa_tables_t *tab);
+const char *sre_nfa_sa_kernel_name(const sre_nfa_sa_tables_t *tab, char *buf, size_t n);
 size_t sre_nfa_verify_acc_bytes(uint32_t nstreams);
 hipError_t sre_nfa_verify_acc_init(void *d_acc, uint32_t nstreams, hipStream_t stream);
 /* chain check -> status; also refreshes belief / bvalid for a possible next round and

@@ -364,6 +364,297 @@ sre_k_nfa(sre_nfa_tables_t T, sre_scan_geom_t G, sre_nfa_summary_t *__restrict__
     sum[g] = out;
 }
 
+/* ===================================================================== shift-and kernel */
+
+/*
+ * sre_k_nfa_sa<W64, CARRY, MASKED, EVACC, NLUT> — the SHIFT-AND form of the set step (sre_nfa.h):
+ *
+ *      t  = S & accept[byte]
+ *      S' = ((t [& shift_src]) << 1) | (t & self) | seed | OR_k lut[k][hot byte k of t]
+ *
+ * One accept read per input byte that does not depend on the state (issued a group of bytes
+ * ahead), three ALU operations per 32 bits of mask, and NLUT (0..3) dependent lookups where the
+ * plain slices take nbits / 8.  The hot bytes are gathered by one v_perm_b32 (selector in a kernel
+ * argument), so any layout the host builder finds runs on the same code.  Staging: half a line per
+ * row (sre_hip_tile.h tile2_*), 20 KiB per workgroup, five or six workgroups per CU.
+ * Both modes in one kernel: clean positions are sampled every 16 bytes, which is noise.
+ * Summaries, beliefs and the chain check are those of sre_k_nfa.
+ */
+template <bool W64, bool CARRY, bool MASKED, bool EVACC, int NLUT>
+__global__ __launch_bounds__(SRE_SCAN_BLOCK, (W64 ? 5 : 6)) void
+sre_k_nfa_sa(sre_nfa_sa_tables_t T, sre_scan_geom_t G, sre_nfa_summary_t *__restrict__ sum,
+             const int64_t *__restrict__ lo, const uint64_t *__restrict__ belief,
+             const uint8_t *__restrict__ bvalid)
+{
+    typedef typename std::conditional<W64, uint64_t, uint32_t>::type E; /* a table entry */
+    constexpr int      TILE = SRE_SCAN_ROUND;
+    constexpr int      WARM = SRE_SCAN_LINE;
+    constexpr uint32_t ROWB = SRE_TILE2_ROWB;
+    constexpr int      GRP = W64 ? 4 : 8;       /* accept reads in flight ahead of the chain */
+    constexpr uint32_t ESZ = (uint32_t) sizeof(E);
+    __shared__ __attribute__((aligned(16))) E acc_w[256];
+    __shared__ __attribute__((aligned(16))) E lut_w[(NLUT ? NLUT : 1) * 256];
+    extern __shared__ __attribute__((aligned(16))) uint8_t tile[];
+    RowDesc *rows = reinterpret_cast<RowDesc *>(tile + SRE_SCAN_BLOCK * ROWB);
+
+    const uint32_t tid = threadIdx.x;
+    auto lo32 = [](uint64_t v) { return (uint32_t) v; };
+    auto hi32 = [](uint64_t v) { return (uint32_t) (v >> 32); };
+    auto entry = [&](uint64_t v) -> E { return (E) v; };
+    /* sticky MATCH bits accept every byte and list themselves in the host tables already */
+    acc_w[tid] = entry(T.accept[tid]);
+#pragma unroll
+    for (int k = 0; k < NLUT; k++) lut_w[k * 256 + tid] = entry(T.lut[k * 256 + tid] | (k == 0 ? T.seed : 0));
+    const uint32_t acc_base = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) E *) acc_w;
+    const uint32_t lut_base = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) E *) lut_w;
+    const uint32_t sh = W64 ? 3u : 2u;          /* log2 of a table entry, in a register for SDWA */
+    const uint32_t self_lo = lo32(T.self), self_hi = hi32(T.self), src_lo = lo32(T.shift_src), src_hi = hi32(T.shift_src);
+    const uint32_t seed_lo = NLUT ? 0u : lo32(T.seed), seed_hi = NLUT ? 0u : hi32(T.seed);
+    const uint32_t nany_lo = ~lo32(T.any_bits), nany_hi = ~hi32(T.any_bits);
+    const uint32_t ev_lo = EVACC ? lo32(T.msrc) : lo32(T.match_bits), ev_hi = EVACC ? hi32(T.msrc) : hi32(T.match_bits);
+    const uint32_t val_lo = lo32(T.valid), val_hi = W64 ? hi32(T.valid) : 0u;
+    const uint32_t perm = T.perm;
+
+    /* ---- which segment am I ---- */
+    const uint64_t g = (uint64_t) blockIdx.x * SRE_SCAN_BLOCK + tid;
+    bool           active = g < G.nsegs;
+    uint32_t       sidx = 0;
+    uint64_t       k = 0;
+    if (active) {
+        sidx = nfa_stream_of(G, g);
+        k = g - geom_first(G, sidx);
+        if (lo != nullptr && (lo[sidx] < 0 || (int64_t) k < lo[sidx])) active = false;
+    }
+
+    const uint8_t *data = nullptr;
+    int64_t        n = 0, seg_a = 0, seg_b = 0;
+    uint32_t       s_lo = 0, s_hi = 0;
+    uint64_t       s_in = 0;
+    bool           warm = false, finished = false;
+    int64_t        first_ev = -1, last_clean = -1;
+    int32_t        clean_mode = 0;
+    RowDesc        mine;
+    mine.addr = 0;
+    mine.lo = 0;
+    mine.hi16 = -1;
+    if (active) {
+        data = geom_ptr(G, sidx);
+        n = (int64_t) geom_len(G, sidx);
+        seg_a = (int64_t) k * G.seg_bytes;
+        seg_b = seg_a + G.seg_bytes;
+        if (seg_b > n) seg_b = n;
+        uint64_t S;
+        if (k == 0) {
+            S = T.init[G.init_variant];
+            last_clean = 0;                     /* the search starts here */
+        } else if (lo != nullptr && ((int64_t) k == lo[sidx] || bvalid[g])) {
+            S = belief[g];
+        } else {
+            warm = true;
+            S = T.init[seg_a <= WARM ? G.init_variant : 2];
+        }
+        s_in = S;
+        s_lo = lo32(S);
+        s_hi = hi32(S);
+        mine.addr = (uint64_t) reinterpret_cast<uintptr_t>(data) + (uint64_t) (seg_a - WARM);
+        mine.lo = warm ? (seg_a >= WARM ? 0 : (int32_t) (WARM - seg_a)) : WARM;
+        mine.hi16 = (int32_t) (WARM + (seg_b - seg_a)) - 16;
+    }
+    rows[tid] = mine;
+
+    const uint64_t snap = T.init[G.init_variant];
+    const uint32_t snap_lo = lo32(snap), snap_hi = hi32(snap);
+    /* how the reference arrives at a clean position: see sre_k_nfa (no look-ahead assertions here, so
+     * the byte in front of a clean position never is a leading byte) */
+    auto clean_kind = [&](bool before_is_snap, bool prev_clean) -> int {
+        if (!before_is_snap) return 0;
+        return prev_clean ? 1 : -1;
+    };
+    uint32_t evv = 0;           /* EVACC: threads that reached MATCH in this round */
+    /* one step; a = the byte's accept entry; returns whether only the ".*?" thread consumed the byte */
+    auto step = [&](uint32_t a_lo, uint32_t a_hi) -> bool {
+        const uint32_t t_lo = s_lo & a_lo, t_hi = W64 ? (s_hi & a_hi) : 0u;
+        uint32_t       e_lo = seed_lo, e_hi = seed_hi;
+        if (NLUT > 0) {
+            const uint32_t hot = __builtin_amdgcn_perm(W64 ? t_hi : t_lo, t_lo, perm);
+#pragma unroll
+            for (int q = 0; q < NLUT; q++) {
+                const uint32_t off = q == 0 ? byte_shl<0>(hot, sh) : q == 1 ? byte_shl<1>(hot, sh) : byte_shl<2>(hot, sh);
+                const uint32_t at = lut_base + (uint32_t) q * 256u * ESZ + off;
+                if constexpr (W64) {
+                    const uint64_t v = *(const __attribute__((address_space(3))) uint64_t *) (uintptr_t) at;
+                    e_lo |= (uint32_t) v;
+                    e_hi |= (uint32_t) (v >> 32);
+                } else {
+                    e_lo |= *(const __attribute__((address_space(3))) uint32_t *) (uintptr_t) at;
+                }
+            }
+        }
+        const uint32_t ts_lo = MASKED ? (t_lo & src_lo) : t_lo, ts_hi = MASKED ? (t_hi & src_hi) : t_hi;
+        const uint32_t u_lo = (t_lo & self_lo) | e_lo;
+        s_lo = (ts_lo << 1) | u_lo;
+        if (W64) {
+            const uint32_t u_hi = (t_hi & self_hi) | e_hi;
+            s_hi = (CARRY ? __builtin_amdgcn_alignbit(ts_hi, ts_lo, 31) : (ts_hi << 1)) | u_hi;
+        }
+        if (EVACC) {
+            /* one v_and_or_b32 per word, kept in order: left to itself the compiler turns the 64
+             * accumulations of a round into a tree and spills the operands */
+            asm("v_and_or_b32 %0, %1, %2, %0" : "+v"(evv) : "v"(t_lo), "v"(ev_lo));
+            if (W64) asm("v_and_or_b32 %0, %1, %2, %0" : "+v"(evv) : "v"(t_hi), "v"(ev_hi));
+        }
+        return ((t_lo & nany_lo) | (W64 ? (t_hi & nany_hi) : 0u)) == 0;
+    };
+    auto event = [&]() -> bool { return EVACC ? evv != 0 : ((s_lo & ev_lo) | (W64 ? (s_hi & ev_hi) : 0u)) != 0; };
+    auto drop_event = [&]() {
+        if (EVACC) evv = 0;
+        else {
+            s_lo &= ~ev_lo;
+            s_hi &= ~ev_hi;
+        }
+    };
+    auto is_snap = [&](uint32_t b_lo, uint32_t b_hi) -> bool {
+        return (((b_lo ^ snap_lo) & val_lo) | (W64 ? ((b_hi ^ snap_hi) & val_hi) : 0u)) == 0;
+    };
+    auto state64 = [&]() -> uint64_t { return ((uint64_t) (s_hi & val_hi) << 32) | (s_lo & val_lo); };
+    auto accept_at = [&](uint32_t byte_addr, uint32_t &a_lo, uint32_t &a_hi) {
+        if constexpr (W64) {
+            const uint64_t v = *(const __attribute__((address_space(3))) uint64_t *) (uintptr_t) (acc_base + byte_addr);
+            a_lo = (uint32_t) v;
+            a_hi = (uint32_t) (v >> 32);
+        } else {
+            a_lo = *(const __attribute__((address_space(3))) uint32_t *) (uintptr_t) (acc_base + byte_addr);
+            a_hi = 0;
+        }
+    };
+
+    const uint32_t nrounds = WARM / TILE + G.seg_bytes / TILE;
+    const uint32_t lag = (tid >> 5) & 1u;
+    uint4          regs[4], hold[2];
+    hold[0] = hold[1] = make_uint4(0, 0, 0, 0);
+    __syncthreads();                        /* tables and row descriptors are complete */
+    tile2_fetch(regs, rows, tid, 0);
+    for (uint32_t s = 0; s <= nrounds; s++) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        tile2_store(regs, hold, tile, tid, s);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (s < nrounds) tile2_fetch(regs, rows, tid, s + 1);
+
+        if (s < lag || s - lag >= nrounds) continue;
+        const uint32_t r = s - lag;
+        const bool     warm_round = (r < WARM / TILE);
+        if (!active || finished || (warm_round && !warm)) continue;
+        const int64_t base = seg_a - WARM + (int64_t) r * TILE;
+        if (base >= seg_b || base < 0) continue;
+
+        const uint32_t s0_lo = s_lo, s0_hi = s_hi;
+        if (base + TILE <= seg_b) {
+            /* the common round: 64 steps, then one look at the event */
+            const uint8_t *src = tile + tid * ROWB;
+            uint4          piece = make_uint4(0, 0, 0, 0);
+            uint32_t       av_lo[2][GRP], av_hi[2][GRP];
+            int32_t        clean_at = -1, clean_how = 0;
+            bool           c14 = false;
+            auto load_group = [&](int q) {
+#pragma unroll
+                for (int i = 0; i < GRP; i++) {
+                    const int j = q * GRP + i;
+                    if ((j & 15) == 0) piece = *reinterpret_cast<const uint4 *>(src + j);
+                    const uint32_t word = ((j >> 2) & 3) == 0 ? piece.x : ((j >> 2) & 3) == 1 ? piece.y
+                                        : ((j >> 2) & 3) == 2 ? piece.z : piece.w;
+                    const uint32_t a = (j & 3) == 0 ? byte_shl<0>(word, sh) : (j & 3) == 1 ? byte_shl<1>(word, sh)
+                                     : (j & 3) == 2 ? byte_shl<2>(word, sh) : byte_shl<3>(word, sh);
+                    accept_at(a, av_lo[q & 1][i], av_hi[q & 1][i]);
+                }
+            };
+            load_group(0);
+#pragma unroll
+            for (int q = 0; q < TILE / GRP; q++) {
+                if (q + 1 < TILE / GRP) load_group(q + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < GRP; i++) {
+                    const int      j = q * GRP + i;
+                    const uint32_t b_lo = s_lo, b_hi = s_hi;
+                    const bool     cl = step(av_lo[q & 1][i], av_hi[q & 1][i]);
+                    if ((j & 15) == 14) c14 = cl;
+                    /* clean positions are sampled at the end of every 16-byte group */
+                    if ((j & 15) == 15 && cl) {
+                        const int how = clean_kind(is_snap(b_lo, b_hi), c14);
+                        if (how >= 0) {
+                            clean_at = j + 1;
+                            clean_how = how;
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (!event()) {
+                if (warm_round) {
+                    if (r + 1 == WARM / TILE) s_in = state64();
+                } else if (clean_at >= 0) {
+                    last_clean = base + clean_at;
+                    clean_mode = clean_how;
+                }
+                continue;
+            }
+            if (warm_round) {
+                /* an event in front of the segment is somebody else's */
+                drop_event();
+                if (r + 1 == WARM / TILE) s_in = state64();
+                continue;
+            }
+            s_lo = s0_lo;
+            s_hi = s0_hi;
+            evv = 0;
+        }
+        /* byte by byte: a round with an event, or the ragged end of the stream */
+        {
+            const int64_t end = base + TILE <= seg_b ? base + TILE : seg_b;
+            bool          prev_clean = (base == 0);     /* the list at offset 0 is the initial one */
+#pragma unroll 1
+            for (int64_t p = base; p < end; p++) {
+                /* from memory, not from the tile: a 16-byte piece that crosses the end
+                 * of the stream is not staged (sre_hip_tile.h) */
+                const uint32_t b = data[p];
+                const uint32_t b_lo = s_lo, b_hi = s_hi;
+                uint32_t       a_lo, a_hi;
+                accept_at(b << sh, a_lo, a_hi);
+                const bool cl = step(a_lo, a_hi);
+                if (event()) {
+                    if (!warm_round) {
+                        first_ev = p;
+                        finished = true;
+                        break;
+                    }
+                    drop_event();
+                    prev_clean = false;
+                } else if (!warm_round && cl) {
+                    const int how = clean_kind(is_snap(b_lo, b_hi), prev_clean);
+                    if (how >= 0) {
+                        last_clean = p + 1;
+                        clean_mode = how;
+                    }
+                    prev_clean = true;
+                } else {
+                    prev_clean = false;
+                }
+            }
+            if (warm_round && r + 1 == WARM / TILE) s_in = state64();
+        }
+    }
+
+    if (!active) return;
+    sre_nfa_summary_t out;
+    out.s_in = s_in;
+    out.s_out = state64();
+    out.first_ev = first_ev;
+    out.last_clean = last_clean < 0 ? -1 : last_clean * 2 + clean_mode;
+    sum[g] = out;
+}
+
 /* ===================================================================== verify */
 
 struct NfaAcc {
@@ -588,4 +879,81 @@ sre_launch_nfa_verify(int mode, sre_scan_geom_t geom, const sre_nfa_summary_t *d
     hipLaunchKernelGGL(sre_k_nfa_verify_c, dim3((geom.nstreams + 63) / 64), dim3(64), 0, stream, mode, geom,
                        d_sum, acc, d_status, d_records, ovec_slots, d_lo);
     return hipGetLastError();
+}
+
+/* ---- the shift-and kernel's variants */
+
+namespace {
+
+template <bool W64, bool CARRY, bool MASKED, bool EVACC>
+nfa_kernel_t
+nfa_sa_kernel_nlut(uint32_t nlut)
+{
+    switch (nlut) {
+    case 0: return reinterpret_cast<nfa_kernel_t>(sre_k_nfa_sa<W64, CARRY, MASKED, EVACC, 0>);
+    case 1: return reinterpret_cast<nfa_kernel_t>(sre_k_nfa_sa<W64, CARRY, MASKED, EVACC, 1>);
+    case 2: return reinterpret_cast<nfa_kernel_t>(sre_k_nfa_sa<W64, CARRY, MASKED, EVACC, 2>);
+    case 3: return reinterpret_cast<nfa_kernel_t>(sre_k_nfa_sa<W64, CARRY, MASKED, EVACC, 3>);
+    default: return nullptr;
+    }
+}
+
+template <bool W64, bool CARRY>
+nfa_kernel_t
+nfa_sa_kernel_opts(const sre_nfa_sa_tables_t &t)
+{
+    if (t.masked) return t.evacc ? nfa_sa_kernel_nlut<W64, CARRY, true, true>(t.nlut) : nfa_sa_kernel_nlut<W64, CARRY, true, false>(t.nlut);
+    return t.evacc ? nfa_sa_kernel_nlut<W64, CARRY, false, true>(t.nlut) : nfa_sa_kernel_nlut<W64, CARRY, false, false>(t.nlut);
+}
+
+/* the address of a kernel is all that is needed of it here (occupancy, attributes); the launch
+ * goes through hipLaunchKernel with the real argument list */
+const void *
+nfa_sa_kernel(const sre_nfa_sa_tables_t &t)
+{
+    nfa_kernel_t k;
+    if (!t.w64) k = nfa_sa_kernel_opts<false, false>(t);
+    else if (t.carry) k = nfa_sa_kernel_opts<true, true>(t);
+    else k = nfa_sa_kernel_opts<true, false>(t);
+    return reinterpret_cast<const void *>(k);
+}
+
+size_t
+nfa_sa_dynamic_lds(void)
+{
+    return (size_t) SRE_SCAN_BLOCK * SRE_TILE2_ROWB + (size_t) SRE_SCAN_BLOCK * 16;
+}
+
+}  // namespace
+
+extern "C" const char *
+sre_nfa_sa_kernel_name(const sre_nfa_sa_tables_t *t, char *buf, size_t n)
+{
+    snprintf(buf, n, "sre_k_nfa_sa<%s, %s, %s, %s, %u>", t->w64 ? "true" : "false", t->carry ? "true" : "false",
+             t->masked ? "true" : "false", t->evacc ? "true" : "false", t->nlut);
+    return buf;
+}
+
+extern "C" int
+sre_nfa_sa_blocks_per_cu(const sre_nfa_sa_tables_t *t)
+{
+    int         n = 0;
+    const void *k = nfa_sa_kernel(*t);
+    if (k == nullptr) return 1;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k, SRE_SCAN_BLOCK, nfa_sa_dynamic_lds());
+    if (e != hipSuccess || n < 1) n = 1;
+    if (n > 8) n = 8;
+    return n;
+}
+
+extern "C" hipError_t
+sre_launch_nfa_sa_scan(sre_nfa_sa_tables_t tab, sre_scan_geom_t geom, sre_nfa_summary_t *d_sum,
+                       const int64_t *d_lo, const uint64_t *d_belief, const uint8_t *d_bvalid, hipStream_t stream)
+{
+    if (geom.nsegs == 0) return hipSuccess;
+    const uint32_t grid = (uint32_t) ((geom.nsegs + SRE_SCAN_BLOCK - 1) / SRE_SCAN_BLOCK);
+    const void    *kern = nfa_sa_kernel(tab);
+    if (kern == nullptr) return hipErrorInvalidValue;
+    void *args[] = {&tab, &geom, &d_sum, &d_lo, &d_belief, &d_bvalid};
+    return hipLaunchKernel(kern, dim3(grid), dim3(SRE_SCAN_BLOCK), args, nfa_sa_dynamic_lds(), stream);
 }

@@ -36,6 +36,22 @@ sre_hip_ready(void)
     return state == 1 ? 0 : -1;
 }
 
+/* compute units of the current device (hipDeviceProp_t.multiProcessorCount; MI355X: 256) */
+extern "C" int
+sre_hip_cu_count(void)
+{
+    static int cached_dev = -1, cached_cus = 0;
+    int        dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    if (dev != cached_dev) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cached_cus = n;
+        cached_dev = dev;
+    }
+    return cached_cus;
+}
+
 static void
 free_program_image(void *data)
 {

@@ -37,6 +37,9 @@ extern "C" {
  * returns -1.  There is no CPU matcher to fall back to. */
 SRE_NOAPI int sre_hip_ready(void);
 
+/* compute units of the current device */
+SRE_NOAPI int sre_hip_cu_count(void);
+
 /* report a HIP failure loudly; returns -1 */
 SRE_NOAPI int sre_hip_fail(const char *what, hipError_t err);
 

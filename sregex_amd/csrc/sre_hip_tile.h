@@ -116,6 +116,53 @@ tile_store(const uint4 (&regs)[4], uint8_t *tile, const uint16_t (*clsx)[256], u
     }
 }
 
+/*
+ * HALF-LINE staging (round 3; the shift-and NFA kernel): the tile keeps 64 bytes per row instead
+ * of a whole line, so a workgroup's tile is 20 KiB instead of 36 and twice as many workgroups
+ * share a CU — these kernels are bound by the latency of one lane's dependent chain, and waves
+ * per SIMD are what hides it.  Lines are still requested whole and once: stage s brings the line
+ * (s >> 1) of the rows of half (s & 1) of the wave; lanes 4q .. 4q + 3 read 64 contiguous bytes,
+ * pieces 0 / 2 the FIRST halves of the lines of rows q and q + 16, pieces 1 / 3 their SECOND
+ * halves.  tile2_store puts the first halves into LDS now and keeps the second halves in
+ * registers (`hold`) for one stage: every row of the wave gets 64 fresh bytes per stage, the rows
+ * of half (s & 1) the first half of a new line, the others the second half of theirs.  The upper
+ * half-wave therefore runs one round behind the lower one, as with tile_fetch.
+ */
+constexpr uint32_t SRE_TILE2_ROWB = SRE_SCAN_ROUND + 16;    /* 64 bytes + pad: 16-byte reads of a row are conflict-free */
+
+__device__ inline void
+tile2_fetch(uint4 (&regs)[4], const RowDesc *rows, uint32_t tid, uint32_t stage)
+{
+    const uint32_t wbase = (tid & ~63u) + (stage & 1u) * 32u, lane = tid & 63u;
+    const int32_t  line_off = (int32_t) ((stage >> 1) * SRE_SCAN_LINE);
+#pragma unroll
+    for (uint32_t i = 0; i < 4; i++) {
+        const uint32_t row = wbase + (lane >> 2) + 16u * (i >> 1), col = (lane & 3u) + 4u * (i & 1u);
+        const int32_t  off = line_off + (int32_t) (col * 16);
+        const uint4    d = *reinterpret_cast<const uint4 *>(&rows[row]);
+        sre_u32x4      v = {0, 0, 0, 0};
+        if ((off >= (int32_t) d.z) & (off <= (int32_t) d.w)) {
+            const uint64_t a = (((uint64_t) d.y << 32) | d.x) + (uint64_t) (int64_t) off;
+            v = *reinterpret_cast<const __attribute__((address_space(1))) sre_u32x4_unaligned *>(a);
+        }
+        regs[i] = make_uint4(v.x, v.y, v.z, v.w);
+    }
+}
+
+__device__ inline void
+tile2_store(const uint4 (&regs)[4], uint4 (&hold)[2], uint8_t *tile, uint32_t tid, uint32_t stage)
+{
+    const uint32_t wave = tid & ~63u, lane = tid & 63u, h = stage & 1u;
+    const uint32_t rnew = wave + h * 32u + (lane >> 2), rold = wave + (1u - h) * 32u + (lane >> 2);
+    const uint32_t col = (lane & 3u) * 16u;
+    *reinterpret_cast<uint4 *>(tile + rnew * SRE_TILE2_ROWB + col) = regs[0];
+    *reinterpret_cast<uint4 *>(tile + (rnew + 16u) * SRE_TILE2_ROWB + col) = regs[2];
+    *reinterpret_cast<uint4 *>(tile + rold * SRE_TILE2_ROWB + col) = hold[0];
+    *reinterpret_cast<uint4 *>(tile + (rold + 16u) * SRE_TILE2_ROWB + col) = hold[1];
+    hold[0] = regs[1];
+    hold[1] = regs[3];
+}
+
 }  // namespace
 
 #endif

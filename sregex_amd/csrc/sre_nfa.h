@@ -54,6 +54,54 @@
 enum { SRE_NFA_KIND_OTHER = 0, SRE_NFA_KIND_WORD = 1, SRE_NFA_KIND_NL = 2, SRE_NFA_KIND_EDGE = 3 };
 #define SRE_NFA_LEADING 4u          /* the byte can start a match (sre_vm_pike.c:992-1061) */
 
+/*
+ * The SHIFT-AND form of the same sets (programs without look-ahead assertions): most compiled
+ * programs are CHAINS — the thread behind `x` in `xy` lists `y` and nothing else — so with a
+ * thread's successor numbered one bit above it the whole follow relation of a chain is one shift:
+ *
+ *      t  = S & accept[byte]
+ *      S' = ((t & shift_src) << 1) | (t & self) | seed | OR_k lut[k][byte hot[k] of t]
+ *
+ * `self`: threads that list themselves (x+ x*).  `seed`: the closure of the ".*?" thread, which is
+ * alive at every position of an unanchored search and therefore kept IMPLICIT (no bit) when its
+ * closure does not depend on ^.  Everything else a thread lists — the other branches of a SPLIT, a
+ * JMP back, the exit of an optional chain — comes from a lookup, by the bytes of the mask that hold
+ * such threads (`hot`, at most three): one or two lookups per input byte where the plain slices need
+ * nbits / 8.  Equivalent threads (same follow set, listed by exactly the same threads: the two arms of
+ * `(?:a|b)`) are merged first; all MATCH instructions become one event test.
+ * The layout either leaves a HOLE (a bit no byte accepts) above every thread that must not shift
+ * (`masked == 0`), or the step masks with shift_src.  MATCH is either sticky bits (`match_bits`, behind
+ * a chain that ends in MATCH) or, when that would cost lookups, no bit at all: `evacc`, a step is an
+ * event when t & msrc.  (The x86 JIT of the reference keeps the same 64-bit thread mask,
+ * sre_vm_thompson_x64.dasc:81-130; its transitions are code, here they are one shift and a table.)
+ */
+#ifdef __cplusplus
+struct sre_nfa_sa_t {
+    uint32_t nbits;             /* highest bit in use + 1 */
+    uint32_t w64;               /* 0: all in the low 32 bits */
+    uint32_t carry;             /* w64: the shift carries bit 31 into bit 32 (else each half shifts alone) */
+    uint32_t masked, evacc;
+    uint32_t nlut;              /* <= SRE_NFA_SA_MAX_LUT */
+    uint32_t hot[4];
+    uint64_t init[3];
+    uint64_t seed, any_bits, match_bits, msrc, valid, self, shift_src;
+    uint64_t accept[256];
+    std::vector<uint64_t> lut;  /* [nlut][256] */
+    std::vector<int>      bit_of;   /* bit of sre_nfa_s -> bit here; -1: implicit ".*?", -2: MATCH (evacc), >= 0 also for merged threads */
+    uint32_t cost;              /* the builder's estimate: instructions per input byte */
+};
+#define SRE_NFA_SA_MAX_LUT 3u
+/* build options (tests force every kernel variant) */
+#define SRE_NFA_SA_FORCE_MASKED  1u
+#define SRE_NFA_SA_FORCE_EVACC   2u
+#define SRE_NFA_SA_FORCE_W64     4u
+#define SRE_NFA_SA_FORCE_CARRY   8u
+#define SRE_NFA_SA_NO_MERGE      16u
+#define SRE_NFA_SA_EXPLICIT_ANY  32u
+#define SRE_NFA_SA_NO_EVACC      64u
+#define SRE_NFA_SA_OFF           128u
+#endif
+
 struct sre_nfa_s {
     uint32_t nbits;             /* bits in use (<= 64) */
     uint32_t nslices;           /* ceil(nbits / 8) */
@@ -68,6 +116,7 @@ struct sre_nfa_s {
     uint32_t assert_slice;          /* the byte of the mask that holds their bits */
     uint8_t  kind[256];             /* per input byte: SRE_NFA_KIND_* | SRE_NFA_LEADING */
     std::vector<uint64_t> expand;   /* [4 prev kinds][4 cur kinds][256 values of the assertion byte] */
+    sre_nfa_sa_t *sa;               /* the shift-and form, NULL when the program has none */
 };
 typedef struct sre_nfa_s sre_nfa_t;
 
@@ -79,6 +128,9 @@ typedef struct sre_nfa_s sre_nfa_t;
 /* NULL + *why when the program has no bit-parallel form (more than 64 bits, more than
  * 8 look-ahead assertions, or a nullable regex: its first event is at offset 0) */
 sre_nfa_t *sre_nfa_build(const sre_program_t *prog, const char **why);
+/* same with SRE_NFA_SA_* options for the shift-and form (sre_nfa_build: the environment's
+ * SRE_HIP_NFA_SA, default 0) */
+sre_nfa_t *sre_nfa_build2(const sre_program_t *prog, unsigned sa_options, const char **why);
 void sre_nfa_free(sre_nfa_t *nfa);
 
 #ifdef __cplusplus

@@ -13,7 +13,8 @@
 
 extern "C" {
 
-void *nfa_sim_build(const sre_program_t *prog, const char **why) { return sre_nfa_build(prog, why); }
+void *nfa_sim_build(const sre_program_t *prog, const char **why) { return sre_nfa_build2(prog, SRE_NFA_SA_OFF, why); }
+void *nfa_sim_build2(const sre_program_t *prog, unsigned sa_options, const char **why) { return sre_nfa_build2(prog, sa_options, why); }
 void nfa_sim_free(void *h) { sre_nfa_free(static_cast<sre_nfa_t *>(h)); }
 uint32_t nfa_sim_nbits(void *h) { return static_cast<sre_nfa_t *>(h)->nbits; }
 
@@ -51,6 +52,75 @@ void nfa_sim_run(void *h, const uint8_t *data, int64_t n, int variant, int64_t *
     out[0] = ev;
     out[1] = clean;
     out[2] = hw;
+}
+
+
+/* ---- the shift-and form (sre_nfa.h): one step as the device kernel takes it */
+
+static inline uint64_t
+sa_step(const sre_nfa_sa_t *a, uint64_t S, unsigned byte, uint64_t *t_out)
+{
+    const uint64_t t = S & a->accept[byte];
+    const uint64_t ts = a->masked ? t & a->shift_src : t;
+    uint64_t       sh;
+    if (!a->w64) sh = (uint64_t) (uint32_t) ((uint32_t) ts << 1);
+    else if (a->carry) sh = ts << 1;
+    else sh = ((uint64_t) (uint32_t) ((uint32_t) (ts >> 32) << 1) << 32) | (uint32_t) ((uint32_t) ts << 1);
+    uint64_t r = sh | (t & a->self) | a->seed;
+    for (uint32_t k = 0; k < a->nlut; k++) r |= a->lut[(size_t) k * 256 + ((t >> (8 * a->hot[k])) & 0xff)];
+    *t_out = t;
+    return r;
+}
+
+/* info[0..9] = has form, nbits, w64, carry, masked, evacc, nlut, cost, threads (valid bits), 0 */
+void nfa_sim_sa_info(void *h, int32_t *info)
+{
+    const sre_nfa_t *n = static_cast<sre_nfa_t *>(h);
+    for (int i = 0; i < 10; i++) info[i] = 0;
+    if (!n->sa) return;
+    const sre_nfa_sa_t *a = n->sa;
+    info[0] = 1; info[1] = (int32_t) a->nbits; info[2] = (int32_t) a->w64; info[3] = (int32_t) a->carry;
+    info[4] = (int32_t) a->masked; info[5] = (int32_t) a->evacc; info[6] = (int32_t) a->nlut; info[7] = (int32_t) a->cost;
+    info[8] = __builtin_popcountll(a->valid);
+}
+
+/* Runs the plain form and the shift-and form side by side over the buffer.  out[0] / out[1] as
+ * nfa_sim_run (from the shift-and form), out[2] = first position at which the two disagree (-1:
+ * never): the state sets (mapped through bit_of), the "only the .*? thread consumed" test, the event. */
+void nfa_sim_run_sa(void *h, const uint8_t *data, int64_t n, int variant, int64_t *out)
+{
+    const sre_nfa_t    *g = static_cast<sre_nfa_t *>(h);
+    const sre_nfa_sa_t *a = g->sa;
+    out[0] = out[1] = out[2] = -1;
+    if (!a) return;
+    uint64_t S = a->init[variant], G = g->init[variant];
+    int64_t  clean = 0, ev = -1, bad = -1;
+    auto map = [&](uint64_t gm) {
+        uint64_t m = 0;
+        for (uint32_t i = 0; i < g->nbits; i++) {
+            if (((gm >> i) & 1) && a->bit_of[i] >= 0) m |= 1ull << a->bit_of[i];
+        }
+        return m;
+    };
+    if (map(G) != (S & a->valid)) bad = 0;
+    for (int64_t p = 0; p < n; p++) {
+        uint64_t t, gt = G & g->accept[data[p]], gr = 0;
+        S = sa_step(a, S, data[p], &t);
+        for (uint32_t k = 0; k < g->nslices; k++) gr |= g->follow[(size_t) k * 256 + ((gt >> (8 * k)) & 0xff)];
+        G = gr;
+        const bool event = a->evacc ? (t & a->msrc) != 0 : (S & a->match_bits) != 0;
+        const bool gevent = (G & g->match_bits) != 0;
+        const bool cl = (t & ~a->any_bits) == 0, gcl = (gt & ~g->any_bits) == 0;
+        if (bad < 0 && (event != gevent || (!event && (cl != gcl || map(G) != (S & a->valid & ~a->match_bits))))) bad = p + 1;
+        if (event) {
+            ev = p;
+            break;
+        }
+        if (cl) clean = p + 1;
+    }
+    out[0] = ev;
+    out[1] = clean;
+    out[2] = bad;
 }
 
 }

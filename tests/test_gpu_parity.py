@@ -803,7 +803,27 @@ def test_nfa_tier_segments_vs_oracle(gpu, seg):
     window from the last clean position), forced, against the oracle: first match
     + captures and Thompson; small segments force speculative entry sets, the
     chain check and fix-up rounds."""
+    _nfa_zoo_vs_oracle(gpu, seg)
+
+
+# sre_nfa.h SRE_NFA_SA_*: every option set that selects another variant of the shift-and kernel
+# (masked shift, events from the consumed set, 64-bit masks with and without a carry, explicit ".*?"
+# thread without merging), and 128 = the plain slices only (the round-2 kernel)
+@pytest.mark.parametrize("sa", [1, 2, 4, 12, 48, 15, 100, 128])
+@pytest.mark.parametrize("seg", [64, 0])
+def test_nfa_tier_shift_and_variants_vs_oracle(gpu, seg, sa, monkeypatch):
+    monkeypatch.setenv("SRE_HIP_NFA_SA", str(sa))
+    kernels = _nfa_zoo_vs_oracle(gpu, seg)
+    print("sa option", sa, "kernels:", sorted(kernels))
+    if sa == 128:
+        assert not any("nfa_sa" in k for k in kernels), kernels
+    else:
+        assert any("nfa_sa" in k for k in kernels), kernels
+
+
+def _nfa_zoo_vs_oracle(gpu, seg):
     import random
+    kernels = set()
     ora = harness.OracleEngine()
     rng = random.Random(99 + seg)
     alphabets = [b"abc", b"ab c\n.x@:/?y,d", b"aaaaab", b"ab"]
@@ -819,6 +839,7 @@ def test_nfa_tier_segments_vs_oracle(gpu, seg):
             scs = {m: S.Scanner(pool, prog, m, S.ENGINE_NFA) for m in (S.HIP_THOMPSON, S.HIP_PIKE_FIRST)}
             for sc in scs.values():
                 assert sc.engine == S.ENGINE_NFA
+                kernels.add(sc.kernel_name)
                 if seg:
                     sc.set_segment_bytes(seg)
             datas = []
@@ -840,6 +861,7 @@ def test_nfa_tier_segments_vs_oracle(gpu, seg):
                                                      1 if first[0] >= 0 else 0], (pats, seg, d[:60])
             for b in bufs:
                 b.free()
+    return kernels
 
 
 def test_nfa_tier_takes_what_the_step_automaton_declines(gpu, blocks):

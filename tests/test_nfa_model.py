@@ -34,6 +34,10 @@ def sim(lib):
     L.nfa_sim_nbits.argtypes = [_vp]
     L.nfa_sim_nbits.restype = ctypes.c_uint32
     L.nfa_sim_run.argtypes = [_vp, ctypes.c_char_p, _i64, ctypes.c_int, ctypes.POINTER(_i64)]
+    L.nfa_sim_build2.restype = _vp
+    L.nfa_sim_build2.argtypes = [_vp, ctypes.c_uint, ctypes.POINTER(ctypes.c_char_p)]
+    L.nfa_sim_sa_info.argtypes = [_vp, ctypes.POINTER(ctypes.c_int32)]
+    L.nfa_sim_run_sa.argtypes = [_vp, ctypes.c_char_p, _i64, ctypes.c_int, ctypes.POINTER(_i64)]
     return L
 
 
@@ -118,3 +122,117 @@ def test_sets_random_patterns_vs_oracle(sim):
                     bad.append((pats, d, r))
     assert admitted > 2000, admitted
     assert not bad, (len(bad), bad[:5])
+
+
+# ---------------------------------------------------------------- the shift-and form
+
+SA_MASKED, SA_EVACC, SA_W64, SA_CARRY, SA_NO_MERGE, SA_EXPLICIT_ANY, SA_NO_EVACC = 1, 2, 4, 8, 16, 32, 64
+SA_OPTIONS = [0, SA_MASKED, SA_EVACC, SA_NO_EVACC, SA_W64, SA_W64 | SA_CARRY, SA_NO_MERGE | SA_EXPLICIT_ANY,
+              SA_MASKED | SA_EVACC | SA_W64 | SA_CARRY, SA_NO_EVACC | SA_W64 | SA_EXPLICIT_ANY]
+
+
+def _sa_info(sim, h):
+    info = (ctypes.c_int32 * 10)()
+    sim.nfa_sim_sa_info(h, info)
+    return dict(zip(("has", "nbits", "w64", "carry", "masked", "evacc", "nlut", "cost", "threads"), info))
+
+
+def _sa_check(sim, prog, datas, options):
+    """-> (info of the default form or None, complaints): the shift-and form against the plain form, step by step"""
+    bad, first = [], None
+    for opt in options:
+        why = ctypes.c_char_p()
+        h = sim.nfa_sim_build2(prog.h, opt, ctypes.byref(why))
+        if not h:
+            return None, bad
+        info = _sa_info(sim, h)
+        if opt == 0:
+            first = info
+        if info["has"]:
+            for d in datas:
+                for variant in (0, 1, 2):
+                    out = (_i64 * 3)()
+                    sim.nfa_sim_run_sa(h, bytes(d), len(d), variant, out)
+                    if out[2] >= 0:
+                        bad.append((opt, variant, info, d[:80], out[2]))
+                    ref = (_i64 * 3)()
+                    sim.nfa_sim_run(h, bytes(d), len(d), variant, ref)
+                    if (ref[0], ref[1]) != (out[0], out[1]):
+                        bad.append(("result", opt, variant, d[:80], tuple(ref)[:2], tuple(out)[:2]))
+        sim.nfa_sim_free(h)
+    return first, bad
+
+
+def test_shift_and_form_equals_the_plain_form_on_reference_blocks(sim, blocks):
+    """Every reference program without look-ahead assertions, every build option that selects
+    another kernel variant: the shift-and step lists exactly the threads the plain slices list
+    (through the bit map), sees the same events and the same clean positions."""
+    rng = random.Random(7)
+    alphabet = b"abcx \n_.@/:"
+    stats, bad, n = {}, [], 0
+    seen = set()
+    for blk in blocks:
+        subject = bytes.fromhex(blk["s"])
+        for name, regexes, flags, multi, ref in harness.block_variants(blk):
+            if ref["rc"] != 0 or (tuple(regexes), tuple(flags)) in seen:
+                continue
+            seen.add((tuple(regexes), tuple(flags)))
+            with S.Pool() as pool:
+                prog = S.compile(pool, S.parse(pool, regexes, flags, multi))
+                datas = [subject, subject * 3 + b"\n" + subject,
+                         bytes(rng.choice(alphabet) for _ in range(200))]
+                info, r = _sa_check(sim, prog, datas, SA_OPTIONS)
+                if info is None:
+                    continue
+                n += 1
+                key = (info["has"], info["w64"], info["nlut"]) if info["has"] else (0,)
+                stats[key] = stats.get(key, 0) + 1
+                if r:
+                    bad.append((regexes, r[:2]))
+    print("shift-and forms over the reference programs (has, w64, nlut):", sorted(stats.items()))
+    assert n > 1000, n
+    assert not bad, (len(bad), bad[:3])
+
+
+def test_shift_and_form_random_patterns(sim):
+    rng = random.Random(int(os.environ.get("SRE_FUZZ_SEED", "20261004")) + 11)
+    alphabet = b"abcx \n_."
+    n, bad, forms = 0, [], 0
+    for _ in range(1200):
+        nre = 1 if rng.random() < 0.8 else rng.randrange(2, 4)
+        pats = [harness.random_regex(rng) for _ in range(nre)]
+        with S.Pool() as pool:
+            try:
+                re = S.parse(pool, pats)
+            except Exception:
+                continue
+            prog = S.compile(pool, re)
+            datas = [bytes(rng.choice(alphabet) for _ in range(rng.choice([0, 1, 7, 40, 130, 400]))) for _ in range(4)]
+            info, r = _sa_check(sim, prog, datas, SA_OPTIONS)
+            if info is None:
+                continue
+            n += 1
+            forms += info["has"]
+            if r:
+                bad.append((pats, r[:2]))
+    assert n > 500 and forms > 300, (n, forms)
+    assert not bad, (len(bad), bad[:3])
+
+
+def test_shift_and_form_of_the_bench_programs(sim):
+    """the programs of bench.py's NFA variants: what the builder makes of them"""
+    cases = {
+        "nfa": ([rb"(?:a|b)*a(?:a|b){7}@"], dict(w64=0, nlut=1)),
+        "nfa37": ([b"a", b"ab", b"c", b"a(bc)", b"e(f)", b"gh", b"A", b"b", b"BLAH", rb"\s+", b"abcd", b"bc"], dict(w64=0, nlut=0)),
+    }
+    for name, (pats, want) in cases.items():
+        with S.Pool() as pool:
+            prog = S.compile(pool, S.parse(pool, pats))
+            why = ctypes.c_char_p()
+            h = sim.nfa_sim_build2(prog.h, 0, ctypes.byref(why))
+            info = _sa_info(sim, h)
+            sim.nfa_sim_free(h)
+            print(name, info)
+            assert info["has"], name
+            for k, v in want.items():
+                assert info[k] <= v, (name, k, info)
