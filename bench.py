@@ -45,12 +45,77 @@ def cpu_model():
     return None
 
 
-def cpu_baseline(sample_bytes=32 << 20):
+def _host_cores():
+    """threads the CPU legs may use: this process's affinity, at most 16 (a one-GPU box's share of its host)"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))
+
+
+def cpu_baseline_all_cores(per_stream=64 << 20):
+    """the CPU path on ALL host cores of this box, one 64 MiB stream of configs[4] per core
+    (the reference is single-threaded per stream; streams are independent): the reference's own
+    bench/sregex.c --thompson, one process per core, and the oracle/ Pike restatement, one thread per core."""
+    import sregex_amd as S
+    from concurrent.futures import ThreadPoolExecutor
+    cores = _host_cores()
+    data = S.gen_data_host(per_stream, b"aaabbccb")
+    out = {"unit": "GB/s", "cores": cores, "cpu_model": cpu_model(),
+           "sample": "%d streams x %d MiB (one per core), configs[4] pattern" % (cores, per_stream >> 20)}
+    ref_bin = os.path.join(ROOT, "oracle", "_ref", "sregex-bench")
+    if os.path.exists(ref_bin):
+        path = "/tmp/sre_bench_stream.txt"
+        with open(path, "wb") as f:
+            f.write(data)
+        try:
+            t0 = time.perf_counter()
+            procs = [subprocess.Popen([ref_bin, "--thompson", PATTERN.decode(), path], stdout=subprocess.PIPE,
+                                      stderr=subprocess.DEVNULL) for _ in range(cores)]
+            for p in procs:
+                p.communicate(timeout=600)
+            out["reference_thompson_value"] = cores * len(data) / (time.perf_counter() - t0) / 1e9
+            out["kind"] = "reference"
+        except Exception as e:          # noqa: BLE001
+            out["reference_error"] = repr(e)
+        finally:
+            os.unlink(path)
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import harness
+        with S.Pool() as pool:
+            prog = S.compile(pool, S.parse(pool, [PATTERN]))
+            ora = harness.OracleEngine()
+            bufs = [ctypes.create_string_buffer(data, len(data)) for _ in range(cores)]
+
+            def one(buf):
+                p = ora.pike(prog, 0)
+                rc = p.exec(None, True, want_pending=False, base=buf, offset=0, length=len(data))
+                p.close()
+                return rc
+
+            t0 = time.perf_counter()
+            with ThreadPoolExecutor(cores) as ex:       # ctypes releases the GIL for the call
+                list(ex.map(one, bufs))
+            out["port_value"] = cores * len(data) / (time.perf_counter() - t0) / 1e9
+            out.setdefault("kind", "port")
+    except Exception as e:              # noqa: BLE001
+        out["port_error"] = repr(e)
+    out["value"] = out.get("reference_thompson_value", out.get("port_value"))
+    return out
+
+
+def cpu_baseline(sample_bytes=32 << 20, big_sample=256 << 20):
     """The reference's own Pike path on the host cores of this box, one core
     (the reference is single-threaded; bench/sregex.c times one exec with
-    CLOCK_PROCESS_CPUTIME_ID), on a bounded prefix of the same workload."""
+    CLOCK_PROCESS_CPUTIME_ID), on a bounded prefix of the same workload: 32 MiB for the reference's
+    Pike VM (its capture vectors leak ~58 bytes per input byte, SURVEY.md note L: `value` is its
+    page-fault path — compare with thompson_value / port_value), 256 MiB for the
+    reference's Thompson VM and the leak-free port."""
     import sregex_amd as S
     data = S.gen_data_host(sample_bytes, b"aaabbccb")
+    big = S.gen_data_host(big_sample, b"aaabbccb")
     ref_bin = os.path.join(ROOT, "oracle", "_ref", "sregex-bench")
     out = {"unit": "GB/s", "cores": 1, "cpu_model": cpu_model()}
     if os.path.exists(ref_bin):
@@ -64,10 +129,13 @@ def cpu_baseline(sample_bytes=32 << 20):
             out.update(kind="reference", value=len(data) / ms / 1e6,
                        sample="%d MiB prefix of the workload, reference bench/sregex.c --pike "
                               "(oracle/_ref/sregex-bench), 1 core" % (sample_bytes >> 20))
+            with open(path, "wb") as f:
+                f.write(big)
             txt = subprocess.run([ref_bin, "--thompson", PATTERN.decode(), path], capture_output=True,
                                  text=True, timeout=600).stdout
             ms = float(txt.split(":")[-1].split("ms")[0].strip().split()[-1])
-            out["thompson_value"] = len(data) / ms / 1e6
+            out["thompson_value"] = len(big) / ms / 1e6
+            out["thompson_sample"] = "%d MiB prefix, reference bench/sregex.c --thompson, 1 core" % (big_sample >> 20)
         except Exception as e:          # noqa: BLE001 - report, do not hide
             out["reference_error"] = repr(e)
         finally:
@@ -79,12 +147,13 @@ def cpu_baseline(sample_bytes=32 << 20):
         with S.Pool() as pool:
             prog = S.compile(pool, S.parse(pool, [PATTERN]))
             p = harness.OracleEngine().pike(prog, 0)
-            buf = ctypes.create_string_buffer(data, len(data))
+            buf = ctypes.create_string_buffer(big, len(big))
             t0 = time.process_time()
-            rc = p.exec(None, True, want_pending=False, base=buf, offset=0, length=len(data))
+            rc = p.exec(None, True, want_pending=False, base=buf, offset=0, length=len(big))
             dt = time.process_time() - t0
             p.close()
-        port = len(data) / dt / 1e9
+        port = len(big) / dt / 1e9
+        out["port_sample"] = "%d MiB prefix, oracle/ Pike restatement, 1 core" % (big_sample >> 20)
         if "value" not in out:
             out.update(kind="port", value=port,
                        sample="%d MiB prefix of the workload, oracle/ Pike restatement, 1 core"
@@ -102,12 +171,21 @@ URI = rb"([a-z]+)://([^/ ]+)(/[^ ?]*)?(\?[^ ]*)?"
 # a program the <= 55-state step automaton declines (256+ ordered lists) with 19 list-able
 # threads: runs on the 64-bit-mask NFA tier
 NFA_PAT = rb"(?:a|b)*a(?:a|b){7}@"
+# ... 60 list-able threads (2^28 ordered lists); the two arms of every (?:a|b) are one thread of the
+# shift-and form, which then fits 32 bits
+NFA60_PAT, NFA60_TAIL = rb"(?:a|b)*a(?:a|b){27}@", b" " + b"ab" * 15 + b"@ "
+# ... 57 list-able threads, 54 after merging: 64-bit masks
+NFA57_PAT, NFA57_TAIL = rb"(?:a|b)*a[ab]{20}c[^x]{30}@", b" " + b"a" * 22 + b"c" + b"b" * 30 + b"@ "
+# configs[2]'s 37-thread program FORCED onto the NFA tier (the table-driven scanner takes it by itself),
+# first match: the stream must not match before its end, so its body is "BLegx" (partial matches of
+# BLAH, e(f), gh at every position, never a whole one) and the tail "BLAH"
+NFA37_BODY, NFA37_TAIL = b"BLegx", b"BLAH"
 
 
 def workload_spec(name, S, nbytes, rank=0, world=1):
     """name -> dict(pats, mode, lens, tails, text, check(lens, tails, recs))"""
     from sregex_amd import shard
-    pats, mode = [PATTERN], S.HIP_PIKE_FIRST
+    pats, mode, engine, body = [PATTERN], S.HIP_PIKE_FIRST, S.ENGINE_AUTO, None
     if name == "many":
         per = 64 << 20
         nstreams = max(1, nbytes // per)
@@ -134,6 +212,20 @@ def workload_spec(name, S, nbytes, rank=0, world=1):
         elif name == "nfa":
             pats, tail = [NFA_PAT], b" abaabaabab@ "
             text = "declined by the step automaton: /(?:a|b)*a(?:a|b){7}@/ Pike first-match, NFA tier"
+        elif name == "floor":
+            # worst case for the table-driven scanner: a look-ahead match every 4 bytes, so every
+            # 64-byte round of every lane leaves the fast path (find-all count of \bfoo\b over "foo foo foo ..")
+            pats, mode, body, tail = [rb"\bfoo\b"], S.HIP_PIKE_COUNT, b"foo ", b"foo "
+            text = "scanner floor: /\\bfoo\\b/ find-all count over 'foo ' repeated (a look-ahead match every 4 bytes)"
+        elif name == "nfa60":
+            pats, tail = [NFA60_PAT], NFA60_TAIL
+            text = "declined by the step automaton, 60 list-able threads: /(?:a|b)*a(?:a|b){27}@/ Pike first-match, NFA tier"
+        elif name == "nfa57w":
+            pats, tail = [NFA57_PAT], NFA57_TAIL
+            text = "declined by the step automaton, 57 list-able threads (64-bit masks): /(?:a|b)*a[ab]{20}c[^x]{30}@/ Pike first-match, NFA tier"
+        elif name == "nfa37":
+            pats, tail, engine, body = CFG3, NFA37_TAIL, S.ENGINE_NFA, NFA37_BODY
+            text = "configs[2]'s 12 regexes (37 list-able threads) forced onto the NFA tier, Pike first-match, body 'BLegx'"
         elif name in ("dense", "densef", "densela"):
             # a match every MiB: the stream is one 1 MiB gen-data block with a matching tail, repeated
             block = S.gen_data_length(1 << 20, 10)
@@ -150,8 +242,10 @@ def workload_spec(name, S, nbytes, rank=0, world=1):
                             if name != "densef" else
                             (lambda recs, b=block: _assert_eq(recs[0], [0, 1, b - 9, b - 1]))))
         n = S.gen_data_length(nbytes, len(tail))
+        if body and len(body) != 5:
+            n = (nbytes - len(tail)) // len(body) * len(body) + len(tail)
         lens, tails = [n], [tail]
-        text = "%s; 1 stream x %.2f GiB gen-data (abccc.. + %r)" % (text, n / GIB, tail.decode())
+        text = "%s; 1 stream x %.2f GiB gen-data (%s.. + %r)" % (text, n / GIB, (body or b"abccc").decode(), tail.decode())
 
     def check(recs):
         # correctness of what is being timed (size-independent closed forms, each
@@ -165,13 +259,19 @@ def workload_spec(name, S, nbytes, rank=0, world=1):
                 assert r[:2] == [0, 1], r
             elif name == "nfa":
                 assert r[:4] == [0, 1, n - 12, n - 1], (r, n)
+            elif name in ("nfa60", "nfa57w"):
+                assert r[:4] == [0, 1, n - (len(t) - 1), n - 1], (r, n)      # from behind the tail's first blank to its '@'
+            elif name == "nfa37":
+                assert r == [8, 1, n - 4, n, -1, -1], (r, n)                 # regex 8 = BLAH
+            elif name == "floor":
+                assert r == [0, n // 4, n - 4, n - 1], (r, n)                # one match per "foo ", the last one
             elif t == b"@abc.cc ":
                 assert r[:4] == [0, 1, 0, n - 1], (r, n)         # the match spans the whole stream
             elif b"@" in t:
                 assert r[:4] == [0, 1, n - 9, n - 1], (r, n)      # "a@abc.cc" in front of the last space
             else:
                 assert r[0] == S.SRE_DECLINED and r[1] == 0, r
-    return dict(name=name, pats=pats, mode=mode, lens=lens, tails=tails, text=text, check=check)
+    return dict(name=name, pats=pats, mode=mode, lens=lens, tails=tails, text=text, check=check, engine=engine, body=body)
 
 
 def _assert_eq(got, want):
@@ -192,14 +292,21 @@ class Resident:
             self._side[k] = self.torch.cuda.Stream()
         return self._side[k]
 
-    def fill(self, lens, tails, block=0):
+    def fill(self, lens, tails, block=0, body=None):
         need = [max(n, 16) for n in lens]
         if [b.numel() for b in self.bufs] != need:
             self.bufs = []
             self.torch.cuda.empty_cache()
             self.bufs = [self.torch.empty(n, dtype=self.torch.uint8, device="cuda") for n in need]
         for b, n, t in zip(self.bufs, lens, tails):
-            if block:
+            if body:
+                # another period than gen-data's "abccc": body x k + tail
+                pat = self.torch.tensor(list(body), dtype=self.torch.uint8, device="cuda")
+                k = (n - len(t)) // len(body)
+                assert k * len(body) + len(t) == n, (n, len(body), len(t))
+                b[:k * len(body)].view(-1, len(body)).copy_(pat.expand(k, len(body)))
+                b[k * len(body):n].copy_(self.torch.tensor(list(t), dtype=self.torch.uint8, device="cuda"))
+            elif block:
                 # one generated block, repeated (a device-to-device broadcast copy)
                 assert self.lib.sre_hip_gen_data(b.data_ptr(), block, t, len(t), self.hstream) == 0
                 self.torch.cuda.synchronize()
@@ -212,7 +319,7 @@ class Resident:
 def measure(spec, S, torch, res, hstream, stream, steps, warmup, barrier):
     """W untimed + K timed passes of one workload over this rank's resident input,
     through the public batched C ABI, results included."""
-    ptrs = res.fill(spec["lens"], spec["tails"], spec.get("block", 0))
+    ptrs = res.fill(spec["lens"], spec["tails"], spec.get("block", 0), spec.get("body"))
     lens = spec["lens"]
     pool = S.Pool()
     prog = S.compile(pool, S.parse(pool, spec["pats"]))
@@ -221,7 +328,7 @@ def measure(spec, S, torch, res, hstream, stream, steps, warmup, barrier):
     # queued work), and the small kernels behind a scan (chain check, captures, the copy
     # of the records) overlap with the next scan instead of sitting between two of them
     depth = max(2, int(os.environ.get("SRE_BENCH_DEPTH", "2")))       # scanners (steps) in flight
-    scs = [S.Scanner(pool, prog, spec["mode"], S.ENGINE_AUTO) for _ in range(depth)]
+    scs = [S.Scanner(pool, prog, spec["mode"], spec.get("engine", S.ENGINE_AUTO)) for _ in range(depth)]
     sc = scs[0]
     if sc.engine == S.ENGINE_VM and sum(lens) > (64 << 20):
         pool.destroy()
@@ -326,7 +433,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true",
                     help="N=1: do not measure the other configurations beside the headline (config.variants)")
-    ap.add_argument("--config", default="cfg2", choices=["cfg1", "cfg2", "cfg2m", "cfg3", "cfg4", "nfa", "dense", "densef", "densela"],
+    ap.add_argument("--config", default="cfg2", choices=["cfg1", "cfg2", "cfg2m", "cfg3", "cfg4", "nfa", "nfa37", "nfa60", "nfa57w", "dense", "densef", "densela", "floor"],
                     help="N=1 headline workload: cfg2 = BASELINE configs[1] (default); cfg2m = same with a "
                          "matching tail (captures span the whole stream); cfg3 = configs[2] multi-regex "
                          "find-all count; cfg4 = configs[3] URI, 4 groups; cfg1 = configs[0]'s pattern, "
@@ -372,6 +479,13 @@ def main():
 
     dt = shard.allreduce_max(m["dt"], "cuda")                        # slowest rank
     matches, total_all = shard.allreduce_counts([m["matches"], m["total"]], "cuda")   # the path's only exchange step
+    fixups = shard.allreduce_max(float(m["fixup_rounds"]), "cuda")
+    if many:
+        # every second stream ends in a matching tail: half of the rank's streams, on every rank, and the
+        # speculative entry states of this workload settle without a fix-up round
+        want = (len(head["lens"]) * world + 1) // 2          # the even global stream indices
+        assert matches == want, ("all-reduced match count", matches, want)
+        assert fixups == 0, ("fix-up rounds on some rank", fixups)
     devices = shard.allgather_ints(device, "cuda")                   # which ordinal each rank drives
 
     if rank == 0:
@@ -431,9 +545,13 @@ def main():
             # time and whole-step fraction of the HBM peak (every kernel of the step), the
             # dominant kernel alone beside it
             variants = {}
-            for name in ("cfg2m", "cfg3", "cfg4", "nfa", "dense", "densef", "densela", "many"):
+            sweep = {"size_1.0GiB": GIB, "size_2.5GiB": 5 * GIB // 2, "size_3.3GiB": 33 * GIB // 10, "size_6.0GiB": 6 * GIB}
+            for name in ("cfg2m", "cfg3", "cfg4", "nfa", "nfa37", "nfa60", "nfa57w", "dense", "densef", "densela", "floor",
+                         "many") + tuple(sweep):
                 try:
-                    vs = workload_spec(name, S, 8 * GIB if name == "many" else args.bytes)
+                    # size_*: the headline workload at other stream lengths (the segment geometry follows the total)
+                    vs = workload_spec("cfg2" if name in sweep else name, S,
+                                       sweep[name] if name in sweep else 8 * GIB if name == "many" else args.bytes)
                     vm = measure(vs, S, torch, res, hstream, stream, min(args.steps, 6), 2, barrier)
                     r = roofline(vm)
                     variants[name] = {"workload": vs["text"], "ms_per_step": vm["dt"] / min(args.steps, 6) * 1e3,
@@ -441,7 +559,9 @@ def main():
                                       "kernel": vm["kernel"], "kernel_ms": vm["kernel_ms"],
                                       "kernel_frac": r["kernel_frac"], "engine": vm["engine"],
                                       "matches": vm["matches"], "fixup_rounds": vm["fixup_rounds"],
-                                      "lineage_passes": vm["lineage_passes"]}
+                                      "lineage_passes": vm["lineage_passes"], "segment_bytes": vm["segment_bytes"]}
+                    if name == "many" and not args.no_cpu_baseline:
+                        variants[name]["cpu_baseline_all_cores"] = cpu_baseline_all_cores()
                 except Exception as e:          # noqa: BLE001 - a variant must not take the headline down
                     variants[name] = {"error": repr(e)}
             line["config"]["variants"] = variants

@@ -252,7 +252,75 @@ def findall_goldens(path):
             ref.L.sre_destroy_pool(pool)
 
 
+# ---------------------------------------------------------------- SRE_REGEX_NEWLINE goldens
+
+# flag 2 = SRE_REGEX_NEWLINE ('.' and \C do not match "\n", src/sregex/sre_yyparser.y:293-297, :865-869),
+# 3 = with SRE_REGEX_CASELESS.  The reference CLI has no switch for it, so the library is driven directly:
+# AST dump, program dump and the first match over a subject with newlines.
+NEWLINE_CASES = [
+    ([b"."], [2]), ([b"a.b"], [2]), ([rb"\C"], [2]), ([rb"a\Cb"], [2]), ([b".*"], [2]), ([b".+x"], [2]),
+    ([b"(.)(.)"], [2]), ([b"[^a]"], [2]), ([b"[^a]."], [2]), ([rb"\N."], [2]), ([rb".\n."], [2]),
+    ([rb"\s.\S"], [2]), ([b"a.?b"], [2]), ([b"a.{2,3}b"], [2]), ([b"(?:.|x)y"], [2]), ([b"^.$"], [2]),
+    ([b".\\z"], [2]), ([rb"\b.\b"], [2]), ([b"A.b"], [3]), ([b"[a-c].D"], [3]), ([rb"\C+"], [3]),
+    ([b"a.", b".b"], [2, 2]), ([b"a.", b".b"], [2, 0]), ([b"a.", b".b"], [0, 2]), ([b"x.y", rb"\C\C", b"."], [2, 3, 0]),
+    ([b"."], [0]), ([rb"\C"], [0]), ([b"a.b"], [1]),
+]
+NEWLINE_SUBJECTS = [b"a\nb a.b AxB\n\nxy", b"\n", b"ab\ncd", b"", b"x\ny a\n\nb"]
+
+
+def _capture_stdout(fn):
+    libc = ctypes.CDLL(None)
+    libc.fflush(None)
+    import tempfile
+    with tempfile.TemporaryFile() as tf:
+        saved = os.dup(1)
+        os.dup2(tf.fileno(), 1)
+        try:
+            fn()
+            libc.fflush(None)
+        finally:
+            os.dup2(saved, 1)
+            os.close(saved)
+        tf.seek(0)
+        return tf.read()
+
+
+def newline_goldens(path):
+    ref = RefLib()
+    L = ref.L
+    L.sre_regex_dump.argtypes = [ctypes.c_void_p]
+    L.sre_program_dump.argtypes = [ctypes.c_void_p]
+    with open(path, "w") as f:
+        for pats, flags in NEWLINE_CASES:
+            pool = L.sre_create_pool(4096)
+            ncaps = ctypes.c_size_t(0)
+            eo = ctypes.c_ssize_t(-1)
+            if len(pats) == 1:
+                re = L.sre_regex_parse(pool, pats[0], ctypes.byref(ncaps), flags[0], ctypes.byref(eo))
+            else:
+                arr = (ctypes.c_char_p * len(pats))(*pats)
+                fl = (ctypes.c_int * len(pats))(*flags)
+                ei = ctypes.c_ssize_t(-1)
+                re = L.sre_regex_parse_multi(pool, arr, len(pats), ctypes.byref(ncaps), fl, ctypes.byref(eo), ctypes.byref(ei))
+            assert re, (pats, flags)
+            ast = _capture_stdout(lambda: L.sre_regex_dump(re)).decode("latin-1")
+            prog = L.sre_regex_compile(pool, re)
+            assert prog
+            pdump = _capture_stdout(lambda: L.sre_program_dump(prog)).decode("latin-1")
+            runs = []
+            for subj in NEWLINE_SUBJECTS:
+                rc, ov = ref.pike_first(prog, ncaps.value, subj)
+                runs.append({"s": subj.hex(), "thompson": ref.thompson(prog, subj), "pike_rc": rc,
+                             "pike_ov": ov if rc >= 0 else None})
+            f.write(json.dumps({"re": [p.hex() for p in pats], "flags": flags, "ncaps": ncaps.value,
+                                "ast": ast, "prog": pdump, "runs": runs}) + "\n")
+            L.sre_destroy_pool(pool)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--newline-only":
+        newline_goldens(os.path.join(HERE, "newline_flag.jsonl"))
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "--gen-data-only":
         gen_data_goldens(os.path.join(HERE, "gen_data.jsonl"))
         return

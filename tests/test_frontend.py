@@ -65,9 +65,23 @@ def test_quantifier_stacking_is_rejected_at_the_second_quantifier(lib):
                 raise AssertionError("accepted %r" % src)
 
 
+def test_newline_flag_against_the_reference_library(lib):
+    """SRE_REGEX_NEWLINE ('.' and \\C become [^\\n], sre_yyparser.y:293-297, :865-869), alone, with
+    SRE_REGEX_CASELESS and per regex of a multi-regex parse: AST dump and program dump equal what the
+    real reference library printed (tests/golden/newline_flag.jsonl, made by make_goldens.py
+    --newline-only from oracle/_ref/libsregex_ref.so; the reference CLI has no switch for the flag)."""
+    recs = harness.load_jsonl("newline_flag.jsonl")
+    assert len(recs) >= 25
+    for r in recs:
+        pats = [bytes.fromhex(h) for h in r["re"]]
+        with S.Pool() as pool:
+            re = S.parse(pool, pats, r["flags"])
+            assert re.ncaps == r["ncaps"], (pats, r["flags"])
+            assert re.dump() == r["ast"], (pats, r["flags"], re.dump(), r["ast"])
+            assert S.compile(pool, re).dump() == r["prog"], (pats, r["flags"])
+
+
 def test_newline_flag_turns_dot_into_not_newline(lib):
-    # SRE_REGEX_NEWLINE: '.' and \C become [^\n] (sre_yyparser.y:293-297, 865-869);
-    # not exercised by the reference CLI => checked against the documented shape only
     with S.Pool() as pool:
         re = S.parse(pool, [b"a.\\C"], [S.SRE_REGEX_NEWLINE])
         assert re.dump() == ("Cat(NgStar(Dot), TOPLEVEL(0, Paren(0, Cat(Cat(Lit(97), NCLASS([10, 10])), "

@@ -929,6 +929,76 @@ def test_nfa_tier_large_stream_closed_form(gpu):
         buf.free()
 
 
+def test_bench_floor_variant_closed_form_vs_oracle(gpu):
+    """bench.py's `floor` variant (a look-ahead match every 4 bytes: every round of every lane leaves the
+    scan kernel's fast path): the closed form it asserts at 4 GiB, against the oracle at small sizes."""
+    ora = harness.OracleEngine()
+    with S.Pool() as pool:
+        re = S.parse(pool, [rb"\bfoo\b"])
+        prog = S.compile(pool, re)
+        sc = S.Scanner(pool, prog, S.HIP_PIKE_COUNT, S.ENGINE_AUTO)
+        assert sc.engine == S.ENGINE_SCAN
+        for k in (1, 17, 5000):
+            data = b"foo " * k
+            _, cnt = _expect(ora, prog, re.ncaps, data)
+            n = len(data)
+            assert cnt == [0, n // 4, n - 4, n - 1], (k, cnt)
+            buf = S.DeviceBuffer.from_bytes(data)
+            rec = sc.scan([buf.ptr], [n])[0]
+            buf.free()
+            assert rec == cnt, (k, rec, cnt)
+
+
+def test_newline_flag_exec_vs_reference_goldens(gpu):
+    """programs parsed with SRE_REGEX_NEWLINE through the compat API: Thompson status, Pike rc and
+    ovector equal the real reference library's (tests/golden/newline_flag.jsonl)."""
+    n = 0
+    for r in harness.load_jsonl("newline_flag.jsonl"):
+        pats = [bytes.fromhex(h) for h in r["re"]]
+        with S.Pool() as pool:
+            prog = S.compile(pool, S.parse(pool, pats, r["flags"]))
+            for run in r["runs"]:
+                subj = bytes.fromhex(run["s"])
+                t = S.ThompsonCtx(pool, prog)
+                assert t.exec(subj, True) == run["thompson"], (pats, r["flags"], subj)
+                p = S.PikeCtx(pool, prog, r["ncaps"])
+                rc = p.exec(subj, True)
+                assert rc == run["pike_rc"], (pats, r["flags"], subj, rc)
+                if rc >= 0:
+                    assert list(p.ovector) == run["pike_ov"], (pats, r["flags"], subj, list(p.ovector))
+                n += 1
+    assert n >= 125, n
+
+
+def test_bench_nfa_variants_closed_forms_vs_oracle(gpu):
+    """bench.py's NFA-tier variants (nfa37: configs[2]'s program forced onto the tier over a body that
+    never matches; nfa60 / nfa57w: declined programs with ~60 list-able threads): the closed forms
+    bench.py asserts at 4 GiB, checked against the oracle at a size it finishes, on the kernels the
+    bench measures."""
+    import bench
+    ora = harness.OracleEngine()
+    cases = [
+        ("nfa37", bench.CFG3, bench.NFA37_BODY, bench.NFA37_TAIL, S.ENGINE_NFA, lambda n, t: [8, 1, n - 4, n, -1, -1]),
+        ("nfa60", [bench.NFA60_PAT], b"abccc", bench.NFA60_TAIL, S.ENGINE_AUTO, lambda n, t: [0, 1, n - (len(t) - 1), n - 1]),
+        ("nfa57w", [bench.NFA57_PAT], b"abccc", bench.NFA57_TAIL, S.ENGINE_AUTO, lambda n, t: [0, 1, n - (len(t) - 1), n - 1]),
+    ]
+    for name, pats, body, tail, engine, want in cases:
+        with S.Pool() as pool:
+            re = S.parse(pool, pats)
+            prog = S.compile(pool, re)
+            for size in (3000, 200000):
+                data = body * ((size - len(tail)) // len(body)) + tail
+                first, _ = _expect(ora, prog, re.ncaps, data)
+                assert first == want(len(data), tail), (name, size, first, want(len(data), tail))
+                sc = S.Scanner(pool, prog, S.HIP_PIKE_FIRST, engine)
+                assert sc.engine == S.ENGINE_NFA and "nfa_sa" in sc.kernel_name, (name, sc.engine, sc.kernel_name)
+                buf = S.DeviceBuffer.from_bytes(data)
+                rec = sc.scan([buf.ptr], [len(data)])[0]
+                buf.free()
+                assert rec == first, (name, size, rec, first)
+            print(name, sc.kernel_name)
+
+
 # ------------------------------------------------------------ randomised differential
 
 @pytest.mark.parametrize("seg", [64, 0])

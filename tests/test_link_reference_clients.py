@@ -20,11 +20,8 @@ pytestmark = pytest.mark.skipif(not os.path.exists(REF + "/src/sre_cli.c"),
 
 
 def _cc(src, exe, extra=()):
-    os.makedirs(OUT, exist_ok=True)
-    libdir = os.path.join(ROOT, "sregex_amd", "lib")
-    cmd = ["gcc", "-O2", "-w", "-I" + os.path.join(ROOT, "include"), src, "-L" + libdir, "-lsregex",
-           "-Wl,-rpath," + libdir, "-o", os.path.join(OUT, exe)] + list(extra)
-    subprocess.check_call(cmd)
+    # oracle/Makefile `clients`: gcc on the reference's file where it lies, -lsregex = the product library
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "clients"])
     return os.path.join(OUT, exe)
 
 
