@@ -23,6 +23,12 @@ pytestmark = [pytest.mark.gpu,
                                  reason="client binaries not built (needs the reference's sources: make -C oracle clients)")]
 
 
+@pytest.fixture(scope="module")
+def gpu(lib):
+    assert lib.sre_hip_device_count() >= 1, "no HIP device: the product has no CPU path"
+    return lib
+
+
 def _run_cli(res, flags, subject, multi):
     # how t/SRegex.pm:73-84 drives the CLI (tests/golden/make_goldens.py run_cli)
     args = [CLI, "--stdin"]
