@@ -83,6 +83,16 @@ SRE_API int sre_hip_scanner_last_exact_passes(sre_hip_scanner_t *sc);
  * stream through the table-driven scanner, out[2] the exact VM kernel */
 SRE_API void sre_hip_compat_route_counts(unsigned long long out[3]);
 
+/* The compat entry points (sregex.h) keep released device streams — a HIP stream, a VM context, staging
+ * buffers of at most 8 MiB each — in a process-wide free list of at most 32 for the next context.  This
+ * call frees them all and returns how many there were.
+ * THREADS: as in the reference, distinct programs and pools may be used from different threads (the
+ * library's process-wide state is locked); the contexts of ONE program must not run concurrently (they
+ * share the program's device scanners — the reference's programs carry the VM's generation tags,
+ * src/sregex/sre_vm_bytecode.h:51, and are not re-entrant either).  A scanner of the batched API below
+ * belongs to one thread at a time. */
+SRE_API int sre_hip_compat_trim(void);
+
 /* diagnostics: 1 when the last scan had to build per-segment ancestor maps to
  * reconstruct the captures of a match spanning many segments */
 SRE_API int sre_hip_scanner_last_lineage_passes(sre_hip_scanner_t *sc);

@@ -62,6 +62,7 @@ API = {
     "sre_hip_scanner_last_lineage_passes": (ctypes.c_int, [_vp]),
     "sre_hip_scanner_last_exact_passes": (ctypes.c_int, [_vp]),
     "sre_hip_compat_route_counts": (None, [ctypes.POINTER(ctypes.c_ulonglong)]),
+    "sre_hip_compat_trim": (ctypes.c_int, []),
     "sre_hip_scanner_set_tail_stream": (ctypes.c_int, [_vp, _vp]),
     "sre_hip_scanner_class_bits": (ctypes.c_int, [_vp]),
     "sre_hip_scanner_kernel_name": (ctypes.c_char_p, [_vp]),
@@ -85,6 +86,12 @@ _lib = None
 _libc = None
 
 
+def _missing_symbol(name, path):
+    def fail(*_a, **_k):
+        raise RuntimeError("%s is not exported by %s (SREGEX_AMD_LIB points at an older build)" % (name, path))
+    return fail
+
+
 def load_library(path=None):
     """Load libsregex.so and declare every entry point.  Fails loudly if the
     library has not been built (see __graft_entry__.build())."""
@@ -99,7 +106,10 @@ def load_library(path=None):
     lib = ctypes.CDLL(p)
     for name, (res, args) in API.items():
         if os.environ.get("SREGEX_AMD_LIB") and not hasattr(lib, name):
-            continue                 # an older build given for an A/B run (tools/exp_knobs.sh)
+            # an older build given for an A/B run (tools/exp_knobs.sh) may lack the newest entry points:
+            # such a name fails on first USE with a clear message, never with ctypes' default int restype
+            setattr(lib, name, _missing_symbol(name, p))
+            continue
         fn = getattr(lib, name)      # AttributeError if a declared symbol is not exported
         fn.restype = res
         fn.argtypes = args

@@ -24,20 +24,29 @@
  * sre_uint_t, sre_regex_compiler.c:244, and then fails its single allocation).
  * Counting saturates here and stops walking once the cap is passed. */
 #define SRE_MAX_PROGRAM_LEN  (1u << 24)
+/* ... and the WORK is bounded, not only the result: a nest of shared subtrees that emits nothing
+ * — (?:(?:(?:(?:){499}){499}){499}){499} — never reaches the length cap and would be walked
+ * 499^4 times (round-2 advisor finding).  Node visits count against a cap of their own; past it
+ * the count saturates and sre_regex_compile() fails as for a program that is too long. */
+#define SRE_MAX_COMPILE_VISITS  (4ull * SRE_MAX_PROGRAM_LEN)
 
 static void
-count_insns(const sre_regex_t *r, uint64_t *n, uint64_t *nranges)
+count_insns(const sre_regex_t *r, uint64_t *n, uint64_t *nranges, uint64_t *visits)
 {
     if (*n > SRE_MAX_PROGRAM_LEN) return;       /* saturated: end the walk early */
+    if (++*visits > SRE_MAX_COMPILE_VISITS) {
+        *n = (uint64_t) SRE_MAX_PROGRAM_LEN + 1;
+        return;
+    }
     switch (r->type) {
     case SRE_RE_ALT:
         *n += 2;
-        count_insns(r->left, n, nranges);
-        count_insns(r->right, n, nranges);
+        count_insns(r->left, n, nranges, visits);
+        count_insns(r->right, n, nranges, visits);
         break;
     case SRE_RE_CAT:
-        count_insns(r->left, n, nranges);
-        count_insns(r->right, n, nranges);
+        count_insns(r->left, n, nranges, visits);
+        count_insns(r->right, n, nranges, visits);
         break;
     case SRE_RE_CLASS:
     case SRE_RE_NCLASS:
@@ -52,13 +61,13 @@ count_insns(const sre_regex_t *r, uint64_t *n, uint64_t *nranges)
     case SRE_RE_PAREN:
     case SRE_RE_STAR:
         *n += 2;
-        count_insns(r->left, n, nranges);
+        count_insns(r->left, n, nranges, visits);
         break;
     case SRE_RE_QUEST:
     case SRE_RE_PLUS:
     case SRE_RE_TOPLEVEL:
         *n += 1;
-        count_insns(r->left, n, nranges);
+        count_insns(r->left, n, nranges, visits);
         break;
     case SRE_RE_NIL:
     default:
@@ -235,10 +244,10 @@ sre_regex_compile(sre_pool_t *pool, sre_regex_t *re)
     sre_program_t *prog;
     sre_emit_t     e;
     uint32_t       n, nranges, i;
-    uint64_t       n64 = 0, nranges64 = 0;
+    uint64_t       n64 = 0, nranges64 = 0, visits = 0;
     uint8_t       *seen;
 
-    count_insns(re, &n64, &nranges64);
+    count_insns(re, &n64, &nranges64, &visits);
     if (n64 > SRE_MAX_PROGRAM_LEN || nranges64 > 16ull * SRE_MAX_PROGRAM_LEN) return NULL;
     n = (uint32_t) n64;
     nranges = (uint32_t) nranges64;

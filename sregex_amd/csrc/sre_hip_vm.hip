@@ -818,6 +818,11 @@ sre_k_pike_exec(const uint8_t *__restrict__ blob, const sre_dev_req_t *__restric
         sre_dev_result_t *res = static_cast<sre_dev_result_t *>(rq.result);
         int64_t          *ov = reinterpret_cast<int64_t *>(res + 1);
         res->rc = vm.exec(rq.size, rq.eof, rq.want_pending != 0, res, ov, rq.ovec_slots, &rq);
+        /* what the context holds between two searches (the host mirrors it after a match, so the
+         * next search may run on a throughput scanner again: sre_vm_api.cpp) */
+        res->pad[0] = 16 | (vm.h->empty_capture ? SRE_PRESET_EMPTY_CAPTURE : 0) | (vm.h->seen_newline ? SRE_PRESET_SEEN_NEWLINE : 0)
+                      | (vm.h->seen_word ? SRE_PRESET_SEEN_WORD : 0) | (vm.h->eof ? SRE_PRESET_EOF : 0);
+        res->pad[1] = vm.h->processed_bytes;
     }
     if (use_lds) {
         __syncthreads();

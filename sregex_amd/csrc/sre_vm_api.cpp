@@ -21,6 +21,8 @@
 #include <sregex_hip.h>
 #include <stddef.h>
 #include <stdio.h>
+#include <atomic>
+#include <mutex>
 #include <stdlib.h>
 #include <string.h>
 
@@ -85,10 +87,19 @@ struct DeviceStream {
  * stream + two device allocations + a pinned block cost milliseconds to create.
  * Released device streams are therefore parked in a process-wide free list and
  * handed to the next context that fits (same device, large enough), with the VM
- * state zero-filled again.  The list is bounded; the API is single-threaded by
- * contract, so no lock.
+ * state zero-filled again.  The list is bounded, and so is what a parked stream may
+ * keep: a staging buffer above SRE_PARK_KEEP_BYTES is freed when its stream is parked
+ * (a client that once fed multi-GiB buffers through short-lived contexts would pin that
+ * much HBM for the life of the process), and sre_hip_compat_trim() empties the list.
+ * The reference has no globals — separate programs and pools may be used from different
+ * threads — so the process-wide state of this file is guarded: g_mutex for
+ * the parked list and for the creation of a program's scanners, atomics for the counters.
+ * (One PROGRAM is not re-entrant, as in the reference, whose instructions carry the VM's
+ * generation tags: its contexts share the program's scanners here.)
  */
 #define SRE_STREAM_CACHE_MAX 32
+#define SRE_PARK_KEEP_BYTES  (8u << 20)
+std::mutex    g_mutex;
 DeviceStream *g_parked[SRE_STREAM_CACHE_MAX];
 int           g_nparked = 0;
 
@@ -112,10 +123,19 @@ void
 device_stream_release(void *data)
 {
     DeviceStream *ds = static_cast<DeviceStream *>(data);
-    if (!ds->failed && g_nparked < SRE_STREAM_CACHE_MAX) {
-        ds->dp = NULL;                      /* the program may be gone before the next use */
-        g_parked[g_nparked++] = ds;
-        return;
+    if (!ds->failed) {
+        if (ds->in_cap > SRE_PARK_KEEP_BYTES) {
+            /* (the stream has no work in flight: every exec is synchronous on return) */
+            (void) hipFree(ds->d_in);
+            ds->d_in = NULL;
+            ds->in_cap = 0;
+        }
+        std::lock_guard<std::mutex> lock(g_mutex);
+        if (g_nparked < SRE_STREAM_CACHE_MAX) {
+            ds->dp = NULL;                  /* the program may be gone before the next use */
+            g_parked[g_nparked++] = ds;
+            return;
+        }
     }
     device_stream_destroy(ds);
 }
@@ -128,12 +148,15 @@ device_stream_open(sre_pool_t *pool, sre_program_t *prog, size_t ctx_bytes, size
     const size_t blk = sizeof(HostBlock) + ovec_slots * sizeof(int64_t);
 
     DeviceStream *ds = NULL;
-    for (int i = 0; i < g_nparked; i++) {
-        DeviceStream *c = g_parked[i];
-        if (c->device == dp->device && c->ctx_cap >= ctx_bytes && c->blk_cap >= blk) {
-            ds = c;
-            g_parked[i] = g_parked[--g_nparked];
-            break;
+    {
+        std::lock_guard<std::mutex> lock(g_mutex);
+        for (int i = 0; i < g_nparked; i++) {
+            DeviceStream *c = g_parked[i];
+            if (c->device == dp->device && c->ctx_cap >= ctx_bytes && c->blk_cap >= blk) {
+                ds = c;
+                g_parked[i] = g_parked[--g_nparked];
+                break;
+            }
         }
     }
     if (ds != NULL) {
@@ -318,6 +341,7 @@ compat_scanner(sre_program_t *prog, int mode, int chunked = 0)
     /* chunked: the automaton of a look-ahead program whose stream arrives in chunks (other
      * programs: the ordinary one) */
     const int slot = (chunked ? 2 : 0) + (mode == SRE_HIP_THOMPSON ? 0 : 1);
+    std::lock_guard<std::mutex> lock(g_mutex);
     if (!dp->compat_tried[slot]) {
         dp->compat_tried[slot] = 1;
         sre_hip_scanner_t *sc = chunked ? sre_hip_scanner_create_chunked(prog->pool, prog, mode)
@@ -328,12 +352,27 @@ compat_scanner(sre_program_t *prog, int mode, int chunked = 0)
     return dp->compat_scanner[slot];
 }
 
-static unsigned long long g_route_counts[3];
+static std::atomic<unsigned long long> g_route_counts[3];
 
 extern "C" SRE_API void
 sre_hip_compat_route_counts(unsigned long long out[3])
 {
-    for (int i = 0; i < 3; i++) out[i] = g_route_counts[i];
+    for (int i = 0; i < 3; i++) out[i] = g_route_counts[i].load();
+}
+
+/* free every parked device stream (HIP stream, context, staging buffers); returns how many */
+extern "C" SRE_API int
+sre_hip_compat_trim(void)
+{
+    DeviceStream *gone[SRE_STREAM_CACHE_MAX];
+    int           n = 0;
+    {
+        std::lock_guard<std::mutex> lock(g_mutex);
+        for (int i = 0; i < g_nparked; i++) gone[n++] = g_parked[i];
+        g_nparked = 0;
+    }
+    for (int i = 0; i < n; i++) device_stream_destroy(gone[i]);
+    return n;
 }
 
 static int
@@ -496,6 +535,12 @@ pike_stream_route(sre_vm_pike_ctx_t *ctx, sre_char *input, size_t len, unsigned 
     }
     const sre_stream_result_t *res = ds->h_sres;
     const sre_int_t            rc = (sre_int_t) res->rc;
+    if (rc == SRE_STREAM_PENDING || rc == SRE_STREAM_UNSETTLED) {
+        /* the tail kernel never published: a device fault.  The stream is not parked for re-use */
+        ds->failed = 1;
+        *prc = SRE_ERROR;
+        return 1;
+    }
     ctx->empty_capture = 0;
     ctx->at_boundary = 0;
     /* What EVERY call does on its way out (sre_vm_pike.c:586-601), SRE_AGAIN included: a MATCH
@@ -622,6 +667,24 @@ sre_vm_pike_exec(sre_vm_pike_ctx_t *ctx, sre_char *input, size_t len, unsigned e
         /* complete match: the whole caller ovector is defined (reference
          * sre_vm_pike.c:978-986) */
         for (size_t k = 0; k < ctx->ovec_slots; k++) ctx->ovector[k] = (sre_int_t) ds->h_blk->ov[k];
+        if (res->pad[0] & 16) {
+            /* The context is between two searches again (:624-628), and everything it holds there
+             * came back with the result: the host takes the state over and the next call is routed
+             * afresh — a stream whose first chunk was a short header line no longer keeps every
+             * later search on the exact VM (round-2 advisor finding).  The device context is
+             * zero-filled so that the VM kernel, if it is needed again, starts from the preset. */
+            ctx->processed_bytes = (sre_int_t) res->pad[1];
+            ctx->empty_capture = (res->pad[0] & SRE_PRESET_EMPTY_CAPTURE) != 0;
+            ctx->seen_newline = (res->pad[0] & SRE_PRESET_SEEN_NEWLINE) != 0;
+            ctx->seen_word = (res->pad[0] & SRE_PRESET_SEEN_WORD) != 0;
+            ctx->eof = (res->pad[0] & SRE_PRESET_EOF) != 0;
+            if (hipMemsetAsync(ds->d_ctx, 0, ds->ctx_bytes, ds->stream) == hipSuccess) {
+                ds->preset_valid = ds->preset_flags = 0;
+                ds->preset_processed = 0;
+                ctx->vm_touched = 0;
+                ctx->at_boundary = 1;
+            }
+        }
     } else if (rc == SRE_AGAIN) {
         /* temporary $& range only (reference sre_vm_pike.c:700-701) */
         for (size_t k = 0; k < ctx->ovec_slots && k < 2; k++) {
@@ -695,6 +758,11 @@ thompson_stream_route(sre_vm_thompson_ctx_t *ctx, sre_char *input, size_t len, u
         return 1;
     }
     const sre_int_t rc = (sre_int_t) ds->h_sres->rc;
+    if (rc == SRE_STREAM_PENDING || rc == SRE_STREAM_UNSETTLED) {
+        ds->failed = 1;                     /* the tail kernel never published: a device fault */
+        *prc = SRE_ERROR;
+        return 1;
+    }
     ctx->started = 1;
     if (rc == SRE_AGAIN) {
         ctx->stream_mode = 1;

@@ -444,6 +444,52 @@ def _feed(ctx, data, sizes, nov):
         return out
 
 
+def test_compat_api_search_after_a_vm_match_is_routed_afresh(gpu):
+    """A context whose FIRST call is short (a header line) runs that call on the exact VM kernel.  When
+    that search ends with a match the context is between two searches again (sre_vm_pike.c:624-628):
+    the host takes its state back and the next call — a megabyte — goes through a throughput scanner
+    instead of staying on the VM for the rest of the stream (round-2 advisor finding).  Results equal
+    the oracle's for the same call sequence; the route counters say where the calls ran."""
+    ora = harness.OracleEngine()
+    eng = harness.ProductEngine()
+    cases = [([rb"[a-z]+@[a-z]+\.[a-z]+"], b"hi a@b.c ", b" x@abc.cc "),
+             ([rb"(a+)$"], b"xaa\n", b" baaa"),                      # look-ahead: seen_newline / seen_word travel
+             ([rb"\bab\b"], b"ab ", b" ab"),
+             ([b"a", b"ab", b"c"], b"zzc", b"aaabbccb")]
+    for pats, head, tail in cases:
+        with S.Pool() as pool:
+            re = S.parse(pool, pats)
+            prog = S.compile(pool, re)
+            data = head + S.gen_data_host(1 << 20, tail)
+
+            def calls(ctx):
+                out = []
+                buf = ctypes.create_string_buffer(data, len(data))
+                rc = ctx.exec(None, False, base=buf, offset=0, length=len(head))       # the short first call
+                out.append((rc, list(ctx.ovector)[:2] if rc >= 0 else None))
+                off = ctx.ovector[1] if rc >= 0 else len(head)
+                for _ in range(3):                                                     # then whole remainders
+                    rc = ctx.exec(None, True, base=buf, offset=off, length=len(data) - off)
+                    out.append((rc, list(ctx.ovector) if rc >= 0 else None))
+                    if rc < 0:
+                        break
+                    off = ctx.ovector[1]
+                return out
+
+            want = calls(ora.pike(prog, re.ncaps))
+            before = S.compat_route_counts()
+            got = calls(eng.pike(prog, re.ncaps))
+            after = S.compat_route_counts()
+            assert got == want, (pats, got, want)
+            assert want[0][0] >= 0, (pats, want)            # the short call ends its search with a match
+            # the short call ran on the VM, and so does a last call on a remainder below the scanners'
+            # 16-byte floor; every other one — the megabyte first of all — on a throughput scanner
+            assert after[0] - before[0] >= 1, (pats, before, after)
+            assert after[2] - before[2] <= 2, (pats, before, after)
+            assert (after[0] - before[0]) + (after[2] - before[2]) == len(got), (pats, before, after, len(got))
+            eng.recycle()
+
+
 def test_compat_api_chunked_streams_take_the_scanner(gpu):
     """sre_vm_pike_exec fed in CHUNKS (eof = 0, then a last chunk with eof): the chunks run
     on the table-driven scanner, the thread list travelling from chunk to chunk as automaton

@@ -10,6 +10,7 @@
 
 static const char *builtin[] = {
     "(?:(?:(?:a{499}){499}){499}){35}", "(?:(?:a{499}){499}){100}", "(?:(?:a{499}){499}){60}",
+    "(?:(?:(?:(?:){499}){499}){499}){499}", "x(?:(?:(?:(?:(?:){499}){499}){499}){499}){499}y",
     "(a|b)*a(a|b){15}", "[a-z]+@[a-z]+\\.[a-z]+", "(x{3,}|[^y]{0,499}){2}", "\\bfoo$|^bar\\z", NULL
 };
 
