@@ -226,6 +226,15 @@ def workload_spec(name, S, nbytes, rank=0, world=1):
         elif name == "nfa37":
             pats, tail, engine, body = CFG3, NFA37_TAIL, S.ENGINE_NFA, NFA37_BODY
             text = "configs[2]'s 12 regexes (37 list-able threads) forced onto the NFA tier, Pike first-match, body 'BLegx'"
+        elif name == "count_nfa":
+            # find-all count of a program the step automaton declines: rounds of first-match searches on
+            # the NFA tier (one round trip per match), a match every 64 MiB
+            block = S.gen_data_length(64 << 20, 13)
+            nblk = max(1, nbytes // block)
+            return dict(name=name, pats=[NFA_PAT], mode=S.HIP_PIKE_COUNT, lens=[nblk * block], tails=[b" abaabaabab@ "],
+                        text="declined by the step automaton: /(?:a|b)*a(?:a|b){7}@/ find-all count on the NFA tier, "
+                             "a match every 64 MiB (%d x %d-byte gen-data blocks ending in ' abaabaabab@ ')" % (nblk, block),
+                        block=block, check=(lambda recs, n=nblk * block, k=nblk: _assert_eq(recs[0], [0, k, n - 12, n - 1])))
         elif name in ("dense", "densef", "densela"):
             # a match every MiB: the stream is one 1 MiB gen-data block with a matching tail, repeated
             block = S.gen_data_length(1 << 20, 10)
@@ -433,7 +442,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true",
                     help="N=1: do not measure the other configurations beside the headline (config.variants)")
-    ap.add_argument("--config", default="cfg2", choices=["cfg1", "cfg2", "cfg2m", "cfg3", "cfg4", "nfa", "nfa37", "nfa60", "nfa57w", "dense", "densef", "densela", "floor"],
+    ap.add_argument("--config", default="cfg2", choices=["cfg1", "cfg2", "cfg2m", "cfg3", "cfg4", "nfa", "nfa37", "nfa60", "nfa57w", "count_nfa", "dense", "densef", "densela", "floor"],
                     help="N=1 headline workload: cfg2 = BASELINE configs[1] (default); cfg2m = same with a "
                          "matching tail (captures span the whole stream); cfg3 = configs[2] multi-regex "
                          "find-all count; cfg4 = configs[3] URI, 4 groups; cfg1 = configs[0]'s pattern, "
@@ -546,7 +555,7 @@ def main():
             # dominant kernel alone beside it
             variants = {}
             sweep = {"size_1.0GiB": GIB, "size_2.5GiB": 5 * GIB // 2, "size_3.3GiB": 33 * GIB // 10, "size_6.0GiB": 6 * GIB}
-            for name in ("cfg2m", "cfg3", "cfg4", "nfa", "nfa37", "nfa60", "nfa57w", "dense", "densef", "densela", "floor",
+            for name in ("cfg2m", "cfg3", "cfg4", "nfa", "nfa37", "nfa60", "nfa57w", "count_nfa", "dense", "densef", "densela", "floor",
                          "many") + tuple(sweep):
                 try:
                     # size_*: the headline workload at other stream lengths (the segment geometry follows the total)

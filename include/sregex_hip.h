@@ -93,6 +93,10 @@ SRE_API void sre_hip_compat_route_counts(unsigned long long out[3]);
  * belongs to one thread at a time. */
 SRE_API int sre_hip_compat_trim(void);
 
+/* diagnostics: find-all counting on the NFA tier (a program the step automaton declines) is a loop of
+ * first-match searches, run in rounds over all streams of the call: how many rounds the last call took */
+SRE_API int sre_hip_scanner_last_count_rounds(sre_hip_scanner_t *sc);
+
 /* diagnostics: 1 when the last scan had to build per-segment ancestor maps to
  * reconstruct the captures of a match spanning many segments */
 SRE_API int sre_hip_scanner_last_lineage_passes(sre_hip_scanner_t *sc);

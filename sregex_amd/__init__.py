@@ -61,6 +61,7 @@ API = {
     "sre_hip_scanner_last_fixups": (ctypes.c_int, [_vp]),
     "sre_hip_scanner_last_lineage_passes": (ctypes.c_int, [_vp]),
     "sre_hip_scanner_last_exact_passes": (ctypes.c_int, [_vp]),
+    "sre_hip_scanner_last_count_rounds": (ctypes.c_int, [_vp]),
     "sre_hip_compat_route_counts": (None, [ctypes.POINTER(ctypes.c_ulonglong)]),
     "sre_hip_compat_trim": (ctypes.c_int, []),
     "sre_hip_scanner_set_tail_stream": (ctypes.c_int, [_vp, _vp]),
@@ -309,6 +310,10 @@ class Scanner:
     @property
     def last_exact_passes(self):
         return self.lib.sre_hip_scanner_last_exact_passes(self.h)
+
+    @property
+    def last_count_rounds(self):
+        return self.lib.sre_hip_scanner_last_count_rounds(self.h)
 
     @property
     def last_lineage_passes(self):

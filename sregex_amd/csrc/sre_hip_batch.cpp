@@ -86,6 +86,13 @@ struct sre_hip_scanner_s {
     sre_nfa_tables_t          ntab;             /* device pointers inside */
     sre_nfa_sa_tables_t       satab;            /* the shift-and form (sre_nfa.h), when the program has one */
     bool                      use_sa;
+    /* find-all counting on the NFA tier (nfa_count_rounds) */
+    struct NfaCount          *cnt;
+    uint8_t                  *d_sflags, *h_sflags;      /* per stream of a round: SRE_SFLAG_* */
+    sre_nfa_count_req_t      *d_creq, *h_creq;
+    size_t                    cnt_cap;
+    int                       count_rounds;             /* of the last call (diagnostics) */
+    size_t                    layout_n;                 /* streams the staging blocks are laid out for */
     sre_nfa_summary_t        *d_nsum;
     size_t                    nsum_cap;
     uint64_t                 *d_belief;
@@ -94,10 +101,32 @@ struct sre_hip_scanner_s {
     sre_nfa_status_t         *d_nstatus, *h_nstatus;
 };
 
+/* one stream of a find-all count on the NFA tier */
+struct NfaCountStream {
+    const uint8_t *base;
+    uint64_t       n;
+    uint64_t       cur;         /* where the current search began (the previous match's end) */
+    uint64_t       q;           /* a clean position of that search: where the next scanned buffer starts */
+    uint64_t       horizon;     /* bytes scanned per round */
+    uint32_t       var_cur, var_q, mode_q;
+    int64_t        count;
+    bool           done, error;
+    std::vector<sre_int_t> last;    /* record of the last match */
+};
+struct NfaCount {
+    std::vector<NfaCountStream> st;
+    std::vector<size_t>         active;
+};
+
 static void
 scanner_release(void *data)
 {
     sre_hip_scanner_t *sc = static_cast<sre_hip_scanner_t *>(data);
+    delete sc->cnt;
+    if (sc->d_sflags) (void) hipFree(sc->d_sflags);
+    if (sc->h_sflags) (void) hipHostFree(sc->h_sflags);
+    if (sc->d_creq) (void) hipFree(sc->d_creq);
+    if (sc->h_creq) (void) hipHostFree(sc->h_creq);
     if (sc->d_in) (void) hipFree(sc->d_in);
     if (sc->h_in) (void) hipHostFree(sc->h_in);
     if (sc->d_out) (void) hipFree(sc->d_out);
@@ -203,7 +232,8 @@ nfa_launch_scan(sre_hip_scanner_t *sc, const int64_t *d_lo, const uint64_t *d_be
                 hipStream_t stream)
 {
     if (sc->use_sa) return sre_launch_nfa_sa_scan(sc->satab, sc->geom, sc->d_nsum, d_lo, d_belief, d_bvalid, stream);
-    return sre_launch_nfa_scan(sc->mode, sc->ntab, sc->geom, sc->d_nsum, d_lo, d_belief, d_bvalid, stream);
+    return sre_launch_nfa_scan(sc->mode == SRE_HIP_THOMPSON ? SRE_HIP_THOMPSON : SRE_HIP_PIKE_FIRST, sc->ntab, sc->geom,
+                               sc->d_nsum, d_lo, d_belief, d_bvalid, stream);
 }
 
 extern "C" SRE_API int
@@ -289,10 +319,24 @@ scanner_create(sre_pool_t *pool, sre_program_t *prog, int mode, int engine, int 
         /* the ordered-list automaton is too large (or was not asked for): the
          * bit-parallel form, if the program has one */
         const char *why = NULL;
-        if (mode == SRE_HIP_PIKE_COUNT) why = "COUNT mode needs the ordered list at every match";
-        else sc->nfa = sre_nfa_build(prog, &why);
+        sc->nfa = sre_nfa_build(prog, &why);
+        if (sc->nfa && mode == SRE_HIP_PIKE_COUNT && (sc->nfa->nassert || sc->nfa->init[1] != sc->nfa->init[2])) {
+            /* Find-all on this tier restarts searches in the middle of the stream.  A re-armed search
+             * that does not start behind a newline holds the bare ".*?" list as its initial-state
+             * snapshot, so the reference's leading-byte skip (sre_vm_pike.c:256-309) fires at every
+             * idle position and jumps over newlines whose consumption would have listed the threads
+             * behind ^: `^b+` over "b x\n\nb" finds one match, not two.  Thread SETS step every byte and
+             * cannot know which positions the reference never visits, so programs whose seeded closure
+             * depends on ^ keep the exact VM for find-all (found by the tier's own differential test);
+             * so do look-ahead programs, whose re-armed context carries seen_word (:472-473). */
+            why = sc->nfa->nassert ? "find-all counting of a look-ahead program the step automaton declines"
+                                   : "find-all counting of a program whose initial closure depends on ^ (re-armed searches skip newlines)";
+            sre_nfa_free(sc->nfa);
+            sc->nfa = NULL;
+        }
         if (sc->nfa && nfa_upload(sc) == 0) {
             sc->engine = SRE_HIP_ENGINE_NFA;
+            if (mode == SRE_HIP_PIKE_COUNT) sc->cnt = new NfaCount();
         } else if (engine == SRE_HIP_ENGINE_NFA) {
             fprintf(stderr, "[sregex-hip] bit-parallel NFA scanner not available: %s\n",
                     why ? why : "device allocation failed");
@@ -357,8 +401,8 @@ sre_hip_scanner_kernel_name(sre_hip_scanner_t *sc)
                      sc->tab->h.wide ? "true" : "false");
         } else if (sc->engine == SRE_HIP_ENGINE_NFA) {
             if (sc->use_sa) sre_nfa_sa_kernel_name(&sc->satab, sc->kernel_name, sizeof(sc->kernel_name));
-            else sre_nfa_kernel_name(sc->mode, sc->ntab.nslices, sc->ntab.nassert != 0, sc->kernel_name,
-                                     sizeof(sc->kernel_name));
+            else sre_nfa_kernel_name(sc->mode == SRE_HIP_THOMPSON ? 0 : 1, sc->ntab.nslices, sc->ntab.nassert != 0,
+                                     sc->kernel_name, sizeof(sc->kernel_name));
         } else {
             snprintf(sc->kernel_name, sizeof(sc->kernel_name), "%s",
                      sc->mode == SRE_HIP_THOMPSON ? "sre_k_thompson_scan" : "sre_k_pike_scan");
@@ -449,6 +493,7 @@ scanner_reserve(sre_hip_scanner_t *sc, size_t n)
         sc->cap_streams = n;
     }
     /* this call's layout: [ptrs n][lens n][seg_first n + 1] and [records n][status n] */
+    sc->layout_n = n;
     sc->h_ptrs = reinterpret_cast<const void **>(sc->h_in);
     sc->h_lens = sc->h_in + n;
     sc->h_seg_first = sc->h_in + 2 * n;
@@ -499,7 +544,8 @@ scan_geometry(sre_hip_scanner_t *sc, size_t nstreams)
         if (sc->blocks_per_cu == 0) {
             sc->blocks_per_cu = sc->engine == SRE_HIP_ENGINE_NFA
                                     ? (sc->use_sa ? sre_nfa_sa_blocks_per_cu(&sc->satab)
-                                                  : sre_nfa_blocks_per_cu(sc->mode, sc->ntab.nslices, sc->ntab.nassert != 0))
+                                                  : sre_nfa_blocks_per_cu(sc->mode == SRE_HIP_THOMPSON ? 0 : 1, sc->ntab.nslices,
+                                                                          sc->ntab.nassert != 0))
                                                                  : sre_scan_blocks_per_cu(&sc->tab->h);
         }
         const uint64_t resident = (uint64_t) sre_hip_cu_count() * (uint64_t) sc->blocks_per_cu * SRE_SCAN_BLOCK;
@@ -587,17 +633,244 @@ static int
 nfa_finish(sre_hip_scanner_t *sc, const int64_t *d_lo, hipStream_t stream)
 {
     const uint32_t n = sc->geom.nstreams;
-    SRE_HIP_TRY(sre_launch_nfa_verify(sc->mode, sc->geom, sc->d_nsum, sc->d_nacc, sc->d_nstatus,
+    /* (the kernels know two modes: find-all counting is a loop of first-match searches) */
+    const int kmode = sc->mode == SRE_HIP_THOMPSON ? SRE_HIP_THOMPSON : SRE_HIP_PIKE_FIRST;
+    SRE_HIP_TRY(sre_launch_nfa_verify(kmode, sc->geom, sc->d_nsum, sc->d_nacc, sc->d_nstatus,
                                       sc->d_belief, sc->d_bvalid, sc->d_records, sc->ovec_slots, d_lo, stream));
     if (sc->mode != SRE_HIP_THOMPSON) {
         /* (the window kernel zero-fills the context it uses) */
         SRE_HIP_TRY(sre_launch_pike_window(sc->dp->d_blob, sc->dp->blob_bytes, sc->d_ptrs, sc->d_lens, n, sc->d_ctx, sc->ctx_stride,
                                            sc->d_records, sc->ovec_slots,
-                                           reinterpret_cast<sre_nfa_window_t *>(sc->d_nstatus), d_lo, stream));
+                                           reinterpret_cast<sre_nfa_window_t *>(sc->d_nstatus), d_lo,
+                                           sc->geom.sflags ? sc->d_creq : NULL, stream));
     }
     return 0;
 hip_failed:
     return -1;
+}
+
+/* find-all rounds: the first horizon and the smallest one (SRE_HIP_COUNT_HORIZON: tests force tiny ones) */
+static uint64_t
+count_horizon(uint64_t dflt)
+{
+    const char *e = getenv("SRE_HIP_COUNT_HORIZON");
+    return e && atoll(e) > 0 ? (uint64_t) atoll(e) : dflt;
+}
+
+/* NFA tier: one pass over the batch in h_ptrs / h_lens (geometry, set kernel, chain check, exact
+ * windows), queued; with_copy: the records and status words travel to the host behind it */
+static int
+nfa_enqueue_pass(sre_hip_scanner_t *sc, size_t nstreams, hipStream_t stream, bool with_copy)
+{
+    if (scan_geometry(sc, nstreams) != 0) return -1;
+    /* (a round of a find-all count is a sub-batch: the blocks keep the call's layout) */
+    SRE_HIP_TRY(hipMemcpyAsync(sc->d_in, sc->h_in, (3 * sc->layout_n + 1) * sizeof(uint64_t),
+                               hipMemcpyHostToDevice, stream));
+    if (sc->ev0 == NULL) {
+        SRE_HIP_TRY(hipEventCreate(&sc->ev0));
+        SRE_HIP_TRY(hipEventCreate(&sc->ev1));
+    }
+    {
+        /* set pass, chain check, and (Pike) the exact VM over each stream's window */
+        const bool timed = !sc->ev_valid;       /* find-all: the first round's scan is the one reported */
+        if (timed) SRE_HIP_TRY(hipEventRecord(sc->ev0, stream));
+        SRE_HIP_TRY(nfa_launch_scan(sc, NULL, NULL, NULL, stream));
+        if (timed) SRE_HIP_TRY(hipEventRecord(sc->ev1, stream));
+        sc->ev_valid = 1;
+    }
+    if (sc->tail_stream_set && sc->tail_stream != stream) {
+        SRE_HIP_TRY(hipStreamWaitEvent(sc->tail_stream, sc->ev1, 0));
+        stream = sc->tail_stream;
+    }
+    if (nfa_finish(sc, NULL, stream) != 0) return -1;
+    if (with_copy) return 0;        /* the caller queues the copy */
+    return 0;
+hip_failed:
+    return -1;
+}
+
+/* NFA tier: segments behind a wrong entry set are re-run — the first one from the exact carried
+ * set, the ones behind it from what their predecessor's lane ended in last round (sets only grow
+ * towards the truth, so corrections travel many segments per round) — until every stream's
+ * verified prefix reaches its event or its end.  h_nstatus holds the status of the pass before. */
+static int
+nfa_settle(sre_hip_scanner_t *sc, size_t n, hipStream_t stream, bool *psettled)
+{
+    for (bool first = true;; first = false) {
+        if (!first) {
+            SRE_HIP_TRY(hipMemcpyAsync(sc->h_nstatus, sc->d_nstatus, n * sizeof(sre_nfa_status_t),
+                                       hipMemcpyDeviceToHost, stream));
+            SRE_HIP_TRY(hipStreamSynchronize(stream));
+        }
+        size_t pending = 0;
+        for (size_t i = 0; i < n; i++) {
+            if (sc->h_nstatus[i].done) {
+                sc->h_lo[i] = -1;
+            } else {
+                sc->h_lo[i] = sc->h_nstatus[i].first_bad;
+                pending++;
+            }
+        }
+        if (pending == 0) break;
+        *psettled = false;
+        if (++sc->fixup_rounds > 1000000) {
+            fprintf(stderr, "[sregex-hip] NFA scanner fix-up did not converge\n");
+            return -1;
+        }
+        SRE_HIP_TRY(hipMemcpyAsync(sc->d_lo, sc->h_lo, n * sizeof(int64_t), hipMemcpyHostToDevice, stream));
+        SRE_HIP_TRY(nfa_launch_scan(sc, sc->d_lo, sc->d_belief, sc->d_bvalid, stream));
+        if (nfa_finish(sc, sc->d_lo, stream) != 0) return -1;
+    }
+    return 0;
+hip_failed:
+    return -1;
+}
+
+/*
+ * Find-all counting on the NFA tier: the reference's caller iterates
+ * exec(input + ovector[1], ...) on one re-armed context (sre_vm_pike.c:179-196, :586-636), every
+ * search a first-match search that starts at the previous match's end.  Each ROUND here runs the
+ * next piece of every unfinished stream's current search as one batch: the set kernel scans a
+ * buffer that starts at a CLEAN position of the search (its start, or the last clean position the
+ * previous round found: the list there is the fresh initial closure, so nothing of the stream in
+ * front of it matters) and is at most `horizon` bytes long; a MATCH event in it sends the exact VM
+ * over the stream from the search's start (it picks the search up at the clean position in front of
+ * the event, as for a first match) and the next search starts at the match's end; no event moves
+ * the buffer to its last clean position, or lets the horizon grow when it has none.  The horizon
+ * follows the distance between matches, so sparse matches cost about one pass over the stream and
+ * a round trip per match; dense matches run at the round-trip rate.
+ */
+static int
+nfa_count_rounds(sre_hip_scanner_t *sc, sre_int_t *results)
+{
+    NfaCount    &c = *sc->cnt;
+    const size_t n = c.st.size(), slots = 2 + (size_t) sc->ovec_slots;
+    hipStream_t  stream = sc->last_stream;
+    const bool   tail_set = sc->tail_stream_set;
+    if (n > sc->cnt_cap) {
+        if (sc->d_sflags) (void) hipFree(sc->d_sflags);
+        if (sc->h_sflags) (void) hipHostFree(sc->h_sflags);
+        if (sc->d_creq) (void) hipFree(sc->d_creq);
+        if (sc->h_creq) (void) hipHostFree(sc->h_creq);
+        sc->d_sflags = sc->h_sflags = NULL;
+        sc->d_creq = sc->h_creq = NULL;
+        sc->cnt_cap = 0;
+        SRE_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&sc->d_sflags), n));
+        SRE_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&sc->h_sflags), n, 0));
+        SRE_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&sc->d_creq), n * sizeof(sre_nfa_count_req_t)));
+        SRE_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&sc->h_creq), n * sizeof(sre_nfa_count_req_t), 0));
+        sc->cnt_cap = n;
+    }
+    sc->tail_stream_set = false;            /* every round is read back: one stream */
+    for (;;) {
+        c.active.clear();
+        for (size_t i = 0; i < n; i++) {
+            NfaCountStream &t = c.st[i];
+            /* a search on an empty remainder: size 0 with eof answers SRE_DECLINED (:179-196) */
+            if (!t.done && t.cur >= t.n && t.count > 0) t.done = true;
+            if (!t.done) c.active.push_back(i);
+        }
+        if (c.active.empty()) break;
+        const size_t na = c.active.size();
+        if (++sc->count_rounds > 100000000) return -1;
+        for (size_t j = 0; j < na; j++) {
+            NfaCountStream &t = c.st[c.active[j]];
+            const uint64_t  left = t.n - t.q, len = left < t.horizon ? left : t.horizon;
+            sc->h_ptrs[j] = t.base + t.q;
+            sc->h_lens[j] = len;
+            sc->h_sflags[j] = (uint8_t) (t.var_q | (t.var_cur << 2) | (t.mode_q << 4) | (len < left ? SRE_SFLAG_NO_EOF : 0u));
+            sre_nfa_count_req_t &r = sc->h_creq[j];
+            r.vptr = t.base + t.cur;
+            r.vlen = t.n - t.cur;
+            r.processed = (int64_t) t.cur;
+            r.start_add = (int64_t) (t.q - t.cur);
+            r.preset_flags = t.var_cur == 1 ? SRE_PRESET_SEEN_NEWLINE : 0u;
+            r.pad = 0;
+        }
+        SRE_HIP_TRY(hipMemcpyAsync(sc->d_sflags, sc->h_sflags, na, hipMemcpyHostToDevice, stream));
+        SRE_HIP_TRY(hipMemcpyAsync(sc->d_creq, sc->h_creq, na * sizeof(sre_nfa_count_req_t), hipMemcpyHostToDevice, stream));
+        sc->geom.sflags = sc->d_sflags;
+        sc->geom.flags = 0;
+        if (nfa_enqueue_pass(sc, na, stream, false) != 0) goto hip_failed;
+        SRE_HIP_TRY(hipMemcpyAsync(sc->h_out, sc->d_out, record_bytes(sc, sc->layout_n) + sc->layout_n * sizeof(sre_stream_status_t),
+                                   hipMemcpyDeviceToHost, stream));
+        SRE_HIP_TRY(hipStreamSynchronize(stream));
+        {
+            bool settled = true;
+            if (nfa_settle(sc, na, stream, &settled) != 0) goto hip_failed;
+            if (!settled) {
+                SRE_HIP_TRY(hipMemcpyAsync(sc->h_out, sc->d_out, record_bytes(sc, sc->layout_n) + sc->layout_n * sizeof(sre_stream_status_t),
+                                           hipMemcpyDeviceToHost, stream));
+                SRE_HIP_TRY(hipStreamSynchronize(stream));
+            }
+        }
+        for (size_t j = 0; j < na; j++) {
+            NfaCountStream         &t = c.st[c.active[j]];
+            const sre_nfa_status_t &w = sc->h_nstatus[j];
+            const sre_int_t        *rec = sc->h_records + j * slots;
+            const bool              truncated = (sc->h_sflags[j] & SRE_SFLAG_NO_EOF) != 0;
+            if (getenv("SRE_HIP_DEBUG_COUNT")) {
+                fprintf(stderr, "[sregex-hip] count round %d stream %zu: cur %llu q %llu var %u/%u mode %u len %llu%s -> ev %lld clean %lld "
+                                "cmode %x rec %lld (%lld, %lld)\n", sc->count_rounds, c.active[j], (unsigned long long) t.cur,
+                        (unsigned long long) t.q, t.var_cur, t.var_q, t.mode_q, (unsigned long long) sc->h_lens[j],
+                        truncated ? " (truncated)" : "", (long long) w.ev_pos, (long long) w.clean_pos, w.clean_mode,
+                        (long long) rec[0], (long long) rec[2], (long long) rec[3]);
+            }
+            if (w.ev_pos >= 0) {
+                if (rec[0] < 0) {
+                    /* (an event is a thread reaching MATCH: the exact VM finds that match or an earlier one) */
+                    fprintf(stderr, "[sregex-hip] find-all on the NFA tier: the exact window found no match behind an event\n");
+                    t.error = t.done = true;
+                    continue;
+                }
+                t.count++;
+                t.last.assign(rec, rec + slots);
+                const uint64_t end = (uint64_t) rec[3];
+                /* the next horizon: a few times the distance this match took */
+                const uint64_t gap = end > t.q ? end - t.q : 1;
+                t.horizon = gap * 4 < count_horizon(1u << 20) ? count_horizon(1u << 20) : gap * 4;
+                t.cur = t.q = end;
+                t.var_cur = t.var_q = (w.clean_mode & SRE_NFA_MATCH_AFTER_NL) ? 1u : 2u;
+                t.mode_q = 0;
+                if (w.clean_mode & SRE_NFA_WINDOW_POISONED) t.error = t.done = true;     /* :616-622: the next exec fails */
+            } else if (!truncated) {
+                t.done = true;                  /* SRE_DECLINED ends the iteration */
+            } else if (w.clean_pos > 0) {
+                t.q += (uint64_t) w.clean_pos;
+                t.var_q = (w.clean_mode & SRE_NFA_CLEAN_AFTER_NL) ? 1u : 2u;
+                t.mode_q = (uint32_t) (w.clean_mode & 1);
+                t.horizon *= 2;
+            } else {
+                t.horizon *= 4;                 /* threads alive all along: the same buffer, longer */
+            }
+        }
+    }
+    sc->geom.sflags = NULL;
+    sc->tail_stream_set = tail_set;
+    for (size_t i = 0; i < n; i++) {
+        const NfaCountStream &t = c.st[i];
+        sre_int_t            *out = results + i * slots;
+        if (t.count == 0) {
+            out[0] = t.error ? SRE_ERROR : SRE_DECLINED;
+            out[1] = 0;
+            for (size_t k = 2; k < slots; k++) out[k] = -1;
+        } else {
+            for (size_t k = 0; k < slots; k++) out[k] = t.last[k];
+            if (t.error) out[0] = SRE_ERROR;
+            out[1] = (sre_int_t) t.count;
+        }
+    }
+    return 0;
+hip_failed:
+    sc->geom.sflags = NULL;
+    sc->tail_stream_set = tail_set;
+    return -1;
+}
+
+extern "C" SRE_API int
+sre_hip_scanner_last_count_rounds(sre_hip_scanner_t *sc)
+{
+    return sc->count_rounds;
 }
 
 extern "C" SRE_API int
@@ -630,24 +903,28 @@ sre_hip_scan_enqueue(sre_hip_scanner_t *sc, const void *const *d_streams, const 
         SRE_HIP_TRY(sre_launch_vm_scan(sc->dp->d_blob, sc->mode, sc->d_ptrs, sc->d_lens,
                                        (uint32_t) nstreams, sc->d_ctx, sc->ctx_stride,
                                        sc->d_records, sc->ovec_slots, stream));
+    } else if (sc->engine == SRE_HIP_ENGINE_NFA && sc->cnt != NULL) {
+        /* find-all counting: a loop of first-match searches, run by results() (nfa_count_rounds) */
+        NfaCount &c = *sc->cnt;
+        c.st.assign(nstreams, NfaCountStream());
+        for (size_t i = 0; i < nstreams; i++) {
+            NfaCountStream &t = c.st[i];
+            t.base = static_cast<const uint8_t *>(d_streams[i]);
+            t.n = lens[i];
+            t.cur = t.q = 0;
+            t.horizon = count_horizon(8u << 20);
+            t.var_cur = t.var_q = sc->geom.init_variant;
+            t.mode_q = 0;
+            t.count = 0;
+            t.done = t.error = false;
+        }
+        sc->count_rounds = 0;
+        sc->last_n = nstreams;
+        sc->last_stream = stream;
+        return 0;
     } else if (sc->engine == SRE_HIP_ENGINE_NFA) {
-        if (scan_geometry(sc, nstreams) != 0) return -1;
-        SRE_HIP_TRY(hipMemcpyAsync(sc->d_in, sc->h_in, (3 * nstreams + 1) * sizeof(uint64_t),
-                                   hipMemcpyHostToDevice, stream));
-        if (sc->ev0 == NULL) {
-            SRE_HIP_TRY(hipEventCreate(&sc->ev0));
-            SRE_HIP_TRY(hipEventCreate(&sc->ev1));
-        }
-        /* set pass, chain check, and (Pike) the exact VM over each stream's window */
-        SRE_HIP_TRY(hipEventRecord(sc->ev0, stream));
-        SRE_HIP_TRY(nfa_launch_scan(sc, NULL, NULL, NULL, stream));
-        SRE_HIP_TRY(hipEventRecord(sc->ev1, stream));
-        sc->ev_valid = 1;
-        if (sc->tail_stream_set && sc->tail_stream != stream) {
-            SRE_HIP_TRY(hipStreamWaitEvent(sc->tail_stream, sc->ev1, 0));
-            stream = sc->tail_stream;
-        }
-        if (nfa_finish(sc, NULL, stream) != 0) return -1;
+        if (nfa_enqueue_pass(sc, nstreams, stream, true) != 0) return -1;
+        if (sc->tail_stream_set && sc->tail_stream != stream) stream = sc->tail_stream;
     } else {
         if (scan_geometry(sc, nstreams) != 0) return -1;
         if (!sc->geom_one) {
@@ -772,39 +1049,10 @@ sre_hip_scan_results(sre_hip_scanner_t *sc, sre_int_t *results)
     const size_t bytes = n * (2 + (size_t) sc->ovec_slots) * sizeof(int64_t);
     bool         settled = true;        /* the copies queued by enqueue() are the answer */
 
+    if (sc->engine == SRE_HIP_ENGINE_NFA && sc->cnt != NULL) return nfa_count_rounds(sc, results);
     /* everything enqueue() queued for this call, result copies included */
     SRE_HIP_TRY(hipEventSynchronize(sc->ev_done));
-    if (sc->engine == SRE_HIP_ENGINE_NFA) {
-        /* segments behind a wrong entry set are re-run: the first one from the
-         * exact carried set, the ones behind it from what their predecessor's lane
-         * ended in last round (sets only grow towards the truth, so corrections
-         * travel many segments per round) */
-        for (bool first = true;; first = false) {
-            if (!first) {
-                SRE_HIP_TRY(hipMemcpyAsync(sc->h_nstatus, sc->d_nstatus, n * sizeof(sre_nfa_status_t),
-                                           hipMemcpyDeviceToHost, stream));
-                SRE_HIP_TRY(hipStreamSynchronize(stream));
-            }
-            size_t pending = 0;
-            for (size_t i = 0; i < n; i++) {
-                if (sc->h_nstatus[i].done) {
-                    sc->h_lo[i] = -1;
-                } else {
-                    sc->h_lo[i] = sc->h_nstatus[i].first_bad;
-                    pending++;
-                }
-            }
-            if (pending == 0) break;
-            settled = false;
-            if (++sc->fixup_rounds > 1000000) {
-                fprintf(stderr, "[sregex-hip] NFA scanner fix-up did not converge\n");
-                return -1;
-            }
-            SRE_HIP_TRY(hipMemcpyAsync(sc->d_lo, sc->h_lo, n * sizeof(int64_t), hipMemcpyHostToDevice, stream));
-            SRE_HIP_TRY(nfa_launch_scan(sc, sc->d_lo, sc->d_belief, sc->d_bvalid, stream));
-            if (nfa_finish(sc, sc->d_lo, stream) != 0) return -1;
-        }
-    }
+    if (sc->engine == SRE_HIP_ENGINE_NFA && nfa_settle(sc, n, stream, &settled) != 0) return -1;
     if (sc->engine == SRE_HIP_ENGINE_SCAN) {
         if (scan_settle(sc, n, stream, true, &settled) != 0) return -1;
         /* a match whose lineage outran the plain backward walk: build the

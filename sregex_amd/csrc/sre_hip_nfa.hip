@@ -164,6 +164,11 @@ sre_k_nfa(sre_nfa_tables_t T, sre_scan_geom_t G, sre_nfa_summary_t *__restrict__
     mine.addr = 0;
     mine.lo = 0;
     mine.hi16 = -1;
+    /* per-stream start conditions (find-all rounds), else the batch's */
+    const uint32_t sfl = (active && G.sflags != nullptr) ? G.sflags[sidx] : 0u;
+    const uint32_t v_init = G.sflags != nullptr ? SRE_SFLAG_INIT(sfl) : G.init_variant;
+    const uint32_t v_snap = G.sflags != nullptr ? SRE_SFLAG_SNAP(sfl) : G.init_variant;
+    const bool     no_eof = G.sflags != nullptr ? (sfl & SRE_SFLAG_NO_EOF) != 0 : (G.flags & SRE_GEOM_NO_EOF) != 0;
     if (active) {
         data = geom_ptr(G, sidx);
         n = (int64_t) geom_len(G, sidx);
@@ -172,8 +177,9 @@ sre_k_nfa(sre_nfa_tables_t T, sre_scan_geom_t G, sre_nfa_summary_t *__restrict__
         last_seg = (k + 1 == geom_first(G, sidx + 1) - geom_first(G, sidx));
         if (seg_b > n) seg_b = n;
         if (k == 0) {
-            S = (M) T.init[G.init_variant];
+            S = (M) T.init[v_init];
             last_clean = 0;                     /* the search starts here */
+            clean_mode = (int32_t) SRE_SFLAG_MODE(sfl);
         } else if (lo != nullptr && ((int64_t) k == lo[sidx] || bvalid[g])) {
             /* exact carry of the verified prefix, or (later segments of a fix-up
              * round) what the previous round's lane in front of this one ended in */
@@ -181,7 +187,7 @@ sre_k_nfa(sre_nfa_tables_t T, sre_scan_geom_t G, sre_nfa_summary_t *__restrict__
         } else {
             warm = true;
             /* a search that is (re)started in the middle of a stream: ^ false */
-            S = (M) T.init[seg_a <= WARM ? G.init_variant : 2];
+            S = (M) T.init[seg_a <= WARM ? v_init : 2];
         }
         s_in = S;
         mine.addr = (uint64_t) reinterpret_cast<uintptr_t>(data) + (uint64_t) (seg_a - WARM);
@@ -211,7 +217,7 @@ sre_k_nfa(sre_nfa_tables_t T, sre_scan_geom_t G, sre_nfa_summary_t *__restrict__
      *   it is equal and q - 1 is clean too (same list, fresh)   -> a skip target   (1)
      *   equal as a set but not known to be the same list        -> unusable        (-1)
      */
-    const M snap = (M) T.init[G.init_variant];
+    const M snap = (M) T.init[v_snap];
     auto clean_kind = [&](M s_before, bool prev_clean, bool leading) -> int {
         if (leading || s_before != snap) return 0;
         return prev_clean ? 1 : -1;
@@ -351,7 +357,7 @@ sre_k_nfa(sre_nfa_tables_t T, sre_scan_geom_t G, sre_nfa_summary_t *__restrict__
     }
 
     if (!active) return;
-    if (LA && last_seg && !finished && !(G.flags & SRE_GEOM_NO_EOF)) {
+    if (LA && last_seg && !finished && !no_eof) {
         /* the extra iteration at end of input (sre_vm_pike.c:235): assertions that hold
          * in front of the end list their continuations; a MATCH among them is an event */
         if (expand(S, 3u * XCOL) & match) first_ev = n;
@@ -437,6 +443,10 @@ sre_k_nfa_sa(sre_nfa_sa_tables_t T, sre_scan_geom_t G, sre_nfa_summary_t *__rest
     mine.addr = 0;
     mine.lo = 0;
     mine.hi16 = -1;
+    /* per-stream start conditions (find-all rounds), else the batch's */
+    const uint32_t sfl = (active && G.sflags != nullptr) ? G.sflags[sidx] : 0u;
+    const uint32_t v_init = G.sflags != nullptr ? SRE_SFLAG_INIT(sfl) : G.init_variant;
+    const uint32_t v_snap = G.sflags != nullptr ? SRE_SFLAG_SNAP(sfl) : G.init_variant;
     if (active) {
         data = geom_ptr(G, sidx);
         n = (int64_t) geom_len(G, sidx);
@@ -445,13 +455,14 @@ sre_k_nfa_sa(sre_nfa_sa_tables_t T, sre_scan_geom_t G, sre_nfa_summary_t *__rest
         if (seg_b > n) seg_b = n;
         uint64_t S;
         if (k == 0) {
-            S = T.init[G.init_variant];
+            S = T.init[v_init];
             last_clean = 0;                     /* the search starts here */
+            clean_mode = (int32_t) SRE_SFLAG_MODE(sfl);
         } else if (lo != nullptr && ((int64_t) k == lo[sidx] || bvalid[g])) {
             S = belief[g];
         } else {
             warm = true;
-            S = T.init[seg_a <= WARM ? G.init_variant : 2];
+            S = T.init[seg_a <= WARM ? v_init : 2];
         }
         s_in = S;
         s_lo = lo32(S);
@@ -462,7 +473,7 @@ sre_k_nfa_sa(sre_nfa_sa_tables_t T, sre_scan_geom_t G, sre_nfa_summary_t *__rest
     }
     rows[tid] = mine;
 
-    const uint64_t snap = T.init[G.init_variant];
+    const uint64_t snap = T.init[v_snap];
     const uint32_t snap_lo = lo32(snap), snap_hi = hi32(snap);
     /* how the reference arrives at a clean position: see sre_k_nfa (no look-ahead assertions here, so
      * the byte in front of a clean position never is a leading byte) */
@@ -747,6 +758,8 @@ sre_k_nfa_verify_c(int mode, sre_scan_geom_t G, const sre_nfa_summary_t *__restr
     st.ev_pos = (st.done && end < nseg) ? sum[first + end].first_ev : -1;
     st.clean_pos = acc.clean ? (int64_t) ((acc.clean - 1) >> 1) : 0;
     st.clean_mode = acc.clean ? (int32_t) ((acc.clean - 1) & 1) : 0;
+    /* ^ in the closure seeded at clean_pos goes by the byte in front of it (find-all rounds restart there) */
+    if (st.clean_pos > 0 && st.clean_pos <= (int64_t) geom_len(G, s) && geom_ptr(G, s)[st.clean_pos - 1] == '\n') st.clean_mode |= 2;
     status[s] = st;
 
     int64_t *rec = records + (size_t) s * (2 + ovec_slots);

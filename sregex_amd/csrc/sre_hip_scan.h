@@ -238,7 +238,17 @@ typedef struct {
      * are not read: a call on one buffer uploads nothing) */
     const uint8_t *one_ptr;
     uint64_t one_len;
+    /* NFA tier, find-all rounds (sre_hip_batch.cpp nfa_count_rounds): per stream, instead of
+     * init_variant / flags — SRE_SFLAG_*: which initial list the stream's offset 0 starts with, which
+     * one the search it belongs to began with (the reference's snapshot, sre_vm_pike.c:218-229), how
+     * the reference arrives at offset 0 (bit 0 of sre_nfa_summary_t.last_clean's mode), whether
+     * the buffer ends before the stream does.  NULL: init_variant / flags hold for every stream. */
+    const uint8_t *sflags;
 } sre_scan_geom_t;
+#define SRE_SFLAG_INIT(f)    ((f) & 3u)
+#define SRE_SFLAG_SNAP(f)    (((f) >> 2) & 3u)
+#define SRE_SFLAG_MODE(f)    (((f) >> 4) & 1u)
+#define SRE_SFLAG_NO_EOF     32u
 
 #define SRE_GEOM_CONTINUES 1u       /* the buffers are chunks of streams whose search began earlier */
 #define SRE_GEOM_NO_EOF    2u       /* more chunks follow: no EOF step at the end of the buffer */

@@ -39,6 +39,20 @@ typedef struct {
                                SRE_NFA_WINDOW_POISONED: set by the window kernel (see there) */
 } sre_nfa_window_t;
 #define SRE_NFA_WINDOW_POISONED 0x100
+#define SRE_NFA_CLEAN_AFTER_NL  0x2     /* set by the chain check: the byte in front of clean_pos is a newline */
+#define SRE_NFA_MATCH_AFTER_NL  0x200   /* set by the window kernel: the byte in front of the match's end is one */
+
+/* find-all rounds on the NFA tier (sre_hip_batch.cpp): the scanned buffer of a stream starts at a
+ * clean position of the current SEARCH; the exact VM runs on the stream from where that search
+ * began, as the reference's re-armed context does (sre_vm_pike.c:179-196, 624-628) */
+typedef struct {
+    const uint8_t *vptr;        /* the stream from the start of the current search */
+    uint64_t       vlen;        /* ... to its end */
+    int64_t        processed;   /* absolute offset of vptr: the re-armed context's processed_bytes */
+    int64_t        start_add;   /* offset of the scanned buffer inside vptr */
+    uint32_t       preset_flags;/* SRE_PRESET_SEEN_NEWLINE */
+    uint32_t       pad;
+} sre_nfa_count_req_t;
 
 #ifdef __cplusplus
 extern "C" {
@@ -46,7 +60,7 @@ extern "C" {
 hipError_t sre_launch_pike_window(const void *blob, size_t blob_bytes, const void *const *d_streams,
     const uint64_t *d_lens, uint32_t nstreams, void *d_ctx, uint64_t ctx_stride,
     int64_t *d_records, uint32_t ovec_slots, sre_nfa_window_t *d_win, const int64_t *d_lo,
-    hipStream_t stream);
+    const sre_nfa_count_req_t *d_creq, hipStream_t stream);
 /* ctx_bytes: size of one stream context (copied into LDS for the call when it fits) */
 hipError_t sre_launch_pike_exec(const void *blob, size_t blob_bytes, const sre_dev_req_t *d_reqs,
     uint32_t nreqs, size_t ctx_bytes, hipStream_t stream);

@@ -936,8 +936,8 @@ extern "C" __global__ void
 sre_k_pike_window(const uint8_t *__restrict__ blob, const uint8_t *const *__restrict__ streams,
                   const uint64_t *__restrict__ lens, uint32_t nstreams, uint8_t *ctx_base,
                   uint64_t ctx_stride, int64_t *__restrict__ records, uint32_t ovec_slots,
-                  sre_nfa_window_t *__restrict__ win, const int64_t *__restrict__ lo, uint32_t use_lds,
-                  uint32_t blob_lds_bytes)
+                  sre_nfa_window_t *__restrict__ win, const int64_t *__restrict__ lo,
+                  const sre_nfa_count_req_t *__restrict__ creq, uint32_t use_lds, uint32_t blob_lds_bytes)
 {
     /* one workgroup per stream; the (fresh) context lives in LDS when it fits, see
      * sre_k_pike_exec */
@@ -974,13 +974,31 @@ sre_k_pike_window(const uint8_t *__restrict__ blob, const uint8_t *const *__rest
     int64_t         *rec = records + (size_t) i * (2 + ovec_slots);
     sre_dev_result_t res;
     for (uint32_t k = 0; k < ovec_slots; k++) rec[2 + k] = -1;
-    const int64_t rc = vm.exec(lens[i], 1u, false, &res, rec + 2, ovec_slots, nullptr, win[i].clean_pos,
+    uint64_t      len = lens[i];
+    int64_t       start = win[i].clean_pos;
+    sre_dev_req_t preset;
+    preset.preset_valid = 0;
+    if (creq != nullptr) {
+        /* a search of a find-all iteration: the context is the re-armed one of the reference's caller */
+        vm.in.p = creq[i].vptr;
+        len = creq[i].vlen;
+        start += creq[i].start_add;
+        preset.preset_valid = 1;
+        preset.preset_processed = creq[i].processed;
+        preset.preset_flags = creq[i].preset_flags;
+    }
+    const int64_t rc = vm.exec(len, 1u, false, &res, rec + 2, ovec_slots, preset.preset_valid ? &preset : nullptr, start,
                                (win[i].clean_mode & 1) != 0);
     rec[0] = rc;
     rec[1] = rc >= 0 ? 1 : 0;
     /* a match returned with threads still listed at end of input: the context is
      * poisoned, its next exec fails (sre_vm_pike.c:616-622) — the compat API asks */
     if (rc >= 0 && vm.h->eof) win[i].clean_mode |= SRE_NFA_WINDOW_POISONED;
+    if (rc >= 0 && creq != nullptr && ovec_slots >= 2) {
+        /* what the next search's ^ goes by (seen_newline, :586-601) */
+        const int64_t e = rec[3] - creq[i].processed;
+        if (e > 0 && vm.in.p[e - 1] == '\n') win[i].clean_mode |= SRE_NFA_MATCH_AFTER_NL;
+    }
 }
 
 /* dynamic LDS a one-request VM kernel may take for the context (and program) copy */
@@ -998,7 +1016,7 @@ extern "C" hipError_t
 sre_launch_pike_window(const void *blob, size_t blob_bytes, const void *const *d_streams, const uint64_t *d_lens,
                        uint32_t nstreams, void *d_ctx, uint64_t ctx_stride, int64_t *d_records,
                        uint32_t ovec_slots, sre_nfa_window_t *d_win, const int64_t *d_lo,
-                       hipStream_t stream)
+                       const sre_nfa_count_req_t *d_creq, hipStream_t stream)
 {
     const uint32_t blob_lds = vm_blob_lds(blob_bytes, ctx_stride);
     const size_t   bytes = (((size_t) ctx_stride + 15) & ~(size_t) 15) + blob_lds;
@@ -1011,7 +1029,7 @@ sre_launch_pike_window(const void *blob, size_t blob_bytes, const void *const *d
     hipLaunchKernelGGL(sre_k_pike_window, dim3(nstreams), dim3(64), use_lds ? bytes : 0, stream,
                        static_cast<const uint8_t *>(blob),
                        reinterpret_cast<const uint8_t *const *>(d_streams), d_lens, nstreams,
-                       static_cast<uint8_t *>(d_ctx), ctx_stride, d_records, ovec_slots, d_win, d_lo, use_lds,
+                       static_cast<uint8_t *>(d_ctx), ctx_stride, d_records, ovec_slots, d_win, d_lo, d_creq, use_lds,
                        use_lds ? blob_lds : 0u);
     return hipGetLastError();
 }

@@ -118,6 +118,54 @@ def test_batched_count_vs_oracle(gpu, engine):
             assert rec == cnt, (pats, rec, cnt)
 
 
+@pytest.mark.parametrize("horizon", [0, 512])
+def test_count_on_the_nfa_tier_vs_oracle(gpu, horizon, monkeypatch):
+    """Find-all counting of programs the step automaton declines (ENGINE_NFA forced): rounds of
+    first-match searches — set kernel to the next MATCH event, exact VM over its window, next search
+    from the match's end (sre_vm_pike.c:179-196, :586-636).  Count, last regex id and last ovector
+    equal the oracle's iteration; a tiny horizon forces the rounds that move a search's buffer to its
+    last clean position and the ones that must let the horizon grow; several streams per batch."""
+    import random
+    if horizon:
+        monkeypatch.setenv("SRE_HIP_COUNT_HORIZON", str(horizon))
+    ora = harness.OracleEngine()
+    rng = random.Random(2025 + horizon)
+    zoo = [[rb"(?:a|b)*a(?:a|b){7}@"], [rb"(a|b)*a(a|b){5}(c)"], [rb"[ab]{3,9}c{2}(x)?"], [rb"x.{0,10}y"],
+           [rb"(a|ab|abc){2,6}x"], [rb"a[^x]{20}x"], [rb"(\w+ ){3}(\w+)"], [rb"\Aa.{3}b", rb"\nc{2,4}"],
+           [rb"[a-z]+@[a-z]+\.[a-z]+"], [rb"(a+)(b+)?"], [rb"(?:a.*b|a)"], [rb"\Ab+|xb"], [rb"(\n|a)b"],
+           [b"a", b"ab", b"c", b"a(bc)", b"e(f)", b"gh", b"A", b"b", b"BLAH", rb"\s+", b"abcd", b"bc"]]
+    alphabets = [b"abc", b"ab c\n.x@:/?y,d", b"aaaaab", b"ab", b"abcx@ \n"]
+    with S.Pool() as pool:
+        # a re-armed search that does not start behind a newline skips over newlines (the leading-byte
+        # skip fires on its bare initial list): programs whose seeded closure depends on ^ keep the VM
+        for pat in (rb"^b+", rb"(^|a)b"):
+            with pytest.raises(RuntimeError):
+                S.Scanner(pool, S.compile(pool, S.parse(pool, [pat])), S.HIP_PIKE_COUNT, S.ENGINE_NFA)
+    for pats in zoo:
+        with S.Pool() as pool:
+            re = S.parse(pool, pats)
+            prog = S.compile(pool, re)
+            sc = S.Scanner(pool, prog, S.HIP_PIKE_COUNT, S.ENGINE_NFA)
+            assert sc.engine == S.ENGINE_NFA
+            datas = []
+            for i in range(7):
+                alpha = alphabets[i % len(alphabets)]
+                n = rng.choice([0, 1, 65, 300, 2000, 9000])
+                datas.append(bytes(rng.choice(alpha) for _ in range(n)))
+            # sparse matches far apart, and none at all
+            datas.append((S.gen_data_host(5000, b" abaabaabab@ abccc") * 3)[:14000])
+            datas.append(b"x" * 3000 + b"abababab@" + b"x" * 2500 + b"\nb" + b"y" * 900)
+            datas.append(b"z" * 6000)
+            bufs = [S.DeviceBuffer.from_bytes(d) for d in datas]
+            recs = sc.scan([b.ptr for b in bufs], [len(d) for d in datas])
+            for d, rec in zip(datas, recs):
+                _, cnt = _expect(ora, prog, re.ncaps, d)
+                assert rec == cnt, (pats, horizon, d[:60], len(d), rec, cnt)
+            assert sc.last_count_rounds >= 1
+            for b in bufs:
+                b.free()
+
+
 def test_count_with_lookahead_assertions_on_the_scanner(gpu):
     """Find-all counting of a program with $ \\z \\b \\B on the table-driven scanner
     (ENGINE_SCAN is forced: a decline raises).  A re-armed search starts from the initial
@@ -1091,7 +1139,7 @@ def test_scanner_random_patterns_vs_oracle(gpu, seg):
                 if seg:
                     sc.set_segment_bytes(int(os.environ.get("SRE_FUZZ_SEG", seg)))
                 engines[("scan", mode)] = sc
-            for mode in (S.HIP_THOMPSON, S.HIP_PIKE_FIRST):
+            for mode in (S.HIP_THOMPSON, S.HIP_PIKE_FIRST, S.HIP_PIKE_COUNT):
                 # the bit-parallel NFA tier, forced (it is chosen by itself only when the
                 # step automaton declines): set pass + exact VM window.  (Not the look-ahead
                 # programs the builder declines: the reference VM itself may diverge on them,
