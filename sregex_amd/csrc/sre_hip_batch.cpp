@@ -405,7 +405,8 @@ sre_hip_scanner_kernel_name(sre_hip_scanner_t *sc)
                                      sc->kernel_name, sizeof(sc->kernel_name));
         } else {
             snprintf(sc->kernel_name, sizeof(sc->kernel_name), "%s",
-                     sc->mode == SRE_HIP_THOMPSON ? "sre_k_thompson_scan" : "sre_k_pike_scan");
+                     sc->mode == SRE_HIP_THOMPSON ? (sc->dp->has_wave ? "sre_k_thompson_wave_scan" : "sre_k_thompson_scan")
+                                                  : "sre_k_pike_scan");
         }
     }
     return sc->kernel_name;
@@ -826,9 +827,9 @@ nfa_count_rounds(sre_hip_scanner_t *sc, sre_int_t *results)
                 t.count++;
                 t.last.assign(rec, rec + slots);
                 const uint64_t end = (uint64_t) rec[3];
-                /* the next horizon: a few times the distance this match took */
-                const uint64_t gap = end > t.q ? end - t.q : 1;
-                t.horizon = gap * 4 < count_horizon(1u << 20) ? count_horizon(1u << 20) : gap * 4;
+                /* the next horizon: a little more than the distance from the previous match to this one */
+                const uint64_t gap = end > t.cur ? end - t.cur : 1;
+                t.horizon = gap + gap / 4 < count_horizon(1u << 20) ? count_horizon(1u << 20) : gap + gap / 4;
                 t.cur = t.q = end;
                 t.var_cur = t.var_q = (w.clean_mode & SRE_NFA_MATCH_AFTER_NL) ? 1u : 2u;
                 t.mode_q = 0;
@@ -902,7 +903,7 @@ sre_hip_scan_enqueue(sre_hip_scanner_t *sc, const void *const *d_streams, const 
         SRE_HIP_TRY(hipMemsetAsync(sc->d_ctx, 0, nstreams * sc->ctx_stride, stream));
         SRE_HIP_TRY(sre_launch_vm_scan(sc->dp->d_blob, sc->mode, sc->d_ptrs, sc->d_lens,
                                        (uint32_t) nstreams, sc->d_ctx, sc->ctx_stride,
-                                       sc->d_records, sc->ovec_slots, stream));
+                                       sc->d_records, sc->ovec_slots, sc->dp->has_wave, stream));
     } else if (sc->engine == SRE_HIP_ENGINE_NFA && sc->cnt != NULL) {
         /* find-all counting: a loop of first-match searches, run by results() (nfa_count_rounds) */
         NfaCount &c = *sc->cnt;

@@ -40,7 +40,7 @@ typedef struct {
     uint32_t  nclasses;
     uint32_t  nleading;    /* leading instructions (0: no leading-byte skip) */
     int32_t   leading_byte;/* single leading CHAR, or -1 */
-    uint32_t  pad;
+    uint32_t  wave_off;    /* byte offset of the sre_dev_wave_t behind the arrays below, 0: the program has none */
     /* followed, 16-B aligned, by:
      *   sre_dev_insn_t insns[len]
      *   uint32_t       classes[nclasses][8]
@@ -63,6 +63,21 @@ SRE_HD static inline size_t sre_dev_prog_bytes(uint32_t len, uint32_t nclasses, 
                                                uint32_t nleading) {
     return sre_dev_prog_leading_off(len, nclasses, nregexes) + SRE_DEV_ALIGN((size_t) (nleading + 1) * 4);
 }
+
+/*
+ * The WAVE form of a program (Thompson semantics, programs without look-ahead assertions whose
+ * list-able threads fit 64 bits): one wavefront walks one stream, lane q IS thread q of the
+ * bit-parallel form (sre_nfa.h), the live set is a 64-bit lane mask in scalar registers, and one
+ * input byte is  T = S & accept[byte];  S' = ballot((pred[lane] & T) != 0)  — BASELINE.json's
+ * north_star layout (reference loop: sre_vm_thompson.c:88-258; the x86 JIT keeps the same mask,
+ * sre_vm_thompson_x64.dasc:81-130).  pred[q] = the threads whose closure lists q.
+ */
+typedef struct {
+    uint64_t init0;         /* the list of the first buffer: \A and ^ hold */
+    uint64_t match;         /* MATCH threads */
+    uint64_t accept[256];
+    uint64_t pred[64];
+} sre_dev_wave_t;
 
 /* ---- per-stream request / result of one exec() on the exact VM kernels ---- */
 

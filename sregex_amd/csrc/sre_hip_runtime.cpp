@@ -4,6 +4,7 @@
  */
 #include "sre_hip_runtime.h"
 #include "sre_dfa.h"
+#include "sre_nfa.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -108,8 +109,35 @@ sre_hip_program_get(sre_program_t *prog)
     uint32_t nclasses = (uint32_t) (classes.size() / 8);
 
     size_t               bytes = sre_dev_prog_bytes(prog->len, nclasses, prog->nregexes, prog->nleading);
+    /* the wave form (sre_hip_common.h), when the program has one */
+    sre_dev_wave_t wave;
+    bool           has_wave = false;
+    {
+        sre_nfa_t *n = sre_nfa_build2(prog, SRE_NFA_SA_OFF, NULL);
+        if (n != NULL && n->nassert == 0) {
+            memset(&wave, 0, sizeof(wave));
+            wave.init0 = n->init[0];
+            wave.match = n->match_bits;
+            memcpy(wave.accept, n->accept, sizeof(wave.accept));
+            for (uint32_t i = 0; i < n->nbits; i++) {
+                /* follow of bit i = its slice's entry for the value with only that bit set */
+                const uint64_t f = n->follow[(size_t) (i / 8) * 256 + (1u << (i % 8))];
+                for (uint32_t q = 0; q < n->nbits; q++) {
+                    if ((f >> q) & 1) wave.pred[q] |= 1ull << i;
+                }
+            }
+            has_wave = true;
+        }
+        sre_nfa_free(n);
+    }
+    const size_t wave_off = bytes;
+    if (has_wave) bytes += SRE_DEV_ALIGN(sizeof(sre_dev_wave_t));
     std::vector<uint8_t> img(bytes, 0);
     sre_dev_prog_hdr_t  *h = reinterpret_cast<sre_dev_prog_hdr_t *>(img.data());
+    if (has_wave) {
+        h->wave_off = (uint32_t) wave_off;
+        memcpy(img.data() + wave_off, &wave, sizeof(wave));
+    }
     h->len = prog->len;
     h->nslots = prog->nslots;
     h->nregexes = prog->nregexes;
@@ -144,6 +172,7 @@ sre_hip_program_get(sre_program_t *prog)
     SRE_HIP_TRY(hipMalloc(&dp->d_blob, bytes));
     SRE_HIP_TRY(hipMemcpy(dp->d_blob, img.data(), bytes, hipMemcpyHostToDevice));
     dp->blob_bytes = bytes;
+    dp->has_wave = has_wave ? 1 : 0;
     dp->nclasses = nclasses;
     dp->pike_layout = sre_pike_layout(prog->len, prog->nthreads, prog->nslots);
     dp->thompson_layout = sre_thompson_layout(prog->len);

@@ -18,6 +18,7 @@ struct sre_hip_program_s {
     void       *d_blob;         /* sre_dev_prog_hdr_t + arrays */
     size_t      blob_bytes;
     uint32_t    nclasses;
+    int         has_wave;       /* the blob carries a sre_dev_wave_t: Thompson runs one wavefront per stream */
     sre_pike_layout_t      pike_layout;
     sre_thompson_layout_t  thompson_layout;
     /* step automata for the scanner (NULL until first use / if not buildable) */

@@ -69,7 +69,7 @@ hipError_t sre_launch_thompson_exec(const void *blob, size_t blob_bytes, const s
 /* whole-stream scan, one lane per stream; mode = SRE_HIP_THOMPSON / PIKE_FIRST / PIKE_COUNT */
 hipError_t sre_launch_vm_scan(const void *blob, int mode, const void *const *d_streams,
     const uint64_t *d_lens, uint32_t nstreams, void *d_ctx, uint64_t ctx_stride,
-    int64_t *d_records, uint32_t ovec_slots, hipStream_t stream);
+    int64_t *d_records, uint32_t ovec_slots, int has_wave, hipStream_t stream);
 #ifdef __cplusplus
 }
 #endif

@@ -611,6 +611,67 @@ struct Pike {
     }
 };
 
+
+/* ============================================================ Thompson, one wavefront per stream */
+
+constexpr uint32_t THOMPSON_WAVE_MAGIC = 0x54485756u;
+
+/*
+ * BASELINE.json's north_star layout, for the VM whose answer is a SET property (match / no match,
+ * sre_vm_thompson.c:63-270): lane q of the wave is thread q of the program's bit-parallel form,
+ * the live set S is a 64-bit lane mask in scalar registers, and one input byte is
+ *      T  = S & accept[byte]                       two scalar ANDs
+ *      S' = ballot((pred[lane] & T) != 0)          every lane: "does a thread that consumed list me?"
+ * The wave fetches 64 input bytes with one coalesced load (lane l byte l) and their accept masks
+ * with one gather; inside the block a byte costs two v_readlane, two scalar and four vector
+ * instructions and no memory access.  MATCH answers when the position it is listed at is RUN
+ * (:233-235): by the next byte, or by the extra iteration at end of input — a match completed by a
+ * chunk's last byte waits for the next call.  The context between calls is the mask.
+ * Programs with look-ahead assertions (their splices go by generation tags, sre_nfa.cpp) and with
+ * more than 64 thread bits keep the scalar VM below.
+ */
+__device__ inline uint64_t
+wave_readlane64(uint64_t v, uint32_t i)
+{
+    const uint32_t lo = (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) v, (int) i);
+    const uint32_t hi = (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) (v >> 32), (int) i);
+    return ((uint64_t) hi << 32) | lo;
+}
+
+__device__ inline uint64_t
+wave_uniform64(uint64_t v)
+{
+    const uint32_t lo = (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) v);
+    const uint32_t hi = (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) (v >> 32));
+    return ((uint64_t) hi << 32) | lo;
+}
+
+/* one exec() of sre_vm_thompson_exec on the set S; input == nullptr: the (<= 8) bytes travel in `inl` */
+__device__ inline int64_t
+thompson_wave_run(const sre_dev_wave_t *W, uint64_t &S, const uint8_t *input, uint64_t inl, uint64_t size, bool eof)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t pred = W->pred[lane];
+    const uint32_t pred_lo = (uint32_t) pred, pred_hi = (uint32_t) (pred >> 32);
+    const uint64_t match = wave_uniform64(W->match);
+    for (uint64_t base = 0; base < size; base += 64) {
+        const uint64_t idx = base + lane;
+        uint32_t       byte = 0;
+        if (idx < size) byte = input != nullptr ? input[idx] : (uint32_t) ((inl >> (8 * idx)) & 0xffu);
+        const uint64_t acc = W->accept[byte];
+        const uint32_t nb = size - base < 64 ? (uint32_t) (size - base) : 64u;
+        for (uint32_t i = 0; i < nb; i++) {
+            if (S == 0) return eof ? RC_DECLINED : RC_AGAIN;            /* :89 the list is empty */
+            if (S & match) return RC_OK;                                /* :233-235 */
+            const uint64_t T = S & wave_readlane64(acc, i);
+            S = __builtin_amdgcn_ballot_w64(((pred_lo & (uint32_t) T) | (pred_hi & (uint32_t) (T >> 32))) != 0);
+        }
+    }
+    /* the extra iteration at end of input (:88): a listed MATCH is met, nothing consumes */
+    if (eof && (S & match)) return RC_OK;
+    return eof ? RC_DECLINED : RC_AGAIN;
+}
+
 /* =================================================================== Thompson */
 
 constexpr uint32_t THOMPSON_MAGIC = 0x54484f4du;
@@ -838,6 +899,25 @@ sre_k_thompson_exec(const uint8_t *__restrict__ blob, const sre_dev_req_t *__res
     const uint32_t i = blockIdx.x;
     if (i >= nreqs) return;
     const sre_dev_req_t rq = reqs[i];
+    {
+        const uint32_t wave_off = reinterpret_cast<const sre_dev_prog_hdr_t *>(blob)->wave_off;
+        if (wave_off != 0) {
+            /* the wave form: the context is the live set (zero-filled == fresh) */
+            const sre_dev_wave_t *W = reinterpret_cast<const sre_dev_wave_t *>(blob + wave_off);
+            uint64_t             *cw = static_cast<uint64_t *>(rq.ctx);
+            uint64_t              S = wave_uniform64((uint32_t) cw[0] == THOMPSON_WAVE_MAGIC ? cw[1] : W->init0);
+            const int64_t         rc = thompson_wave_run(W, S, rq.input, rq.inline_bytes, rq.size, rq.eof != 0);
+            if (threadIdx.x == 0) {
+                sre_dev_result_t *res = static_cast<sre_dev_result_t *>(rq.result);
+                cw[0] = THOMPSON_WAVE_MAGIC;
+                cw[1] = S;
+                res->has_pending = 0;
+                res->consumed = 0;
+                res->rc = rc;
+            }
+            return;
+        }
+    }
     /* the program image too: the VM fetches an instruction per thread and step */
     blob = stage_blob(blob, ctx_lds, blob_lds_bytes);
 
@@ -1062,13 +1142,37 @@ sre_k_thompson_scan(const uint8_t *__restrict__ blob, const uint8_t *const *__re
     for (uint32_t k = 0; k < ovec_slots; k++) rec[2 + k] = -1;
 }
 
+/* whole streams, one wavefront each (the wave form, see thompson_wave_run) */
+extern "C" __global__ __launch_bounds__(64) void
+sre_k_thompson_wave_scan(const uint8_t *__restrict__ blob, const uint8_t *const *__restrict__ streams,
+                         const uint64_t *__restrict__ lens, uint32_t nstreams, int64_t *__restrict__ records,
+                         uint32_t ovec_slots)
+{
+    const uint32_t i = blockIdx.x;
+    if (i >= nstreams) return;
+    const sre_dev_wave_t *W = reinterpret_cast<const sre_dev_wave_t *>(
+        blob + reinterpret_cast<const sre_dev_prog_hdr_t *>(blob)->wave_off);
+    uint64_t      S = wave_uniform64(W->init0);
+    const int64_t rc = thompson_wave_run(W, S, streams[i], 0, lens[i], true);
+    int64_t      *rec = records + (size_t) i * (2 + ovec_slots);
+    if (threadIdx.x == 0) {
+        rec[0] = rc;
+        rec[1] = rc == RC_OK ? 1 : 0;
+    }
+    for (uint32_t k = threadIdx.x; k < ovec_slots; k += 64) rec[2 + k] = -1;
+}
+
 extern "C" hipError_t
 sre_launch_vm_scan(const void *blob, int mode, const void *const *d_streams,
                    const uint64_t *d_lens, uint32_t nstreams, void *d_ctx, uint64_t ctx_stride,
-                   int64_t *d_records, uint32_t ovec_slots, hipStream_t stream)
+                   int64_t *d_records, uint32_t ovec_slots, int has_wave, hipStream_t stream)
 {
     uint32_t block = 64, grid = (nstreams + block - 1) / block;
-    if (mode == 0) {
+    if (mode == 0 && has_wave) {
+        hipLaunchKernelGGL(sre_k_thompson_wave_scan, dim3(nstreams), dim3(64), 0, stream,
+                           static_cast<const uint8_t *>(blob),
+                           reinterpret_cast<const uint8_t *const *>(d_streams), d_lens, nstreams, d_records, ovec_slots);
+    } else if (mode == 0) {
         hipLaunchKernelGGL(sre_k_thompson_scan, dim3(grid), dim3(block), 0, stream,
                            static_cast<const uint8_t *>(blob),
                            reinterpret_cast<const uint8_t *const *>(d_streams), d_lens, nstreams,
