@@ -22,7 +22,11 @@
 #include <stddef.h>
 #include <stdio.h>
 #include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <mutex>
+#include <thread>
+#include <vector>
 #include <stdlib.h>
 #include <string.h>
 
@@ -74,6 +78,9 @@ struct DeviceStream {
      * (pinned, device-visible), allocated on first use */
     sre_stream_ctx_t    *d_sctx;
     sre_stream_result_t *h_sres, *d_sres;
+    /* large chunks: a ring of pinned pieces the copy pool fills while the DMA engine drains it */
+    uint8_t            *h_ring;             /* SRE_RING_SLOTS x SRE_RING_PIECE, hipHostMallocNonCoherent */
+    hipEvent_t          ev_ring[4];
     /* pinned double buffer of stage_input */
     uint8_t            *h_stage[2];
     uint8_t            *d_stage;            /* device view of h_stage[0] */
@@ -112,6 +119,10 @@ device_stream_destroy(DeviceStream *ds)
         if (ds->h_stage[b]) (void) hipHostFree(ds->h_stage[b]);
         if (ds->ev_stage[b]) (void) hipEventDestroy(ds->ev_stage[b]);
     }
+    if (ds->h_ring) (void) hipHostFree(ds->h_ring);
+    for (int b = 0; b < 4; b++) {
+        if (ds->ev_ring[b]) (void) hipEventDestroy(ds->ev_ring[b]);
+    }
     if (ds->d_sctx) (void) hipFree(ds->d_sctx);
     if (ds->h_sres) (void) hipHostFree(ds->h_sres);
     if (ds->h_blk) (void) hipHostFree(ds->h_blk);
@@ -129,6 +140,10 @@ device_stream_release(void *data)
             (void) hipFree(ds->d_in);
             ds->d_in = NULL;
             ds->in_cap = 0;
+        }
+        if (ds->h_ring) {
+            (void) hipHostFree(ds->h_ring);     /* 16 MiB of pinned memory: not kept by a parked stream */
+            ds->h_ring = NULL;
         }
         std::lock_guard<std::mutex> lock(g_mutex);
         if (g_nparked < SRE_STREAM_CACHE_MAX) {
@@ -288,6 +303,161 @@ sre_k_pull(const uint4 *__restrict__ src, uint4 *__restrict__ dst, uint32_t n16)
 
 #define SRE_STAGE_PIECE   (2u << 20)
 #define SRE_STAGE_MIN     (64u << 10)
+#define SRE_RING_SLOTS    4u
+#define SRE_RING_PIECE    (4u << 20)        /* one transfer: the link reaches its rate from ~4 MiB on (2 MiB: 45 GB/s) */
+#define SRE_RING_UNIT     (1u << 20)        /* one thread's copy: a transfer's four units are copied side by side */
+#define SRE_RING_MIN      (8u << 20)        /* chunks from here on go through the ring */
+
+/*
+ * Large chunks (round 3).  The runtime's own path for a pageable source is erratic on this pool —
+ * 55 GB/s in a copy loop of its own (tools/exp/h2d_ring.cpp), 4-27 GB/s inside a stream's calls
+ * (profiles/r02_stream_rate.json, r03) — so the chunk travels through a ring of pinned 4 MiB
+ * buffers: helper threads copy 1 MiB units into the slots (one core copies ~30 GB/s, four ~55)
+ * while the DMA engine drains the slots that are complete on the context's stream — the copy of
+ * the chunk's tail overlaps the transfer of its head inside ONE synchronous call.  The pool is
+ * process-wide, started on first use, and sleeps between calls.
+ */
+namespace {
+
+struct CopyPool {
+    std::mutex              m;
+    std::condition_variable cv_work;
+    std::vector<std::thread> threads;
+    /* the job in flight (one at a time: g_copy_mutex) */
+    const uint8_t          *src = nullptr;
+    uint8_t                *ring = nullptr;
+    size_t                  len = 0, nunits = 0;
+    std::atomic<size_t>     next{0};            /* next unit to copy */
+    std::atomic<size_t>     freed{0};           /* transfers whose slot may be overwritten: piece < freed + SLOTS */
+    std::atomic<uint64_t>   ready[64];          /* per unit (mod 64): (epoch, unit) once its copy is complete */
+    uint32_t                epoch = 0;
+    bool                    stop = false;
+    uint64_t                generation = 0;
+
+    void worker()
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv_work.wait(lk, [&] { return stop || generation != seen; });
+                if (stop) return;
+                seen = generation;
+            }
+            run();
+        }
+    }
+    /* copy units until none is left */
+    void run()
+    {
+        constexpr size_t UPP = SRE_RING_PIECE / SRE_RING_UNIT;
+        for (;;) {
+            const size_t u = next.fetch_add(1);
+            if (u >= nunits) return;
+            while (u / UPP >= freed.load(std::memory_order_acquire) + SRE_RING_SLOTS) {
+                /* the slot is still being drained */
+#if defined(__x86_64__)
+                __builtin_ia32_pause();
+#endif
+            }
+            const size_t off = u * (size_t) SRE_RING_UNIT, n = len - off < SRE_RING_UNIT ? len - off : SRE_RING_UNIT;
+            memcpy(ring + off % ((size_t) SRE_RING_SLOTS * SRE_RING_PIECE), src + off, n);
+            ready[u % 64].store(((uint64_t) epoch << 32) | (uint32_t) u, std::memory_order_release);
+        }
+    }
+};
+
+CopyPool  *g_copy_pool;
+std::mutex g_copy_mutex;        /* one chunk at a time through the pool */
+
+int
+copy_threads()
+{
+    const char *e = getenv("SRE_HIP_COPY_THREADS");
+    /* never more than the machine has to spare */
+    const int   hw = (int) std::thread::hardware_concurrency();
+    const int   n = e ? atoi(e) : (hw >= 8 ? 4 : hw >= 4 ? 2 : 1);
+    return n < 0 ? 0 : n > 8 ? 8 : n;
+}
+
+/* the chunk -> ds->d_in, queued on ds->stream; returns when every piece has been handed to the DMA engine */
+int
+ring_upload(DeviceStream *ds, const sre_char *input, size_t len)
+{
+    constexpr size_t UPP = SRE_RING_PIECE / SRE_RING_UNIT;
+    if (ds->h_ring == NULL) {
+        if (hipHostMalloc(reinterpret_cast<void **>(&ds->h_ring), (size_t) SRE_RING_SLOTS * SRE_RING_PIECE,
+                          hipHostMallocNonCoherent) != hipSuccess)
+        {
+            ds->h_ring = NULL;
+            return -1;
+        }
+        for (uint32_t b = 0; b < SRE_RING_SLOTS; b++) {
+            if (hipEventCreateWithFlags(&ds->ev_ring[b], hipEventDisableTiming) != hipSuccess) return -1;
+        }
+    }
+    std::lock_guard<std::mutex> job(g_copy_mutex);
+    if (g_copy_pool == NULL) {
+        g_copy_pool = new CopyPool();
+        for (int i = 0; i < 64; i++) g_copy_pool->ready[i].store(~0ull);
+        const int nt = copy_threads();
+        for (int i = 0; i < nt; i++) g_copy_pool->threads.emplace_back([] { g_copy_pool->worker(); });
+    }
+    CopyPool &P = *g_copy_pool;
+    const size_t npieces = (len + SRE_RING_PIECE - 1) / SRE_RING_PIECE;
+    {
+        std::lock_guard<std::mutex> lk(P.m);
+        P.src = input;
+        P.ring = ds->h_ring;
+        P.len = len;
+        P.nunits = (len + SRE_RING_UNIT - 1) / SRE_RING_UNIT;
+        P.epoch++;
+        P.next.store(0);
+        P.freed.store(0);
+        P.generation++;
+    }
+    P.cv_work.notify_all();
+    int    rc = 0;
+    size_t drained = 0;         /* transfers that have completed */
+    for (size_t p = 0; p < npieces; p++) {
+        const size_t u_end = (p + 1) * UPP < P.nunits ? (p + 1) * UPP : P.nunits;
+        for (size_t u = p * UPP; u < u_end; u++) {
+            /* no helpers (SRE_HIP_COPY_THREADS=0): the caller copies */
+            while (P.ready[u % 64].load(std::memory_order_acquire) != (((uint64_t) P.epoch << 32) | (uint32_t) u)) {
+                if (P.threads.empty()) {
+                    P.run();
+                } else {
+#if defined(__x86_64__)
+                    __builtin_ia32_pause();
+#endif
+                }
+            }
+        }
+        const size_t off = p * (size_t) SRE_RING_PIECE, n = len - off < SRE_RING_PIECE ? len - off : SRE_RING_PIECE;
+        if (rc == 0
+            && (hipMemcpyAsync(static_cast<uint8_t *>(ds->d_in) + off, ds->h_ring + (p % SRE_RING_SLOTS) * (size_t) SRE_RING_PIECE,
+                               n, hipMemcpyHostToDevice, ds->stream) != hipSuccess
+                || hipEventRecord(ds->ev_ring[p % SRE_RING_SLOTS], ds->stream) != hipSuccess))
+        {
+            rc = -1;            /* keep the ring turning so that the helpers finish */
+        }
+        /* free the slots whose transfer is over; wait for the oldest one when the ring is full */
+        while (drained <= p) {
+            const size_t q = drained;
+            const bool   must = (p + 1 - drained) >= SRE_RING_SLOTS && p + 1 < npieces;
+            if (rc == 0) {
+                hipError_t e = must ? hipEventSynchronize(ds->ev_ring[q % SRE_RING_SLOTS]) : hipEventQuery(ds->ev_ring[q % SRE_RING_SLOTS]);
+                if (e == hipErrorNotReady) break;
+                if (e != hipSuccess) rc = -1;
+            }
+            drained++;
+            P.freed.store(drained, std::memory_order_release);
+        }
+    }
+    return rc;
+}
+
+}  // namespace
 
 static int
 stage_input(DeviceStream *ds, const sre_char *input, size_t len)
@@ -300,6 +470,11 @@ stage_input(DeviceStream *ds, const sre_char *input, size_t len)
         ds->in_cap = len + (len >> 2) + 4096;
     }
     if (len == 0) return 0;
+    static const bool use_ring = getenv("SRE_HIP_NO_RING") == NULL;
+    if (len >= SRE_RING_MIN && use_ring) {
+        if (ring_upload(ds, input, len) == 0) return 0;
+        return -1;
+    }
     if (len < SRE_STAGE_MIN || len > SRE_STAGE_PIECE) {
         return hipMemcpyAsync(ds->d_in, input, len, hipMemcpyHostToDevice, ds->stream) == hipSuccess ? 0 : -1;
     }
@@ -522,7 +697,21 @@ pike_stream_route(sre_vm_pike_ctx_t *ctx, sre_char *input, size_t len, unsigned 
     {
         return 0;
     }
+    static const bool dbg_t = getenv("SRE_HIP_DEBUG_TIMING") != NULL;
+    const auto t_a = std::chrono::steady_clock::now();
     if (stage_input(ds, input, len) != 0) return 0;
+    const auto t_b = std::chrono::steady_clock::now();
+    if (dbg_t) {
+        (void) hipStreamSynchronize(ds->stream);
+        const auto t_c = std::chrono::steady_clock::now();
+        fprintf(stderr, "[sregex-hip] chunk %zu B: stage %.1f us (+%.1f us until landed)", len,
+                std::chrono::duration<double, std::micro>(t_b - t_a).count(), std::chrono::duration<double, std::micro>(t_c - t_b).count());
+    }
+    const auto t_d = std::chrono::steady_clock::now();
+    struct ChunkTimer {
+        bool on; std::chrono::steady_clock::time_point t0;
+        ~ChunkTimer() { if (on) fprintf(stderr, ", scan+tail %.1f us\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count()); }
+    } chunk_timer{dbg_t, t_d};
     ds->h_sres->rc = SRE_STREAM_PENDING;
     if (sre_hip_scan_stream_chunk(sc, static_cast<const uint8_t *>(ds->d_in) + skip, len - skip, variant,
                                   ctx->stream_mode, entry, eof ? 1 : 0,

@@ -767,7 +767,8 @@ def test_compat_api_chunked_stream_rate(gpu):
         prog = S.compile(pool, re)
         # each shape twice: the first pass pays for the context's device buffers
         for name, step in (("1 MiB chunks (cold)", chunk), ("1 MiB chunks", chunk),
-                           ("16 MiB chunks (cold)", 16 << 20), ("16 MiB chunks", 16 << 20)):
+                           ("16 MiB chunks (cold)", 16 << 20), ("16 MiB chunks", 16 << 20),
+                           ("64 KiB chunks", 64 << 10), ("4 MiB chunks", 4 << 20), ("64 MiB chunks", 64 << 20)):
             with S.Pool() as ep:
                 ctx = S.PikeCtx(ep, prog, re.ncaps)
                 buf = ctypes.create_string_buffer(data, L)
