@@ -16,6 +16,7 @@
 #include "sre_dfa.h"
 #include "sre_nfa.h"
 #include "sre_hip_nfa.h"
+#include "sre_pwave.h"
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -92,6 +93,8 @@ struct sre_hip_scanner_s {
     sre_nfa_count_req_t      *d_creq, *h_creq;
     size_t                    cnt_cap;
     int                       count_rounds;             /* of the last call (diagnostics) */
+    sre_pwave_hdr_t          *h_pwave;                  /* the wave form of the exact window's step (sre_pwave.h), or NULL */
+    void                     *d_pwave;
     size_t                    layout_n;                 /* streams the staging blocks are laid out for */
     sre_nfa_summary_t        *d_nsum;
     size_t                    nsum_cap;
@@ -123,6 +126,8 @@ scanner_release(void *data)
 {
     sre_hip_scanner_t *sc = static_cast<sre_hip_scanner_t *>(data);
     delete sc->cnt;
+    free(sc->h_pwave);
+    if (sc->d_pwave) (void) hipFree(sc->d_pwave);
     if (sc->d_sflags) (void) hipFree(sc->d_sflags);
     if (sc->h_sflags) (void) hipHostFree(sc->h_sflags);
     if (sc->d_creq) (void) hipFree(sc->d_creq);
@@ -337,6 +342,23 @@ scanner_create(sre_pool_t *pool, sre_program_t *prog, int mode, int engine, int 
         if (sc->nfa && nfa_upload(sc) == 0) {
             sc->engine = SRE_HIP_ENGINE_NFA;
             if (mode == SRE_HIP_PIKE_COUNT) sc->cnt = new NfaCount();
+            if (mode != SRE_HIP_THOMPSON && getenv("SRE_HIP_NO_PWAVE") == NULL) {
+                /* the exact window's step by a wavefront, when the program has the form */
+                sc->h_pwave = sre_pwave_build(prog);
+                if (sc->h_pwave && !sre_pwave_fits(sc->h_pwave)) {
+                    free(sc->h_pwave);
+                    sc->h_pwave = NULL;
+                }
+                if (sc->h_pwave
+                    && (hipMalloc(&sc->d_pwave, sc->h_pwave->bytes) != hipSuccess
+                        || hipMemcpy(sc->d_pwave, sc->h_pwave, sc->h_pwave->bytes, hipMemcpyHostToDevice) != hipSuccess))
+                {
+                    if (sc->d_pwave) (void) hipFree(sc->d_pwave);
+                    sc->d_pwave = NULL;
+                    free(sc->h_pwave);
+                    sc->h_pwave = NULL;
+                }
+            }
         } else if (engine == SRE_HIP_ENGINE_NFA) {
             fprintf(stderr, "[sregex-hip] bit-parallel NFA scanner not available: %s\n",
                     why ? why : "device allocation failed");
@@ -639,11 +661,17 @@ nfa_finish(sre_hip_scanner_t *sc, const int64_t *d_lo, hipStream_t stream)
     SRE_HIP_TRY(sre_launch_nfa_verify(kmode, sc->geom, sc->d_nsum, sc->d_nacc, sc->d_nstatus,
                                       sc->d_belief, sc->d_bvalid, sc->d_records, sc->ovec_slots, d_lo, stream));
     if (sc->mode != SRE_HIP_THOMPSON) {
-        /* (the window kernel zero-fills the context it uses) */
-        SRE_HIP_TRY(sre_launch_pike_window(sc->dp->d_blob, sc->dp->blob_bytes, sc->d_ptrs, sc->d_lens, n, sc->d_ctx, sc->ctx_stride,
-                                           sc->d_records, sc->ovec_slots,
-                                           reinterpret_cast<sre_nfa_window_t *>(sc->d_nstatus), d_lo,
-                                           sc->geom.sflags ? sc->d_creq : NULL, stream));
+        if (sc->d_pwave) {
+            SRE_HIP_TRY(sre_launch_pike_window_wave(sc->d_pwave, sc->h_pwave, sc->d_ptrs, sc->d_lens, n, sc->d_records,
+                                                    sc->ovec_slots, reinterpret_cast<sre_nfa_window_t *>(sc->d_nstatus), d_lo,
+                                                    sc->geom.sflags ? sc->d_creq : NULL, stream));
+        } else {
+            /* (the window kernel zero-fills the context it uses) */
+            SRE_HIP_TRY(sre_launch_pike_window(sc->dp->d_blob, sc->dp->blob_bytes, sc->d_ptrs, sc->d_lens, n, sc->d_ctx, sc->ctx_stride,
+                                               sc->d_records, sc->ovec_slots,
+                                               reinterpret_cast<sre_nfa_window_t *>(sc->d_nstatus), d_lo,
+                                               sc->geom.sflags ? sc->d_creq : NULL, stream));
+        }
     }
     return 0;
 hip_failed:

@@ -1,0 +1,397 @@
+/*
+ * sre_hip_pwave.hip — the exact Pike step taken by a WAVEFRONT (gfx950): lanes = the threads of
+ * the ordered list, for the exact window behind the bit-parallel NFA scanner (sre_hip_nfa.hip).
+ *
+ * The one-lane VM (sre_hip_vm.hip) walks the reference loop thread by thread, ~1 us per
+ * thread-step: the 13-57-byte windows of 19-60-thread programs cost 0.6-1.4 ms, more than the 4 GiB
+ * set pass in front of them (profiles/r03_kernel_stats_nfa*.csv).  Here one byte step
+ * (sre_vm_pike.c:312-581) is
+ *   1. every lane i < n tests ITS thread against the byte (one LDS word of the thread's 256-bit
+ *      accept map) and says whether it is a MATCH thread: two ballots — the consuming threads and
+ *      the first listed MATCH, which cuts everything behind it (:530-553);
+ *   2. the consuming threads in priority order (a scalar loop over the ballot's bits): the lanes
+ *      load the source's STATIC closure list (sre_pwave.h), drop the targets an earlier source of
+ *      this step has listed (a stamp per thread in LDS: the generation tags of :770, :792), rank
+ *      the rest by a prefix count over the ballot of survivors — the new list's order is the
+ *      source order, then the closure's order — and take the source's capture vector, the slots
+ *      saved on the way replaced by the position (:826-837), broadcast from the source's column;
+ *   3. a closure that reaches MATCH ends the step (SRE_DONE, :895-898): its captures become the
+ *      match, lower-priority threads are dropped.
+ * Between steps the leading-byte skip (:256-309) compares the list with the snapshot by one
+ * ballot and looks for the next byte that can start a match 64 bytes at a time.
+ * Everything the reference's quirks need is kept: seen_start_state, the snapshot without its last
+ * thread, a skip target stepped without a check, the poisoned context.  Control flow is uniform;
+ * the list (thread id per lane) and the capture vectors (one column per lane, slot-major) live in
+ * LDS.  Cost per byte: ~2 LDS round trips per consuming thread plus 5 instructions per capture
+ * slot and new thread — 0.3-0.5 us for the usual two or three consumers, a few us for thirty.
+ * Measured (same box, bench.py --config nfa60, 4 GiB): whole step 1.33 ms with the one-lane
+ * window, 0.98 ms with this kernel (the set pass alone: 0.94).
+ */
+#include <hip/hip_runtime.h>
+#include "sre_pwave.h"
+#include "sre_hip_common.h"
+#include "sre_hip_vm.h"
+
+#define PW_RC_DECLINED (-5)
+
+namespace {
+
+__device__ inline uint32_t
+pw_lane_rank(uint64_t mask)
+{
+    /* set bits of `mask` below this lane */
+    return __builtin_amdgcn_mbcnt_hi((uint32_t) (mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mask, 0u));
+}
+
+__device__ inline uint32_t
+pw_uniform(uint32_t v)
+{
+    return (uint32_t) __builtin_amdgcn_readfirstlane((int) v);
+}
+
+__device__ inline uint32_t
+pw_readlane(uint32_t v, uint32_t lane)
+{
+    return (uint32_t) __builtin_amdgcn_readlane((int) v, (int) lane);
+}
+
+struct PikeWave {
+    /* tables (LDS copies, entries possibly global) */
+    const sre_pwave_hdr_t   *W;
+    const uint32_t          *accw;      /* [64][8] */
+    const sre_pwave_list_t  *lists;     /* [nlists][3] */
+    const sre_pwave_entry_t *ents;
+    const uint16_t          *tid_list, *tid_match;
+    /* state (LDS) */
+    int64_t  *caps[2];      /* [nslots][64] each */
+    int64_t  *matched;      /* [nslots] */
+    uint16_t *tidv[2];      /* [64] */
+    uint32_t *stamp;        /* [64] */
+    uint16_t *initial;      /* [64] */
+    /* uniform state */
+    const uint8_t *in;
+    uint32_t nslots, lane;
+    uint32_t n, cur, stamp_cur;
+    int64_t  processed;
+    uint32_t seen_newline, sss, initial_count, has_matched, poisoned;
+    int64_t  matched_id;
+
+    __device__ inline uint32_t ctx_at(int64_t pos) const
+    {
+        if (pos == 0) return processed == 0 ? 2u : (seen_newline ? 1u : 0u);    /* :841-860 */
+        return pw_uniform(in[pos - 1] == '\n' ? 1u : 0u);
+    }
+
+    /* the list of a search that (re)starts at `pos`: closure of instruction 0 with an all -1 vector */
+    __device__ inline void seed(int64_t pos)
+    {
+        const sre_pwave_list_t L = lists[0 * SRE_PWAVE_NCTX + ctx_at(pos)];
+        const bool             valid = lane < L.len;
+        sre_pwave_entry_t      e;
+        e.tid = 0;
+        e.saves = 0;
+        if (valid) e = ents[L.off + lane];
+        if (valid) tidv[cur][lane] = e.tid;
+        const int64_t at = processed + pos;
+        for (uint32_t s = 0; s < nslots; s++) {
+            if (valid) caps[cur][s * 64 + lane] = ((e.saves >> s) & 1) ? at : (int64_t) -1;
+        }
+        n = pw_uniform(L.len);          /* (every lane read the same entry: tell the compiler) */
+        if (pw_uniform(L.sss)) sss = 1;
+    }
+
+    /* sre_vm_pike.c:992-1061, 64 bytes at a time */
+    __device__ inline int64_t find_first_byte(int64_t pos, int64_t last) const
+    {
+        while (pos < last) {
+            const int64_t  p = pos + lane;
+            bool           hit = false;
+            if (p < last) {
+                const uint32_t c = in[p];
+                hit = (W->lead[c >> 5] >> (c & 31)) & 1;
+            }
+            const uint64_t m = __builtin_amdgcn_ballot_w64(hit);
+            if (m) return pos + __builtin_ctzll(m);
+            pos += 64;
+        }
+        return last;
+    }
+
+    /* one whole-buffer exec() of a fresh (possibly re-armed) context with eof, picked up at `start`
+     * (sre_hip_vm.hip Pike::exec) */
+    __device__ int64_t exec(int64_t size, int64_t start, bool start_is_skip_target, int64_t *ov, uint32_t ovec_slots)
+    {
+        const int64_t last = size;
+        int64_t       sp = 0;
+        bool          no_check_once = false, skip_ran_out = false;
+        int64_t       last_matched_pos = -1;
+        cur = 0;
+        n = 0;
+        sss = 0;
+        has_matched = 0;
+        poisoned = 0;
+        stamp_cur = 0;
+        stamp[lane] = 0;
+        /* :202-233 */
+        seed(sp);
+        initial_count = n;
+        if (lane + 1 < n) initial[lane] = tidv[cur][lane];      /* all but its last thread (:218-229) */
+        if (start > sp) {
+            sp = start;
+            if (W->nleading && start_is_skip_target) {
+                sp = find_first_byte(sp, last);
+                no_check_once = true;
+                if (sp == last) skip_ran_out = true;            /* :304-306 */
+            }
+            seed(sp);
+        }
+
+        for (; !skip_ran_out && sp <= last; sp++) {             /* :235 (eof) */
+            if (n == 0) break;
+            if (no_check_once) {
+                no_check_once = false;
+            } else if (W->nleading && sss) {                    /* :256-309 */
+                sss = 0;
+                bool same = (sp != last) && (n == initial_count);
+                if (same) {
+                    const bool diff = lane + 1 < n && tidv[cur][lane] != initial[lane];
+                    same = __builtin_amdgcn_ballot_w64(diff) == 0;
+                }
+                if (same) {
+                    const int64_t p = find_first_byte(sp, last);
+                    if (p > sp) {
+                        sp = p;
+                        seed(sp);
+                        if (sp == last) break;
+                    }
+                }
+            }
+            /* ---- the step (:312-581) */
+            const bool     at_end = sp == last;
+            const uint32_t c = at_end ? 0u : pw_uniform((uint32_t) in[sp]);
+            const uint32_t nxt = cur ^ 1u;
+            const int64_t  pos1 = processed + sp + 1;
+            uint32_t       t = 0, is_m = 0, acc = 0;
+            uint32_t       l_off = 0, l_len = 0, l_done = 0, l_sss = 0;
+            if (lane < n) {
+                t = tidv[cur][lane];
+                is_m = tid_match[t];
+                if (!at_end && !is_m) {
+                    acc = (accw[t * 8 + (c >> 5)] >> (c & 31)) & 1u;
+                    if (acc) {
+                        /* ^ behind the byte goes by the byte (:851-860); \A never holds there */
+                        const sre_pwave_list_t L = lists[(uint32_t) tid_list[t] * SRE_PWAVE_NCTX + (c == '\n' ? 1u : 0u)];
+                        l_off = L.off;
+                        l_len = L.len;
+                        l_done = L.done;
+                        l_sss = L.sss;
+                    }
+                }
+            }
+            const uint64_t mm = __builtin_amdgcn_ballot_w64(is_m != 0);
+            const uint32_t m = mm ? (uint32_t) __builtin_ctzll(mm) : 64u;
+            uint64_t       src = __builtin_amdgcn_ballot_w64(acc != 0);
+            if (m < 64) src &= (1ull << m) - 1;                 /* a listed MATCH cuts what is behind it (:530-553) */
+            const uint64_t dm = __builtin_amdgcn_ballot_w64(l_done != 0) & src;
+            const uint32_t d = dm ? (uint32_t) __builtin_ctzll(dm) : 64u;
+            if (d < 63) src &= (2ull << d) - 1;                 /* SRE_DONE ends the step behind its source (:895-898) */
+            stamp_cur++;
+            uint32_t nn = 0;
+            bool     done = false;
+            for (uint64_t rem = src; rem; rem &= rem - 1) {
+                const uint32_t i = (uint32_t) __builtin_ctzll(rem);
+                const uint32_t off = pw_readlane(l_off, i), len = pw_readlane(l_len, i);
+                if (pw_readlane(l_sss, i)) sss = 1;
+                const bool        valid = lane < len;
+                sre_pwave_entry_t e;
+                e.tid = 0;
+                e.saves = 0;
+                if (valid) e = ents[off + lane];
+                const bool     keep = valid && stamp[e.tid] != stamp_cur;       /* first arrival wins (:770) */
+                const uint64_t km = __builtin_amdgcn_ballot_w64(keep);
+                const uint32_t rank = nn + pw_lane_rank(km);
+                if (keep) {
+                    stamp[e.tid] = stamp_cur;
+                    tidv[nxt][rank] = e.tid;
+                }
+                /* the source's capture vector, broadcast slot by slot */
+                for (uint32_t s = 0; s < nslots; s++) {
+                    const int64_t v = caps[cur][s * 64 + i];
+                    if (keep) caps[nxt][s * 64 + rank] = ((e.saves >> s) & 1) ? pos1 : v;
+                }
+                nn += (uint32_t) __builtin_popcountll(km);
+                if (i == d) {
+                    /* the closure reached MATCH behind its listed targets: the match (:895-898) */
+                    const sre_pwave_entry_t me = ents[off + len];
+                    if (lane < nslots) matched[lane] = ((me.saves >> lane) & 1) ? pos1 : caps[cur][lane * 64 + i];
+                    matched_id = (int64_t) pw_uniform(tid_match[me.tid]) - 1;
+                    done = true;
+                }
+            }
+            if (!done && m < 64) {
+                /* the listed MATCH thread is reached (:530-553) */
+                if (lane < nslots) matched[lane] = caps[cur][lane * 64 + m];
+                matched_id = (int64_t) pw_readlane(is_m, m) - 1;
+                done = true;
+            }
+            if (done) {
+                has_matched = 1;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                last_matched_pos = (int64_t) (((uint64_t) pw_uniform((uint32_t) ((uint64_t) matched[1] >> 32)) << 32)
+                                              | pw_uniform((uint32_t) (uint64_t) matched[1]));
+            }
+            cur = nxt;
+            n = nn;
+            if (at_end) break;
+        }
+
+        (void) last_matched_pos;        /* (seen_newline / seen_word of the context: the window's context is not used again) */
+        if (has_matched) {                                      /* :607-636, eof */
+            if (matched_id >= (int64_t) W->nregexes) return -1;
+            const uint32_t *ncaps = reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(W) + W->multi_ncaps_off);
+            uint32_t        ofs = 0;
+            for (int64_t r = 0; r < matched_id; r++) ofs += ncaps[r] + 1;
+            ofs *= 2;
+            const uint32_t cnt = 2u * (ncaps[matched_id] + 1);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            for (uint32_t k = lane; k < ovec_slots; k += 64) ov[k] = k < cnt ? matched[ofs + k] : (int64_t) -1;
+            if (n > 0) poisoned = 1;                            /* :616-622 */
+            return matched_id;
+        }
+        return PW_RC_DECLINED;                                  /* :660-666 */
+    }
+};
+
+}  // namespace
+
+/* LDS a window wave needs for a program */
+static size_t
+pwave_lds_bytes(const sre_pwave_hdr_t *h, bool *ents_in_lds)
+{
+    size_t b = 0;
+    b += 2 * (size_t) h->nslots * 64 * 8;       /* caps */
+    b += 64 * 8;                                /* matched */
+    b += 2 * 64 * 2 + 64 * 4 + 64 * 2;          /* tidv, stamp, initial */
+    b += 64 * 8 * 4 + 64 * 2 * 2;               /* accept words, tid_list, tid_match */
+    b += (size_t) h->nlists * SRE_PWAVE_NCTX * sizeof(sre_pwave_list_t);
+    const size_t eb = ((size_t) h->nentries + 1) * sizeof(sre_pwave_entry_t);
+    *ents_in_lds = b + eb <= 60 * 1024;
+    if (*ents_in_lds) b += eb;
+    return (b + 15) & ~(size_t) 15;
+}
+
+extern "C" __global__ __launch_bounds__(64) void
+sre_k_pike_window_wave(const sre_pwave_hdr_t *__restrict__ Wg, const uint8_t *const *__restrict__ streams,
+                       const uint64_t *__restrict__ lens, uint32_t nstreams, int64_t *__restrict__ records,
+                       uint32_t ovec_slots, sre_nfa_window_t *__restrict__ win, const int64_t *__restrict__ lo,
+                       const sre_nfa_count_req_t *__restrict__ creq, uint32_t ents_in_lds)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const uint32_t i = blockIdx.x;
+    if (i >= nstreams) return;
+    if (lo != nullptr && lo[i] < 0) return;     /* settled in an earlier round */
+    if (!win[i].done || win[i].ev_pos < 0) return;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t nslots = Wg->nslots;
+
+    PikeWave vm;
+    uint8_t *p = lds;
+    vm.caps[0] = reinterpret_cast<int64_t *>(p);    p += (size_t) nslots * 64 * 8;
+    vm.caps[1] = reinterpret_cast<int64_t *>(p);    p += (size_t) nslots * 64 * 8;
+    vm.matched = reinterpret_cast<int64_t *>(p);    p += 64 * 8;
+    uint32_t *accw = reinterpret_cast<uint32_t *>(p);   p += 64 * 8 * 4;
+    vm.stamp = reinterpret_cast<uint32_t *>(p);     p += 64 * 4;
+    vm.tidv[0] = reinterpret_cast<uint16_t *>(p);   p += 64 * 2;
+    vm.tidv[1] = reinterpret_cast<uint16_t *>(p);   p += 64 * 2;
+    vm.initial = reinterpret_cast<uint16_t *>(p);   p += 64 * 2;
+    uint16_t *tid_list = reinterpret_cast<uint16_t *>(p);   p += 64 * 2;
+    uint16_t *tid_match = reinterpret_cast<uint16_t *>(p);  p += 64 * 2;
+    sre_pwave_list_t *lists = reinterpret_cast<sre_pwave_list_t *>(p);
+    p += (size_t) Wg->nlists * SRE_PWAVE_NCTX * sizeof(sre_pwave_list_t);
+    p = lds + (((size_t) (p - lds) + 15) & ~(size_t) 15);
+    const uint8_t *wb = reinterpret_cast<const uint8_t *>(Wg);
+    for (uint32_t k = lane; k < 64 * 8; k += 64) accw[k] = Wg->accept[k >> 3][k & 7];
+    tid_list[lane] = Wg->tid_list[lane];
+    tid_match[lane] = Wg->tid_match[lane];
+    {
+        const sre_pwave_list_t *gl = reinterpret_cast<const sre_pwave_list_t *>(wb + Wg->off_lists);
+        for (uint32_t k = lane; k < Wg->nlists * SRE_PWAVE_NCTX; k += 64) lists[k] = gl[k];
+    }
+    const sre_pwave_entry_t *ents = reinterpret_cast<const sre_pwave_entry_t *>(wb + Wg->off_entries);
+    if (ents_in_lds) {
+        sre_pwave_entry_t *le = reinterpret_cast<sre_pwave_entry_t *>(p);
+        for (uint32_t k = lane; k < Wg->nentries + 1; k += 64) le[k] = ents[k];
+        ents = le;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    vm.W = Wg;
+    vm.accw = accw;
+    vm.lists = lists;
+    vm.ents = ents;
+    vm.tid_list = tid_list;
+    vm.tid_match = tid_match;
+    vm.nslots = nslots;
+    vm.lane = lane;
+    vm.in = streams[i];
+    vm.processed = 0;
+    vm.seen_newline = 0;
+
+    int64_t *rec = records + (size_t) i * (2 + ovec_slots);
+    uint64_t len = lens[i];
+    int64_t  start = win[i].clean_pos;
+    if (creq != nullptr) {
+        /* a search of a find-all iteration: the reference's re-armed context */
+        vm.in = creq[i].vptr;
+        len = creq[i].vlen;
+        start += creq[i].start_add;
+        vm.processed = creq[i].processed;
+        vm.seen_newline = (creq[i].preset_flags & SRE_PRESET_SEEN_NEWLINE) ? 1u : 0u;
+    }
+    const int64_t rc = vm.exec((int64_t) len, start, (win[i].clean_mode & 1) != 0, rec + 2, ovec_slots);
+    if (rc < 0) {
+        for (uint32_t k = lane; k < ovec_slots; k += 64) rec[2 + k] = -1;
+    }
+    if (lane == 0) {
+        rec[0] = rc;
+        rec[1] = rc >= 0 ? 1 : 0;
+        int32_t cm = win[i].clean_mode;
+        if (rc >= 0 && vm.poisoned) cm |= SRE_NFA_WINDOW_POISONED;
+        if (rc >= 0 && creq != nullptr && ovec_slots >= 2) {
+            /* what the next search's ^ goes by (seen_newline, :586-601) */
+            const int64_t e = vm.matched[1] - creq[i].processed;
+            /* (slot 1 of the internal vector: the end of a match of regex 0; other regexes' matches
+             * leave last_matched_pos unset and the flag unchanged — the host keeps its own) */
+            if (e > 0 && vm.in[e - 1] == '\n') cm |= SRE_NFA_MATCH_AFTER_NL;
+        }
+        win[i].clean_mode = cm;
+    }
+}
+
+extern "C" hipError_t
+sre_launch_pike_window_wave(const void *d_wave_v, const void *h_wave_v, const void *const *d_streams,
+                            const uint64_t *d_lens, uint32_t nstreams, int64_t *d_records, uint32_t ovec_slots,
+                            sre_nfa_window_t *d_win, const int64_t *d_lo, const sre_nfa_count_req_t *d_creq,
+                            hipStream_t stream)
+{
+    const sre_pwave_hdr_t *d_wave = static_cast<const sre_pwave_hdr_t *>(d_wave_v);
+    const sre_pwave_hdr_t *h_wave = static_cast<const sre_pwave_hdr_t *>(h_wave_v);
+    bool         in_lds = false;
+    const size_t bytes = pwave_lds_bytes(h_wave, &in_lds);
+    if (bytes > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sre_k_pike_window_wave),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(sre_k_pike_window_wave, dim3(nstreams), dim3(64), bytes, stream, d_wave,
+                       reinterpret_cast<const uint8_t *const *>(d_streams), d_lens, nstreams, d_records, ovec_slots,
+                       d_win, d_lo, d_creq, in_lds ? 1u : 0u);
+    return hipGetLastError();
+}
+
+/* does a wave's state for this program fit the LDS of a workgroup? */
+extern "C" int
+sre_pwave_fits(const void *h_wave)
+{
+    bool in_lds;
+    return pwave_lds_bytes(static_cast<const sre_pwave_hdr_t *>(h_wave), &in_lds) <= 96 * 1024;
+}

@@ -61,6 +61,13 @@ hipError_t sre_launch_pike_window(const void *blob, size_t blob_bytes, const voi
     const uint64_t *d_lens, uint32_t nstreams, void *d_ctx, uint64_t ctx_stride,
     int64_t *d_records, uint32_t ovec_slots, sre_nfa_window_t *d_win, const int64_t *d_lo,
     const sre_nfa_count_req_t *d_creq, hipStream_t stream);
+/* the same windows taken by one wavefront per stream (sre_hip_pwave.hip; programs with a wave form,
+ * sre_pwave.h) */
+struct sre_pwave_hdr_s;
+hipError_t sre_launch_pike_window_wave(const void *d_wave, const void *h_wave, const void *const *d_streams,
+    const uint64_t *d_lens, uint32_t nstreams, int64_t *d_records, uint32_t ovec_slots,
+    sre_nfa_window_t *d_win, const int64_t *d_lo, const sre_nfa_count_req_t *d_creq, hipStream_t stream);
+int sre_pwave_fits(const void *h_wave);
 /* ctx_bytes: size of one stream context (copied into LDS for the call when it fits) */
 hipError_t sre_launch_pike_exec(const void *blob, size_t blob_bytes, const sre_dev_req_t *d_reqs,
     uint32_t nreqs, size_t ctx_bytes, hipStream_t stream);
