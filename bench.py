@@ -217,6 +217,9 @@ def workload_spec(name, S, nbytes, rank=0, world=1):
             # 64-byte round of every lane leaves the fast path (find-all count of \bfoo\b over "foo foo foo ..")
             pats, mode, body, tail = [rb"\bfoo\b"], S.HIP_PIKE_COUNT, b"foo ", b"foo "
             text = "scanner floor: /\\bfoo\\b/ find-all count over 'foo ' repeated (a look-ahead match every 4 bytes)"
+        elif name == "nfala":
+            pats, tail = [NFA_PAT + b"$"], b" abaabaabab@"
+            text = "declined by the step automaton, with a look-ahead assertion: /(?:a|b)*a(?:a|b){7}@$/ Pike first-match, NFA tier"
         elif name == "nfa60":
             pats, tail = [NFA60_PAT], NFA60_TAIL
             text = "declined by the step automaton, 60 list-able threads: /(?:a|b)*a(?:a|b){27}@/ Pike first-match, NFA tier"
@@ -268,6 +271,8 @@ def workload_spec(name, S, nbytes, rank=0, world=1):
                 assert r[:2] == [0, 1], r
             elif name == "nfa":
                 assert r[:4] == [0, 1, n - 12, n - 1], (r, n)
+            elif name == "nfala":
+                assert r[:4] == [0, 1, n - 11, n], (r, n)                    # the match ends at the end of input ($)
             elif name in ("nfa60", "nfa57w"):
                 assert r[:4] == [0, 1, n - (len(t) - 1), n - 1], (r, n)      # from behind the tail's first blank to its '@'
             elif name == "nfa37":
@@ -442,7 +447,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true",
                     help="N=1: do not measure the other configurations beside the headline (config.variants)")
-    ap.add_argument("--config", default="cfg2", choices=["cfg1", "cfg2", "cfg2m", "cfg3", "cfg4", "nfa", "nfa37", "nfa60", "nfa57w", "count_nfa", "dense", "densef", "densela", "floor"],
+    ap.add_argument("--config", default="cfg2", choices=["cfg1", "cfg2", "cfg2m", "cfg3", "cfg4", "nfa", "nfala", "nfa37", "nfa60", "nfa57w", "count_nfa", "dense", "densef", "densela", "floor"],
                     help="N=1 headline workload: cfg2 = BASELINE configs[1] (default); cfg2m = same with a "
                          "matching tail (captures span the whole stream); cfg3 = configs[2] multi-regex "
                          "find-all count; cfg4 = configs[3] URI, 4 groups; cfg1 = configs[0]'s pattern, "
@@ -555,7 +560,7 @@ def main():
             # dominant kernel alone beside it
             variants = {}
             sweep = {"size_1.0GiB": GIB, "size_2.5GiB": 5 * GIB // 2, "size_3.3GiB": 33 * GIB // 10, "size_6.0GiB": 6 * GIB}
-            for name in ("cfg2m", "cfg3", "cfg4", "nfa", "nfa37", "nfa60", "nfa57w", "count_nfa", "dense", "densef", "densela", "floor",
+            for name in ("cfg2m", "cfg3", "cfg4", "nfa", "nfala", "nfa37", "nfa60", "nfa57w", "count_nfa", "dense", "densef", "densela", "floor",
                          "many") + tuple(sweep):
                 try:
                     # size_*: the headline workload at other stream lengths (the segment geometry follows the total)

@@ -158,6 +158,7 @@ scanner_release(void *data)
     if (sc->ntab.kind) (void) hipFree(const_cast<uint8_t *>(sc->ntab.kind));
     if (sc->satab.accept) (void) hipFree(const_cast<uint64_t *>(sc->satab.accept));
     if (sc->satab.lut) (void) hipFree(const_cast<uint64_t *>(sc->satab.lut));
+    if (sc->satab.expand) (void) hipFree(const_cast<uint64_t *>(sc->satab.expand));
     sre_nfa_free(sc->nfa);
     sre_scan_tables_release(sc->tab);
     sre_dfa_free(sc->dfa);
@@ -206,6 +207,20 @@ nfa_upload(sre_hip_scanner_t *sc)
             SRE_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_lut), a->lut.size() * sizeof(uint64_t)));
             t.lut = d_lut;
             SRE_HIP_TRY(hipMemcpy(d_lut, a->lut.data(), a->lut.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+        }
+        if (a->nassert) {
+            /* the expansion table, compacted to the assertion bits (bits 0 .. of the mask) */
+            const size_t          per = (size_t) 1 << a->nassert;
+            std::vector<uint64_t> ex(16 * per);
+            for (size_t ctx = 0; ctx < 16; ctx++) {
+                for (size_t v = 0; v < per; v++) ex[ctx * per + v] = a->expand[ctx * 256 + v];
+            }
+            uint64_t *d_ex = NULL;
+            SRE_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_ex), ex.size() * sizeof(uint64_t)));
+            t.expand = d_ex;
+            SRE_HIP_TRY(hipMemcpy(d_ex, ex.data(), ex.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+            t.kind = sc->ntab.kind;
+            t.nassert = a->nassert;
         }
         t.w64 = a->w64;
         t.carry = a->carry;

@@ -29,6 +29,10 @@ typedef struct {
     uint64_t seed, any_bits, match_bits, msrc, valid, self, shift_src;
     const uint64_t *accept;         /* [256]        device */
     const uint64_t *lut;            /* [nlut][256]  device (NULL when nlut == 0) */
+    /* look-ahead assertions: bits 0 .. nassert - 1 of the mask (always masked, with MATCH bits) */
+    uint32_t nassert, pad2;
+    const uint64_t *expand;         /* [16][1 << nassert]  device */
+    const uint8_t  *kind;           /* [256]               device (sre_nfa.h SRE_NFA_KIND_*) */
 } sre_nfa_sa_tables_t;
 
 /* what one lane learnt about its segment */

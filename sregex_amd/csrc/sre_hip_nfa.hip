@@ -386,8 +386,8 @@ sre_k_nfa(sre_nfa_tables_t T, sre_scan_geom_t G, sre_nfa_summary_t *__restrict__
  * Both modes in one kernel: clean positions are sampled every 16 bytes, which is noise.
  * Summaries, beliefs and the chain check are those of sre_k_nfa.
  */
-template <bool W64, bool CARRY, bool MASKED, bool EVACC, int NLUT>
-__global__ __launch_bounds__(SRE_SCAN_BLOCK, (W64 ? 5 : 6)) void
+template <bool W64, bool CARRY, bool MASKED, bool EVACC, int NLUT, bool LA>
+__global__ __launch_bounds__(SRE_SCAN_BLOCK, (W64 || LA ? 5 : 6)) void
 sre_k_nfa_sa(sre_nfa_sa_tables_t T, sre_scan_geom_t G, sre_nfa_summary_t *__restrict__ sum,
              const int64_t *__restrict__ lo, const uint64_t *__restrict__ belief,
              const uint8_t *__restrict__ bvalid)
@@ -396,24 +396,40 @@ sre_k_nfa_sa(sre_nfa_sa_tables_t T, sre_scan_geom_t G, sre_nfa_summary_t *__rest
     constexpr int      TILE = SRE_SCAN_ROUND;
     constexpr int      WARM = SRE_SCAN_LINE;
     constexpr uint32_t ROWB = SRE_TILE2_ROWB;
-    constexpr int      GRP = W64 ? 4 : 8;       /* accept reads in flight ahead of the chain */
+    constexpr int      GRP = LA ? (W64 ? 2 : 4) : (W64 ? 4 : 8);    /* accept reads in flight ahead of the chain */
     constexpr uint32_t ESZ = (uint32_t) sizeof(E);
-    __shared__ __attribute__((aligned(16))) E acc_w[256];
+    /* LA: an accept entry also says what the byte means to the look-ahead assertions (kk, as in sre_k_nfa) */
+    constexpr uint32_t ASZ = LA ? 2 * ESZ : ESZ;
+    static_assert(!LA || (MASKED && !EVACC), "look-ahead forms are masked and keep MATCH bits");
+    __shared__ __attribute__((aligned(16))) uint8_t acc_raw[256 * ASZ];
     __shared__ __attribute__((aligned(16))) E lut_w[(NLUT ? NLUT : 1) * 256];
     extern __shared__ __attribute__((aligned(16))) uint8_t tile[];
     RowDesc *rows = reinterpret_cast<RowDesc *>(tile + SRE_SCAN_BLOCK * ROWB);
+    /* LA: the expansion table [16][1 << nassert] behind the row descriptors */
+    E       *exp_w = reinterpret_cast<E *>(tile + SRE_SCAN_BLOCK * ROWB + SRE_SCAN_BLOCK * 16);
+    const uint32_t XCOL = LA ? (ESZ << T.nassert) : 0u, XROW = 4u * XCOL;
 
     const uint32_t tid = threadIdx.x;
     auto lo32 = [](uint64_t v) { return (uint32_t) v; };
     auto hi32 = [](uint64_t v) { return (uint32_t) (v >> 32); };
     auto entry = [&](uint64_t v) -> E { return (E) v; };
     /* sticky MATCH bits accept every byte and list themselves in the host tables already */
-    acc_w[tid] = entry(T.accept[tid]);
+    *reinterpret_cast<E *>(acc_raw + tid * ASZ) = entry(T.accept[tid]);
+    if (LA) {
+        const uint32_t kd = T.kind[tid];
+        *reinterpret_cast<uint32_t *>(acc_raw + tid * ASZ + ESZ) =
+            ((kd & 3u) * XCOL) | ((kd & 4u) ? 0x8000u : 0u) | (((kd & 3u) * XROW) << 16);
+        for (uint32_t i = tid; i < (16u << T.nassert); i += SRE_SCAN_BLOCK) exp_w[i] = entry(T.expand[i]);
+    }
 #pragma unroll
     for (int k = 0; k < NLUT; k++) lut_w[k * 256 + tid] = entry(T.lut[k * 256 + tid] | (k == 0 ? T.seed : 0));
-    const uint32_t acc_base = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) E *) acc_w;
+    const uint32_t acc_base = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) uint8_t *) acc_raw;
     const uint32_t lut_base = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) E *) lut_w;
+    const uint32_t exp_base = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) E *) exp_w;
     const uint32_t sh = W64 ? 3u : 2u;          /* log2 of a table entry, in a register for SDWA */
+    const uint32_t sha = LA ? sh + 1u : sh;     /* ... of an accept entry */
+    const uint32_t amask = LA ? ((1u << T.nassert) - 1u) : 0u;
+    uint32_t       prev_off = 3u * XROW;        /* LA: the expansion-table row of the byte in front (3: stream start) */
     const uint32_t self_lo = lo32(T.self), self_hi = hi32(T.self), src_lo = lo32(T.shift_src), src_hi = hi32(T.shift_src);
     const uint32_t seed_lo = NLUT ? 0u : lo32(T.seed), seed_hi = NLUT ? 0u : hi32(T.seed);
     const uint32_t nany_lo = ~lo32(T.any_bits), nany_hi = ~hi32(T.any_bits);
@@ -447,11 +463,14 @@ sre_k_nfa_sa(sre_nfa_sa_tables_t T, sre_scan_geom_t G, sre_nfa_summary_t *__rest
     const uint32_t sfl = (active && G.sflags != nullptr) ? G.sflags[sidx] : 0u;
     const uint32_t v_init = G.sflags != nullptr ? SRE_SFLAG_INIT(sfl) : G.init_variant;
     const uint32_t v_snap = G.sflags != nullptr ? SRE_SFLAG_SNAP(sfl) : G.init_variant;
+    const bool     no_eof = G.sflags != nullptr ? (sfl & SRE_SFLAG_NO_EOF) != 0 : (G.flags & SRE_GEOM_NO_EOF) != 0;
+    bool           last_seg = false;
     if (active) {
         data = geom_ptr(G, sidx);
         n = (int64_t) geom_len(G, sidx);
         seg_a = (int64_t) k * G.seg_bytes;
         seg_b = seg_a + G.seg_bytes;
+        last_seg = (k + 1 == geom_first(G, sidx + 1) - geom_first(G, sidx));
         if (seg_b > n) seg_b = n;
         uint64_t S;
         if (k == 0) {
@@ -470,6 +489,11 @@ sre_k_nfa_sa(sre_nfa_sa_tables_t T, sre_scan_geom_t G, sre_nfa_summary_t *__rest
         mine.addr = (uint64_t) reinterpret_cast<uintptr_t>(data) + (uint64_t) (seg_a - WARM);
         mine.lo = warm ? (seg_a >= WARM ? 0 : (int32_t) (WARM - seg_a)) : WARM;
         mine.hi16 = (int32_t) (WARM + (seg_b - seg_a)) - 16;
+        if (LA) {
+            /* the kind of the byte in front of the first byte this lane steps over */
+            const int64_t first_pos = warm ? (seg_a >= WARM ? seg_a - WARM : 0) : seg_a;
+            if (first_pos > 0) prev_off = (T.kind[data[first_pos - 1]] & 3u) * XROW;
+        }
     }
     rows[tid] = mine;
 
@@ -477,13 +501,29 @@ sre_k_nfa_sa(sre_nfa_sa_tables_t T, sre_scan_geom_t G, sre_nfa_summary_t *__rest
     const uint32_t snap_lo = lo32(snap), snap_hi = hi32(snap);
     /* how the reference arrives at a clean position: see sre_k_nfa (no look-ahead assertions here, so
      * the byte in front of a clean position never is a leading byte) */
-    auto clean_kind = [&](bool before_is_snap, bool prev_clean) -> int {
-        if (!before_is_snap) return 0;
+    auto clean_kind = [&](bool before_is_snap, bool prev_clean, bool leading) -> int {
+        if (leading || !before_is_snap) return 0;       /* (leading: only with look-ahead assertions, see sre_k_nfa) */
         return prev_clean ? 1 : -1;
     };
     uint32_t evv = 0;           /* EVACC: threads that reached MATCH in this round */
     /* one step; a = the byte's accept entry; returns whether only the ".*?" thread consumed the byte */
-    auto step = [&](uint32_t a_lo, uint32_t a_hi) -> bool {
+    /* LA: the assertions of the list that hold between the byte in front and this one list their
+     * continuations (one lookup by the assertion bits, bits 0 .. of the mask) */
+    auto expand = [&](uint32_t col_off) {
+        const uint32_t at = exp_base + prev_off + col_off + ((s_lo & amask) << sh);
+        if constexpr (W64) {
+            const uint64_t v = *(const __attribute__((address_space(3))) uint64_t *) (uintptr_t) at;
+            s_lo |= (uint32_t) v;
+            s_hi |= (uint32_t) (v >> 32);
+        } else {
+            s_lo |= *(const __attribute__((address_space(3))) uint32_t *) (uintptr_t) at;
+        }
+    };
+    auto step = [&](uint32_t a_lo, uint32_t a_hi, uint32_t kk) -> bool {
+        if (LA) {
+            expand(kk & 0x7fffu);
+            prev_off = kk >> 16;
+        }
         const uint32_t t_lo = s_lo & a_lo, t_hi = W64 ? (s_hi & a_hi) : 0u;
         uint32_t       e_lo = seed_lo, e_hi = seed_hi;
         if (NLUT > 0) {
@@ -528,13 +568,27 @@ sre_k_nfa_sa(sre_nfa_sa_tables_t T, sre_scan_geom_t G, sre_nfa_summary_t *__rest
         return (((b_lo ^ snap_lo) & val_lo) | (W64 ? ((b_hi ^ snap_hi) & val_hi) : 0u)) == 0;
     };
     auto state64 = [&]() -> uint64_t { return ((uint64_t) (s_hi & val_hi) << 32) | (s_lo & val_lo); };
-    auto accept_at = [&](uint32_t byte_addr, uint32_t &a_lo, uint32_t &a_hi) {
+    auto accept_at = [&](uint32_t byte_addr, uint32_t &a_lo, uint32_t &a_hi, uint32_t &kk) {
+        kk = 0;
         if constexpr (W64) {
-            const uint64_t v = *(const __attribute__((address_space(3))) uint64_t *) (uintptr_t) (acc_base + byte_addr);
-            a_lo = (uint32_t) v;
-            a_hi = (uint32_t) (v >> 32);
+            if constexpr (LA) {
+                const sre_u32x4 v = *(const __attribute__((address_space(3))) sre_u32x4 *) (uintptr_t) (acc_base + byte_addr);
+                a_lo = v.x;
+                a_hi = v.y;
+                kk = v.z;
+            } else {
+                const uint64_t v = *(const __attribute__((address_space(3))) uint64_t *) (uintptr_t) (acc_base + byte_addr);
+                a_lo = (uint32_t) v;
+                a_hi = (uint32_t) (v >> 32);
+            }
         } else {
-            a_lo = *(const __attribute__((address_space(3))) uint32_t *) (uintptr_t) (acc_base + byte_addr);
+            if constexpr (LA) {
+                const uint64_t v = *(const __attribute__((address_space(3))) uint64_t *) (uintptr_t) (acc_base + byte_addr);
+                a_lo = (uint32_t) v;
+                kk = (uint32_t) (v >> 32);
+            } else {
+                a_lo = *(const __attribute__((address_space(3))) uint32_t *) (uintptr_t) (acc_base + byte_addr);
+            }
             a_hi = 0;
         }
     };
@@ -560,12 +614,12 @@ sre_k_nfa_sa(sre_nfa_sa_tables_t T, sre_scan_geom_t G, sre_nfa_summary_t *__rest
         const int64_t base = seg_a - WARM + (int64_t) r * TILE;
         if (base >= seg_b || base < 0) continue;
 
-        const uint32_t s0_lo = s_lo, s0_hi = s_hi;
+        const uint32_t s0_lo = s_lo, s0_hi = s_hi, prev_off0 = prev_off;
         if (base + TILE <= seg_b) {
             /* the common round: 64 steps, then one look at the event */
             const uint8_t *src = tile + tid * ROWB;
             uint4          piece = make_uint4(0, 0, 0, 0);
-            uint32_t       av_lo[2][GRP], av_hi[2][GRP];
+            uint32_t       av_lo[2][GRP], av_hi[2][GRP], av_kk[2][GRP];
             int32_t        clean_at = -1, clean_how = 0;
             bool           c14 = false;
             auto load_group = [&](int q) {
@@ -575,9 +629,9 @@ sre_k_nfa_sa(sre_nfa_sa_tables_t T, sre_scan_geom_t G, sre_nfa_summary_t *__rest
                     if ((j & 15) == 0) piece = *reinterpret_cast<const uint4 *>(src + j);
                     const uint32_t word = ((j >> 2) & 3) == 0 ? piece.x : ((j >> 2) & 3) == 1 ? piece.y
                                         : ((j >> 2) & 3) == 2 ? piece.z : piece.w;
-                    const uint32_t a = (j & 3) == 0 ? byte_shl<0>(word, sh) : (j & 3) == 1 ? byte_shl<1>(word, sh)
-                                     : (j & 3) == 2 ? byte_shl<2>(word, sh) : byte_shl<3>(word, sh);
-                    accept_at(a, av_lo[q & 1][i], av_hi[q & 1][i]);
+                    const uint32_t a = (j & 3) == 0 ? byte_shl<0>(word, sha) : (j & 3) == 1 ? byte_shl<1>(word, sha)
+                                     : (j & 3) == 2 ? byte_shl<2>(word, sha) : byte_shl<3>(word, sha);
+                    accept_at(a, av_lo[q & 1][i], av_hi[q & 1][i], av_kk[q & 1][i]);
                 }
             };
             load_group(0);
@@ -589,11 +643,11 @@ sre_k_nfa_sa(sre_nfa_sa_tables_t T, sre_scan_geom_t G, sre_nfa_summary_t *__rest
                 for (int i = 0; i < GRP; i++) {
                     const int      j = q * GRP + i;
                     const uint32_t b_lo = s_lo, b_hi = s_hi;
-                    const bool     cl = step(av_lo[q & 1][i], av_hi[q & 1][i]);
+                    const bool     cl = step(av_lo[q & 1][i], av_hi[q & 1][i], av_kk[q & 1][i]);
                     if ((j & 15) == 14) c14 = cl;
                     /* clean positions are sampled at the end of every 16-byte group */
                     if ((j & 15) == 15 && cl) {
-                        const int how = clean_kind(is_snap(b_lo, b_hi), c14);
+                        const int how = clean_kind(is_snap(b_lo, b_hi), c14, LA && (av_kk[q & 1][i] & 0x8000u) != 0);
                         if (how >= 0) {
                             clean_at = j + 1;
                             clean_how = how;
@@ -619,6 +673,7 @@ sre_k_nfa_sa(sre_nfa_sa_tables_t T, sre_scan_geom_t G, sre_nfa_summary_t *__rest
             }
             s_lo = s0_lo;
             s_hi = s0_hi;
+            prev_off = prev_off0;
             evv = 0;
         }
         /* byte by byte: a round with an event, or the ragged end of the stream */
@@ -631,9 +686,9 @@ sre_k_nfa_sa(sre_nfa_sa_tables_t T, sre_scan_geom_t G, sre_nfa_summary_t *__rest
                  * of the stream is not staged (sre_hip_tile.h) */
                 const uint32_t b = data[p];
                 const uint32_t b_lo = s_lo, b_hi = s_hi;
-                uint32_t       a_lo, a_hi;
-                accept_at(b << sh, a_lo, a_hi);
-                const bool cl = step(a_lo, a_hi);
+                uint32_t       a_lo, a_hi, kk;
+                accept_at(b << sha, a_lo, a_hi, kk);
+                const bool cl = step(a_lo, a_hi, kk);
                 if (event()) {
                     if (!warm_round) {
                         first_ev = p;
@@ -643,7 +698,7 @@ sre_k_nfa_sa(sre_nfa_sa_tables_t T, sre_scan_geom_t G, sre_nfa_summary_t *__rest
                     drop_event();
                     prev_clean = false;
                 } else if (!warm_round && cl) {
-                    const int how = clean_kind(is_snap(b_lo, b_hi), prev_clean);
+                    const int how = clean_kind(is_snap(b_lo, b_hi), prev_clean, LA && (kk & 0x8000u) != 0);
                     if (how >= 0) {
                         last_clean = p + 1;
                         clean_mode = how;
@@ -658,6 +713,12 @@ sre_k_nfa_sa(sre_nfa_sa_tables_t T, sre_scan_geom_t G, sre_nfa_summary_t *__rest
     }
 
     if (!active) return;
+    if (LA && last_seg && !finished && !no_eof) {
+        /* the extra iteration at end of input (sre_vm_pike.c:235): assertions that hold in front of
+         * the end list their continuations; a MATCH among them is an event */
+        expand(3u * XCOL);
+        if (event()) first_ev = n;
+    }
     sre_nfa_summary_t out;
     out.s_in = s_in;
     out.s_out = state64();
@@ -898,15 +959,15 @@ sre_launch_nfa_verify(int mode, sre_scan_geom_t geom, const sre_nfa_summary_t *d
 
 namespace {
 
-template <bool W64, bool CARRY, bool MASKED, bool EVACC>
+template <bool W64, bool CARRY, bool MASKED, bool EVACC, bool LA>
 nfa_kernel_t
 nfa_sa_kernel_nlut(uint32_t nlut)
 {
     switch (nlut) {
-    case 0: return reinterpret_cast<nfa_kernel_t>(sre_k_nfa_sa<W64, CARRY, MASKED, EVACC, 0>);
-    case 1: return reinterpret_cast<nfa_kernel_t>(sre_k_nfa_sa<W64, CARRY, MASKED, EVACC, 1>);
-    case 2: return reinterpret_cast<nfa_kernel_t>(sre_k_nfa_sa<W64, CARRY, MASKED, EVACC, 2>);
-    case 3: return reinterpret_cast<nfa_kernel_t>(sre_k_nfa_sa<W64, CARRY, MASKED, EVACC, 3>);
+    case 0: return reinterpret_cast<nfa_kernel_t>(sre_k_nfa_sa<W64, CARRY, MASKED, EVACC, 0, LA>);
+    case 1: return reinterpret_cast<nfa_kernel_t>(sre_k_nfa_sa<W64, CARRY, MASKED, EVACC, 1, LA>);
+    case 2: return reinterpret_cast<nfa_kernel_t>(sre_k_nfa_sa<W64, CARRY, MASKED, EVACC, 2, LA>);
+    case 3: return reinterpret_cast<nfa_kernel_t>(sre_k_nfa_sa<W64, CARRY, MASKED, EVACC, 3, LA>);
     default: return nullptr;
     }
 }
@@ -915,8 +976,9 @@ template <bool W64, bool CARRY>
 nfa_kernel_t
 nfa_sa_kernel_opts(const sre_nfa_sa_tables_t &t)
 {
-    if (t.masked) return t.evacc ? nfa_sa_kernel_nlut<W64, CARRY, true, true>(t.nlut) : nfa_sa_kernel_nlut<W64, CARRY, true, false>(t.nlut);
-    return t.evacc ? nfa_sa_kernel_nlut<W64, CARRY, false, true>(t.nlut) : nfa_sa_kernel_nlut<W64, CARRY, false, false>(t.nlut);
+    if (t.nassert) return (t.masked && !t.evacc) ? nfa_sa_kernel_nlut<W64, CARRY, true, false, true>(t.nlut) : nullptr;
+    if (t.masked) return t.evacc ? nfa_sa_kernel_nlut<W64, CARRY, true, true, false>(t.nlut) : nfa_sa_kernel_nlut<W64, CARRY, true, false, false>(t.nlut);
+    return t.evacc ? nfa_sa_kernel_nlut<W64, CARRY, false, true, false>(t.nlut) : nfa_sa_kernel_nlut<W64, CARRY, false, false, false>(t.nlut);
 }
 
 /* the address of a kernel is all that is needed of it here (occupancy, attributes); the launch
@@ -932,9 +994,11 @@ nfa_sa_kernel(const sre_nfa_sa_tables_t &t)
 }
 
 size_t
-nfa_sa_dynamic_lds(void)
+nfa_sa_dynamic_lds(const sre_nfa_sa_tables_t &t)
 {
-    return (size_t) SRE_SCAN_BLOCK * SRE_TILE2_ROWB + (size_t) SRE_SCAN_BLOCK * 16;
+    /* tile, row descriptors, and with look-ahead assertions the expansion table [16][1 << nassert] */
+    return (size_t) SRE_SCAN_BLOCK * SRE_TILE2_ROWB + (size_t) SRE_SCAN_BLOCK * 16
+           + (t.nassert ? ((size_t) 16 << t.nassert) * (t.w64 ? 8 : 4) : 0);
 }
 
 }  // namespace
@@ -942,8 +1006,8 @@ nfa_sa_dynamic_lds(void)
 extern "C" const char *
 sre_nfa_sa_kernel_name(const sre_nfa_sa_tables_t *t, char *buf, size_t n)
 {
-    snprintf(buf, n, "sre_k_nfa_sa<%s, %s, %s, %s, %u>", t->w64 ? "true" : "false", t->carry ? "true" : "false",
-             t->masked ? "true" : "false", t->evacc ? "true" : "false", t->nlut);
+    snprintf(buf, n, "sre_k_nfa_sa<%s, %s, %s, %s, %u, %s>", t->w64 ? "true" : "false", t->carry ? "true" : "false",
+             t->masked ? "true" : "false", t->evacc ? "true" : "false", t->nlut, t->nassert ? "true" : "false");
     return buf;
 }
 
@@ -953,7 +1017,7 @@ sre_nfa_sa_blocks_per_cu(const sre_nfa_sa_tables_t *t)
     int         n = 0;
     const void *k = nfa_sa_kernel(*t);
     if (k == nullptr) return 1;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k, SRE_SCAN_BLOCK, nfa_sa_dynamic_lds());
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, k, SRE_SCAN_BLOCK, nfa_sa_dynamic_lds(*t));
     if (e != hipSuccess || n < 1) n = 1;
     if (n > 8) n = 8;
     return n;
@@ -967,6 +1031,10 @@ sre_launch_nfa_sa_scan(sre_nfa_sa_tables_t tab, sre_scan_geom_t geom, sre_nfa_su
     const uint32_t grid = (uint32_t) ((geom.nsegs + SRE_SCAN_BLOCK - 1) / SRE_SCAN_BLOCK);
     const void    *kern = nfa_sa_kernel(tab);
     if (kern == nullptr) return hipErrorInvalidValue;
+    if (nfa_sa_dynamic_lds(tab) > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) nfa_sa_dynamic_lds(tab));
+        if (e != hipSuccess) return e;
+    }
     void *args[] = {&tab, &geom, &d_sum, &d_lo, &d_belief, &d_bvalid};
-    return hipLaunchKernel(kern, dim3(grid), dim3(SRE_SCAN_BLOCK), args, nfa_sa_dynamic_lds(), stream);
+    return hipLaunchKernel(kern, dim3(grid), dim3(SRE_SCAN_BLOCK), args, nfa_sa_dynamic_lds(tab), stream);
 }

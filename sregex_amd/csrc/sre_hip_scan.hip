@@ -196,13 +196,18 @@ stream_of(const sre_scan_geom_t &G, uint64_t g)
  * after an empty match it is the byte the caller skipped (:179-196).  (Without
  * ^ in the program the three initial lists coincide.) */
 __device__ inline uint32_t
-restart_variant(const sre_scan_tables_t &T, const uint8_t *data, int64_t sp)
+restart_variant_of(const sre_scan_tables_t &T, uint32_t c)
 {
-    const uint32_t c = data[sp - 1];
     if (c == '\n') return 1u;
     /* \b / \B at the search start: the context's seen_word (:472-473, 594), ASCII [0-9A-Za-z_] */
     if (T.word_restart && ((c - '0') < 10u || ((c | 32u) - 'a') < 26u || c == '_')) return 3u;
     return 2u;
+}
+
+__device__ inline uint32_t
+restart_variant(const sre_scan_tables_t &T, const uint8_t *data, int64_t sp)
+{
+    return restart_variant_of(T, data[sp - 1]);
 }
 
 enum : uint32_t {
@@ -268,6 +273,25 @@ __device__ void slow_run(Walk &w, int64_t p, int64_t p_to, bool warm, uint32_t w
 {
     const sre_scan_tables_t &T = *w.T;
     const uint32_t           nsym = T.ncls + 1;
+    /* the exact path read one byte per step from global memory — a dependent L2 round trip, 0.4 us
+     * per byte-step, which is what a stream of look-ahead matches ran at (bench.py `floor`).  The
+     * bytes now come eight at a time through a window in registers (round 3). */
+    int64_t  win_at = -1;       /* aligned offset of the window, -1: empty */
+    uint64_t win_bytes = 0;
+    auto byte_at = [&](int64_t q) -> uint32_t {
+        const int64_t a = q & ~(int64_t) 7;
+        if (a != win_at) {
+            win_at = a;
+            if (a + 8 <= w.n && ((reinterpret_cast<uintptr_t>(w.data) + (uint64_t) a) & 7u) == 0) {
+                win_bytes = *reinterpret_cast<const uint64_t *>(w.data + a);
+            } else {
+                /* the ragged end of the stream, or a stream that does not start on an 8-byte boundary */
+                win_bytes = 0;
+                for (int64_t k = 0; k < 8 && a + k < w.n; k++) win_bytes |= (uint64_t) w.data[a + k] << (8 * k);
+            }
+        }
+        return (uint32_t) (win_bytes >> (8 * (q & 7))) & 0xffu;
+    };
 
     if (MODE == SRE_HIP_PIKE_COUNT && w.f(F_SKIP_NEXT)) {
         w.fl &= ~F_SKIP_NEXT;
@@ -293,7 +317,7 @@ __device__ void slow_run(Walk &w, int64_t p, int64_t p_to, bool warm, uint32_t w
             w.fl |= F_FINISHED;
             return;
         }
-        const uint32_t         sym = p < w.n ? T.cls[w.data[p]] : T.ncls;
+        const uint32_t         sym = p < w.n ? T.cls[byte_at(p)] : T.ncls;
         /* all the exact step needs of a transition: where it goes and what it reports */
         const uint32_t tr2 = w.tr2[w.st * nsym + sym];
         struct { uint32_t next; uint8_t kind; } tr = {tr2 & 0xffu, (uint8_t) (tr2 >> 8)};
@@ -372,7 +396,7 @@ __device__ void slow_run(Walk &w, int64_t p, int64_t p_to, bool warm, uint32_t w
             } else {
                 w.cur_sp = e;
             }
-            w.st = T.init[restart_variant(T, w.data, w.cur_sp)];
+            w.st = T.init[restart_variant_of(T, byte_at(w.cur_sp - 1))];
             p = w.cur_sp;
             /* an empty match that ended with a consumed byte can put the skipped
              * byte just outside this span */

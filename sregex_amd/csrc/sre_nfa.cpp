@@ -323,7 +323,7 @@ sre_nfa_build2(const sre_program_t *prog, unsigned sa_options, const char **why)
             n->follow[(size_t) k * 256 + v] = m;
         }
     }
-    if (n->nassert == 0 && !(sa_options & SRE_NFA_SA_OFF)) build_shift_and(n, fbit, sa_options);
+    if (!(sa_options & SRE_NFA_SA_OFF)) build_shift_and(n, fbit, sa_options);
     return n;
 }
 
@@ -337,6 +337,7 @@ struct SaNode {
     bool     to_match;      /* its closure reaches MATCH */
     bool     is_match;      /* a sticky MATCH bit (accepts every byte, lists itself) */
     bool     is_any;        /* the explicit ".*?" thread (or its newline twin) */
+    bool     is_assert;     /* a look-ahead assertion: consumes nothing, waits for the expansion */
     uint64_t acc[4];        /* bytes it consumes */
     int      next, prev;    /* the node one bit above / below (a link the shift serves) */
     int      gbit;          /* a bit of the plain form it stands for (-1: a MATCH node) */
@@ -365,7 +366,7 @@ sa_cost(bool w64, bool carry, bool masked, bool evacc, uint32_t nlut)
  * of a word.  The order is searched for the fewest bytes that hold a source. */
 SaLayout
 sa_place(const std::vector<std::vector<int>> &chains, const std::vector<uint8_t> &is_src, size_t nnodes,
-         bool masked, bool force_w64, bool force_carry)
+         bool masked, bool force_w64, bool force_carry, int assert_chain)
 {
     SaLayout best;
     best.ok = false;
@@ -390,6 +391,16 @@ sa_place(const std::vector<std::vector<int>> &chains, const std::vector<uint8_t>
             const int swaps = attempt < 200 ? 1 + (int) (rnd() % 3) : (int) nc;
             for (int k = 0; k < swaps && nc > 1; k++) std::swap(order[rnd() % nc], order[rnd() % nc]);
         }
+        if (assert_chain >= 0) {
+            /* the look-ahead assertions: bits 0 .. of the mask (the kernel indexes the expansion table
+             * with them: S & mask) */
+            for (size_t k = 0; k < nc; k++) {
+                if ((int) order[k] == assert_chain) {
+                    std::swap(order[0], order[k]);
+                    break;
+                }
+            }
+        }
         for (int mode = 0; mode < 3; mode++) {
             /* mode 0: 32 bits; 1: two halves that shift alone; 2: 64 bits with a carry */
             if (mode == 0 && force_w64) continue;
@@ -400,6 +411,8 @@ sa_place(const std::vector<std::vector<int>> &chains, const std::vector<uint8_t>
             for (size_t ci = 0; ci < nc && fits; ci++) {
                 const auto    &c = chains[order[ci]];
                 const uint32_t len = (uint32_t) c.size();
+                /* the look-ahead assertions share one byte of the mask */
+                if ((int) order[ci] == assert_chain && (at & 7u) + len > 8) at = (at + 7u) & ~7u;
                 if (mode == 1 && at < 32 && at + len > 32) at = 32;     /* a chain does not straddle the halves */
                 const uint32_t limit = mode == 0 ? 32u : 64u;
                 if (at + len > limit) {
@@ -408,7 +421,7 @@ sa_place(const std::vector<std::vector<int>> &chains, const std::vector<uint8_t>
                 }
                 for (uint32_t j = 0; j < len; j++) pos[c[j]] = (int) (at + j);
                 at += len;
-                if (!masked) {
+                if (!masked && (int) order[ci] != assert_chain) {
                     /* the hole: not needed when the chain ends at the top of a word that drops the shifted-out bit */
                     const bool at_top = at == limit || (mode == 1 && at == 32);
                     if (!at_top) at++;
@@ -474,8 +487,14 @@ build_shift_and(sre_nfa_t *n, const std::vector<uint64_t> &fbit, unsigned option
     for (uint32_t i = 0; i < nb; i++) {
         if (n->bit_pc[i] != 0xffffffffu && !((drop >> i) & 1)) live |= 1ull << i;
     }
+    /* look-ahead assertions: the bits of the plain form's assertion byte */
+    uint64_t assert_bits = 0;
+    for (uint32_t j = 0; j < n->nassert; j++) assert_bits |= 1ull << (8 * n->assert_slice + j);
+    if (n->nassert) options |= SRE_NFA_SA_FORCE_MASKED | SRE_NFA_SA_NO_EVACC;
     uint64_t roots[4] = {n->init[0], n->init[1], n->init[2], implicit_any ? fbit[any_bit] : 0};
-    bool     changed = !(options & SRE_NFA_SA_NO_MERGE);
+    /* (expansions list threads too: a merge would have to compare those memberships as well — programs
+     * with look-ahead assertions keep their threads apart) */
+    bool     changed = !(options & SRE_NFA_SA_NO_MERGE) && n->nassert == 0;
     while (changed) {
         changed = false;
         for (uint32_t i = 0; i < nb && !changed; i++) {
@@ -514,6 +533,7 @@ build_shift_and(sre_nfa_t *n, const std::vector<uint64_t> &fbit, unsigned option
         x.gbit = (int) i;
         x.next = x.prev = -1;
         x.is_any = (n->any_bits >> i) & 1;
+        x.is_assert = (assert_bits >> i) & 1;
         x.to_match = (F[i] & n->match_bits) != 0;
         for (int q = 0; q < 4; q++) x.acc[q] = A[i * 4 + q];
         node_of[i] = (int) nodes.size();
@@ -572,6 +592,21 @@ build_shift_and(sre_nfa_t *n, const std::vector<uint64_t> &fbit, unsigned option
                     }
                 }
                 if (nd.size() > 64) continue;
+                /* an expansion that lists MATCH is an event: it needs a bit to list */
+                bool exp_match = false;
+                for (size_t q = 0; q < n->expand.size() && !exp_match; q++) exp_match = (n->expand[q] & n->match_bits) != 0;
+                if (exp_match && shared_match < 0) {
+                    if (nd.size() >= 64) continue;
+                    SaNode m;
+                    memset(&m, 0, sizeof(m));
+                    m.gbit = -1;
+                    m.next = m.prev = -1;
+                    m.is_match = true;
+                    m.self = true;
+                    for (int q = 0; q < 4; q++) m.acc[q] = ~0ull;
+                    shared_match = (int) nd.size();
+                    nd.push_back(m);
+                }
             }
             const size_t nn = nd.size();
             /* links: a thread with ONE successor first (it then needs no lookup at all) */
@@ -586,7 +621,7 @@ build_shift_and(sre_nfa_t *n, const std::vector<uint64_t> &fbit, unsigned option
                     if (nd[v].next >= 0 || nd[v].fol == 0) continue;
                     if (pass == 0 && popc(nd[v].fol) != 1) continue;
                     for (size_t w = 0; w < nn; w++) {
-                        if (!((nd[v].fol >> w) & 1) || nd[w].prev >= 0 || reaches((int) w, (int) v)) continue;
+                        if (!((nd[v].fol >> w) & 1) || nd[w].prev >= 0 || nd[w].is_assert || reaches((int) w, (int) v)) continue;
                         nd[v].next = (int) w;
                         nd[w].prev = (int) v;
                         break;
@@ -600,14 +635,24 @@ build_shift_and(sre_nfa_t *n, const std::vector<uint64_t> &fbit, unsigned option
                 is_src[v] = rest != 0;
             }
             std::vector<std::vector<int>> chains;
+            std::vector<int>              agroup;
             for (size_t v = 0; v < nn; v++) {
                 if (nd[v].prev >= 0) continue;
+                if (nd[v].is_assert) {
+                    agroup.push_back((int) v);      /* (never linked: one group, one byte of the mask) */
+                    continue;
+                }
                 std::vector<int> c;
                 for (int k = (int) v; k >= 0; k = nd[k].next) c.push_back(k);
                 chains.push_back(c);
             }
+            int assert_chain = -1;
+            if (!agroup.empty()) {
+                assert_chain = (int) chains.size();
+                chains.push_back(agroup);
+            }
             SaLayout L = sa_place(chains, is_src, nn, masked != 0, (options & SRE_NFA_SA_FORCE_W64) != 0,
-                                  (options & SRE_NFA_SA_FORCE_CARRY) != 0);
+                                  (options & SRE_NFA_SA_FORCE_CARRY) != 0, assert_chain);
             if (!L.ok) continue;
             const uint32_t cost = sa_cost(L.w64, L.carry, masked, evacc, L.nlut);
             if (bestsa && bestsa->cost <= cost) continue;
@@ -654,6 +699,28 @@ build_shift_and(sre_nfa_t *n, const std::vector<uint64_t> &fbit, unsigned option
                         m |= bits_of(rest);
                     }
                     sa->lut[(size_t) k * 256 + x] = m;
+                }
+            }
+            sa->nassert = n->nassert;
+            sa->assert_byte = 0;
+            if (n->nassert) {
+                sa->assert_byte = (uint32_t) L.pos[agroup[0]] >> 3;
+                sa->expand.assign(16 * 256, 0);
+                for (uint32_t ctx = 0; ctx < 16; ctx++) {
+                    std::vector<uint64_t> xsa(n->nassert, 0);
+                    for (uint32_t j = 0; j < n->nassert; j++) {
+                        const uint64_t g = n->expand[(size_t) ctx * 256 + (1u << j)];
+                        xsa[j] = bits_of(to_nodes(g & live));
+                        if ((g & n->match_bits) && shared_match >= 0) xsa[j] |= 1ull << L.pos[shared_match];
+                    }
+                    for (uint32_t x = 0; x < 256; x++) {
+                        uint64_t m = 0;
+                        for (uint32_t j = 0; j < n->nassert; j++) {
+                            const int apos = L.pos[node_of[8 * n->assert_slice + j]];
+                            if ((x >> (apos & 7)) & 1) m |= xsa[j];
+                        }
+                        sa->expand[(size_t) ctx * 256 + x] = m;
+                    }
                 }
             }
             sa->bit_of.assign(nb, -3);

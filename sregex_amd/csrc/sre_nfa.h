@@ -89,6 +89,13 @@ struct sre_nfa_sa_t {
     std::vector<uint64_t> lut;  /* [nlut][256] */
     std::vector<int>      bit_of;   /* bit of sre_nfa_s -> bit here; -1: implicit ".*?", -2: MATCH (evacc), >= 0 also for merged threads */
     uint32_t cost;              /* the builder's estimate: instructions per input byte */
+    /* look-ahead assertions ($ \z \b \B), as in the plain form: they wait in the list (bits that no byte
+     * accepts, all in ONE byte of the mask) and the byte AT the position decides them —
+     * S |= expand[prev kind * 4 + cur kind][that byte of S] in front of the step.  Such forms are always
+     * `masked` with MATCH bits (an expansion that lists MATCH is an event). */
+    uint32_t nassert;
+    uint32_t assert_byte;           /* byte of the mask that holds them */
+    std::vector<uint64_t> expand;   /* [16][256], indexed by the whole byte (other bits ignored) */
 };
 #define SRE_NFA_SA_MAX_LUT 3u
 /* build options (tests force every kernel variant) */

@@ -72,7 +72,7 @@ sa_step(const sre_nfa_sa_t *a, uint64_t S, unsigned byte, uint64_t *t_out)
     return r;
 }
 
-/* info[0..9] = has form, nbits, w64, carry, masked, evacc, nlut, cost, threads (valid bits), 0 */
+/* info[0..9] = has form, nbits, w64, carry, masked, evacc, nlut, cost, threads (valid bits), look-ahead assertions */
 void nfa_sim_sa_info(void *h, int32_t *info)
 {
     const sre_nfa_t *n = static_cast<sre_nfa_t *>(h);
@@ -82,6 +82,7 @@ void nfa_sim_sa_info(void *h, int32_t *info)
     info[0] = 1; info[1] = (int32_t) a->nbits; info[2] = (int32_t) a->w64; info[3] = (int32_t) a->carry;
     info[4] = (int32_t) a->masked; info[5] = (int32_t) a->evacc; info[6] = (int32_t) a->nlut; info[7] = (int32_t) a->cost;
     info[8] = __builtin_popcountll(a->valid);
+    info[9] = (int32_t) a->nassert;
 }
 
 /* Runs the plain form and the shift-and form side by side over the buffer.  out[0] / out[1] as
@@ -95,6 +96,7 @@ void nfa_sim_run_sa(void *h, const uint8_t *data, int64_t n, int variant, int64_
     if (!a) return;
     uint64_t S = a->init[variant], G = g->init[variant];
     int64_t  clean = 0, ev = -1, bad = -1;
+    uint32_t prev = SRE_NFA_KIND_EDGE;
     auto map = [&](uint64_t gm) {
         uint64_t m = 0;
         for (uint32_t i = 0; i < g->nbits; i++) {
@@ -103,7 +105,20 @@ void nfa_sim_run_sa(void *h, const uint8_t *data, int64_t n, int variant, int64_
         return m;
     };
     if (map(G) != (S & a->valid)) bad = 0;
-    for (int64_t p = 0; p < n; p++) {
+    for (int64_t p = 0; p <= n; p++) {
+        const uint32_t cur = p < n ? (g->kind[data[p]] & 3u) : (uint32_t) SRE_NFA_KIND_EDGE;
+        if (a->nassert) {
+            /* look-ahead assertions that hold list their continuation at this position */
+            S |= a->expand[(size_t) (prev * 4 + cur) * 256 + ((S >> (8 * a->assert_byte)) & 0xff)];
+            G |= g->expand[(size_t) (prev * 4 + cur) * 256 + ((G >> (8 * g->assert_slice)) & 0xff)];
+            const bool e1 = (S & a->match_bits) != 0, e2 = (G & g->match_bits) != 0;
+            if (bad < 0 && (e1 != e2 || (!e1 && map(G) != (S & a->valid & ~a->match_bits)))) bad = p + 1;
+            if (e1) {
+                ev = p;
+                break;
+            }
+        }
+        if (p == n) break;
         uint64_t t, gt = G & g->accept[data[p]], gr = 0;
         S = sa_step(a, S, data[p], &t);
         for (uint32_t k = 0; k < g->nslices; k++) gr |= g->follow[(size_t) k * 256 + ((gt >> (8 * k)) & 0xff)];
@@ -117,6 +132,7 @@ void nfa_sim_run_sa(void *h, const uint8_t *data, int64_t n, int variant, int64_
             break;
         }
         if (cl) clean = p + 1;
+        prev = cur;
     }
     out[0] = ev;
     out[1] = clean;

@@ -965,6 +965,7 @@ def test_nfa_tier_takes_what_the_step_automaton_declines(gpu, blocks):
     on the NFA tier — first match + captures and Thompson equal the reference
     CLI's lines."""
     bad, n, engines = [], 0, {S.ENGINE_VM: 0, S.ENGINE_SCAN: 0, S.ENGINE_NFA: 0}
+    kernels = {}
     for blk in blocks:
         subject = bytes.fromhex(blk["s"])
         for name, regexes, flags, multi, ref in harness.block_variants(blk):
@@ -976,6 +977,7 @@ def test_nfa_tier_takes_what_the_step_automaton_declines(gpu, blocks):
                 engines[sc.engine] += 1
                 if sc.engine != S.ENGINE_NFA:
                     continue
+                kernels[sc.kernel_name] = kernels.get(sc.kernel_name, 0) + 1
                 buf = S.DeviceBuffer.from_bytes(subject)
                 rec = sc.scan([buf.ptr], [len(subject)])[0]
                 th = S.Scanner(pool, prog, S.HIP_THOMPSON, S.ENGINE_AUTO).scan([buf.ptr], [len(subject)])[0]
@@ -988,6 +990,7 @@ def test_nfa_tier_takes_what_the_step_automaton_declines(gpu, blocks):
                 if line != ref["res"][4] or tl != ref["res"][0]:
                     bad.append((blk["file"], blk["name"], name, line, ref["res"][4], tl, ref["res"][0]))
     print("engine admission over the reference runs (AUTO, first match):", engines)
+    print("NFA-tier kernels of those runs:", sorted(kernels.items(), key=lambda kv: -kv[1]))
     assert not bad, (len(bad), bad[:5])
     assert n > 30, (n, engines)
     assert engines[S.ENGINE_VM] < 40, engines
@@ -1075,6 +1078,7 @@ def test_bench_nfa_variants_closed_forms_vs_oracle(gpu):
     cases = [
         ("nfa37", bench.CFG3, bench.NFA37_BODY, bench.NFA37_TAIL, S.ENGINE_NFA, lambda n, t: [8, 1, n - 4, n, -1, -1]),
         ("nfa60", [bench.NFA60_PAT], b"abccc", bench.NFA60_TAIL, S.ENGINE_AUTO, lambda n, t: [0, 1, n - (len(t) - 1), n - 1]),
+        ("nfala", [bench.NFA_PAT + b"$"], b"abccc", b" abaabaabab@", S.ENGINE_AUTO, lambda n, t: [0, 1, n - 11, n]),
         ("nfa57w", [bench.NFA57_PAT], b"abccc", bench.NFA57_TAIL, S.ENGINE_AUTO, lambda n, t: [0, 1, n - (len(t) - 1), n - 1]),
     ]
     for name, pats, body, tail, engine, want in cases:

@@ -134,7 +134,7 @@ SA_OPTIONS = [0, SA_MASKED, SA_EVACC, SA_NO_EVACC, SA_W64, SA_W64 | SA_CARRY, SA
 def _sa_info(sim, h):
     info = (ctypes.c_int32 * 10)()
     sim.nfa_sim_sa_info(h, info)
-    return dict(zip(("has", "nbits", "w64", "carry", "masked", "evacc", "nlut", "cost", "threads"), info))
+    return dict(zip(("has", "nbits", "w64", "carry", "masked", "evacc", "nlut", "cost", "threads", "nassert"), info))
 
 
 def _sa_check(sim, prog, datas, options):
