@@ -521,7 +521,9 @@ sre_k_nfa_sa(sre_nfa_sa_tables_t T, sre_scan_geom_t G, sre_nfa_summary_t *__rest
     };
     auto step = [&](uint32_t a_lo, uint32_t a_hi, uint32_t kk) -> bool {
         if (LA) {
-            expand(kk & 0x7fffu);
+            /* (a wave in which no lane lists an assertion skips the lookup and its round trip: behind a
+             * trailing `$` or `\b` that is nearly every byte) */
+            if (__builtin_amdgcn_ballot_w64((s_lo & amask) != 0) != 0) expand(kk & 0x7fffu);
             prev_off = kk >> 16;
         }
         const uint32_t t_lo = s_lo & a_lo, t_hi = W64 ? (s_hi & a_hi) : 0u;

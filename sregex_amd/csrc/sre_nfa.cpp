@@ -491,16 +491,19 @@ build_shift_and(sre_nfa_t *n, const std::vector<uint64_t> &fbit, unsigned option
     uint64_t assert_bits = 0;
     for (uint32_t j = 0; j < n->nassert; j++) assert_bits |= 1ull << (8 * n->assert_slice + j);
     if (n->nassert) options |= SRE_NFA_SA_FORCE_MASKED | SRE_NFA_SA_NO_EVACC;
-    uint64_t roots[4] = {n->init[0], n->init[1], n->init[2], implicit_any ? fbit[any_bit] : 0};
-    /* (expansions list threads too: a merge would have to compare those memberships as well — programs
-     * with look-ahead assertions keep their threads apart) */
-    bool     changed = !(options & SRE_NFA_SA_NO_MERGE) && n->nassert == 0;
+    /* every set that lists threads: the initial lists, the ".*?" thread's closure, and what each
+     * look-ahead assertion that holds puts into the list (per context) */
+    std::vector<uint64_t> roots = {n->init[0], n->init[1], n->init[2], implicit_any ? fbit[any_bit] : 0};
+    for (uint32_t ctx = 0; ctx < 16 && n->nassert; ctx++) {
+        for (uint32_t j = 0; j < n->nassert; j++) roots.push_back(n->expand[(size_t) ctx * 256 + (1u << j)]);
+    }
+    bool     changed = !(options & SRE_NFA_SA_NO_MERGE);
     while (changed) {
         changed = false;
         for (uint32_t i = 0; i < nb && !changed; i++) {
-            if (!((live >> i) & 1) || ((n->any_bits >> i) & 1)) continue;
+            if (!((live >> i) & 1) || (((n->any_bits | assert_bits) >> i) & 1)) continue;
             for (uint32_t j = i + 1; j < nb && !changed; j++) {
-                if (!((live >> j) & 1) || ((n->any_bits >> j) & 1)) continue;
+                if (!((live >> j) & 1) || (((n->any_bits | assert_bits) >> j) & 1)) continue;
                 if ((F[i] & ~n->match_bits) != (F[j] & ~n->match_bits)) continue;
                 if (((F[i] & n->match_bits) != 0) != ((F[j] & n->match_bits) != 0)) continue;
                 bool same = true;
@@ -508,14 +511,14 @@ build_shift_and(sre_nfa_t *n, const std::vector<uint64_t> &fbit, unsigned option
                     if (n->bit_pc[k] == 0xffffffffu) continue;
                     same = ((F[k] >> i) & 1) == ((F[k] >> j) & 1);
                 }
-                for (int r = 0; r < 4 && same; r++) same = ((roots[r] >> i) & 1) == ((roots[r] >> j) & 1);
+                for (size_t r = 0; r < roots.size() && same; r++) same = ((roots[r] >> i) & 1) == ((roots[r] >> j) & 1);
                 if (!same) continue;
                 /* j joins i */
                 for (uint32_t k = 0; k < nb; k++) {
                     if (rep[k] == (int) j) rep[k] = (int) i;
                     F[k] &= ~(1ull << j);
                 }
-                for (int r = 0; r < 4; r++) roots[r] &= ~(1ull << j);
+                for (size_t r = 0; r < roots.size(); r++) roots[r] &= ~(1ull << j);
                 for (int q = 0; q < 4; q++) A[i * 4 + q] |= A[j * 4 + q];
                 live &= ~(1ull << j);
                 changed = true;
