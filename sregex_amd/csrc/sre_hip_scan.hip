@@ -492,6 +492,9 @@ byte_x4(uint32_t v, uint32_t sh)
 #ifndef SRE_SCAN_PREFETCH
 #define SRE_SCAN_PREFETCH 1         /* stages of HBM loads in flight per lane (1 or 2), see sre_k_scan */
 #endif
+#ifndef SRE_FIRST_BLOCKS
+#define SRE_FIRST_BLOCKS 4          /* workgroups per CU the FIRST / Thompson kernels' registers are budgeted for */
+#endif
 #ifndef SRE_COUNT_BLOCKS
 #define SRE_COUNT_BLOCKS 3          /* workgroups per CU the COUNT kernel's registers are budgeted for */
 #endif
@@ -504,7 +507,7 @@ byte_x4(uint32_t v, uint32_t sh)
  * same fast loop, nothing recorded.
  */
 template <int MODE, int BITS, bool WIDE>
-__global__ __launch_bounds__(SRE_SCAN_BLOCK, MODE == SRE_HIP_PIKE_COUNT ? SRE_COUNT_BLOCKS : 4) void
+__global__ __launch_bounds__(SRE_SCAN_BLOCK, MODE == SRE_HIP_PIKE_COUNT ? SRE_COUNT_BLOCKS : SRE_FIRST_BLOCKS) void
 sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
            sre_seg_summary_t *__restrict__ sum, const sre_stream_status_t *__restrict__ st_lo,
            const uint8_t *__restrict__ entry)

@@ -1,0 +1,193 @@
+/*
+ * tests/pwave_sim.cpp — TEST-ONLY host model of the wavefront Pike step (sregex_amd/csrc/sre_hip_pwave.hip).
+ *
+ * Takes the tables of sre_pwave_build() (static closure lists per instruction and context) and runs
+ * one whole-buffer exec of a fresh context the way the kernel does — accept test per listed thread,
+ * first listed MATCH cuts the list, consuming threads in priority order load their closure list, a
+ * stamp per thread makes the first arrival win, survivors are ranked in source order then closure
+ * order, capture columns are handed over with the saved slots replaced — only with loops where the
+ * kernel has lanes.  The CPU suite checks it against the oracle (tests/test_pwave_model.py), which
+ * pins the ALGORITHM (that static lists + first-arrival-wins reproduce the reference's generation
+ * tags, its SPLIT re-descent, SRE_DONE and the leading-byte skip) without a GPU.  Compiled into
+ * tests/_build/; not part of, nor linked into, the product library.
+ */
+#include "sre_pwave.h"
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+namespace {
+
+struct Sim {
+    const sre_pwave_hdr_t   *W;
+    const sre_pwave_list_t  *lists;
+    const sre_pwave_entry_t *ents;
+    const uint8_t           *in;
+    uint32_t                 nslots, n = 0, cur = 0, stamp_cur = 0;
+    int64_t                  processed = 0;
+    uint32_t                 seen_newline = 0, sss = 0, initial_count = 0, has_matched = 0, poisoned = 0;
+    int64_t                  matched_id = -1;
+    std::vector<int64_t>     caps[2], matched;
+    uint16_t                 tidv[2][64], initial[64];
+    uint32_t                 stamp[64];
+
+    uint32_t ctx_at(int64_t pos) const
+    {
+        if (pos == 0) return processed == 0 ? 2u : (seen_newline ? 1u : 0u);
+        return in[pos - 1] == '\n' ? 1u : 0u;
+    }
+    void seed(int64_t pos)
+    {
+        const sre_pwave_list_t L = lists[ctx_at(pos)];
+        for (uint32_t k = 0; k < L.len; k++) {
+            const sre_pwave_entry_t e = ents[L.off + k];
+            tidv[cur][k] = e.tid;
+            for (uint32_t s = 0; s < nslots; s++) caps[cur][s * 64 + k] = ((e.saves >> s) & 1) ? processed + pos : -1;
+        }
+        n = L.len;
+        if (L.sss) sss = 1;
+    }
+    int64_t find_first_byte(int64_t pos, int64_t last) const
+    {
+        for (; pos < last; pos++) {
+            const uint32_t c = in[pos];
+            if ((W->lead[c >> 5] >> (c & 31)) & 1) return pos;
+        }
+        return last;
+    }
+    int64_t exec(int64_t size, int64_t start, bool skip_target, int64_t *ov, uint32_t ovec_slots)
+    {
+        const int64_t last = size;
+        int64_t       sp = 0;
+        bool          no_check_once = false, skip_ran_out = false;
+        memset(stamp, 0, sizeof(stamp));
+        seed(sp);
+        initial_count = n;
+        for (uint32_t k = 0; k + 1 < n; k++) initial[k] = tidv[cur][k];
+        if (start > sp) {
+            sp = start;
+            if (W->nleading && skip_target) {
+                sp = find_first_byte(sp, last);
+                no_check_once = true;
+                if (sp == last) skip_ran_out = true;
+            }
+            seed(sp);
+        }
+        for (; !skip_ran_out && sp <= last; sp++) {
+            if (n == 0) break;
+            if (no_check_once) {
+                no_check_once = false;
+            } else if (W->nleading && sss) {
+                sss = 0;
+                bool same = (sp != last) && (n == initial_count);
+                for (uint32_t k = 0; same && k + 1 < n; k++) same = tidv[cur][k] == initial[k];
+                if (same) {
+                    const int64_t p = find_first_byte(sp, last);
+                    if (p > sp) {
+                        sp = p;
+                        seed(sp);
+                        if (sp == last) break;
+                    }
+                }
+            }
+            const bool     at_end = sp == last;
+            const uint32_t c = at_end ? 0u : in[sp];
+            const uint32_t nxt = cur ^ 1u;
+            const int64_t  pos1 = processed + sp + 1;
+            uint32_t       m = 64, d = 64;
+            uint64_t       src = 0;
+            sre_pwave_list_t Ls[64];
+            for (uint32_t i = 0; i < n; i++) {
+                const uint32_t t = tidv[cur][i];
+                if (W->tid_match[t]) {
+                    if (m == 64) m = i;
+                    continue;
+                }
+                if (at_end || !((W->accept[t][c >> 5] >> (c & 31)) & 1)) continue;
+                src |= 1ull << i;
+                Ls[i] = lists[(uint32_t) W->tid_list[t] * SRE_PWAVE_NCTX + (c == '\n' ? 1u : 0u)];
+            }
+            if (m < 64) src &= (1ull << m) - 1;
+            for (uint32_t i = 0; i < 64; i++) {
+                if (((src >> i) & 1) && Ls[i].done) {
+                    d = i;
+                    break;
+                }
+            }
+            if (d < 63) src &= (2ull << d) - 1;
+            stamp_cur++;
+            uint32_t nn = 0;
+            bool     done = false;
+            for (uint32_t i = 0; i < 64; i++) {
+                if (!((src >> i) & 1)) continue;
+                const sre_pwave_list_t L = Ls[i];
+                if (L.sss) sss = 1;
+                for (uint32_t k = 0; k < L.len; k++) {
+                    const sre_pwave_entry_t e = ents[L.off + k];
+                    if (stamp[e.tid] == stamp_cur) continue;
+                    stamp[e.tid] = stamp_cur;
+                    tidv[nxt][nn] = e.tid;
+                    for (uint32_t s = 0; s < nslots; s++) {
+                        caps[nxt][s * 64 + nn] = ((e.saves >> s) & 1) ? pos1 : caps[cur][s * 64 + i];
+                    }
+                    nn++;
+                }
+                if (i == d) {
+                    const sre_pwave_entry_t me = ents[L.off + L.len];
+                    for (uint32_t s = 0; s < nslots; s++) matched[s] = ((me.saves >> s) & 1) ? pos1 : caps[cur][s * 64 + i];
+                    matched_id = (int64_t) W->tid_match[me.tid] - 1;
+                    done = true;
+                }
+            }
+            if (!done && m < 64) {
+                for (uint32_t s = 0; s < nslots; s++) matched[s] = caps[cur][s * 64 + m];
+                matched_id = (int64_t) W->tid_match[tidv[cur][m]] - 1;
+                done = true;
+            }
+            if (done) has_matched = 1;
+            cur = nxt;
+            n = nn;
+            if (at_end) break;
+        }
+        if (has_matched) {
+            if (matched_id >= (int64_t) W->nregexes) return -1;
+            const uint32_t *ncaps = reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(W) + W->multi_ncaps_off);
+            uint32_t        ofs = 0;
+            for (int64_t r = 0; r < matched_id; r++) ofs += ncaps[r] + 1;
+            ofs *= 2;
+            const uint32_t cnt = 2u * (ncaps[matched_id] + 1);
+            for (uint32_t k = 0; k < ovec_slots; k++) ov[k] = k < cnt ? matched[ofs + k] : -1;
+            if (n > 0) poisoned = 1;
+            return matched_id;
+        }
+        return -5;
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+void *pwave_sim_build(const sre_program_t *prog) { return sre_pwave_build(prog); }
+void pwave_sim_free(void *h) { free(h); }
+
+/* one exec of a fresh context with eof; returns rc, fills ov[ovec_slots] and *poisoned */
+int64_t pwave_sim_exec(void *h, const uint8_t *data, int64_t n, int64_t *ov, uint32_t ovec_slots, int *poisoned)
+{
+    const sre_pwave_hdr_t *W = static_cast<const sre_pwave_hdr_t *>(h);
+    Sim s;
+    s.W = W;
+    s.lists = reinterpret_cast<const sre_pwave_list_t *>(reinterpret_cast<const uint8_t *>(W) + W->off_lists);
+    s.ents = reinterpret_cast<const sre_pwave_entry_t *>(reinterpret_cast<const uint8_t *>(W) + W->off_entries);
+    s.in = data;
+    s.nslots = W->nslots;
+    s.caps[0].assign((size_t) W->nslots * 64, -1);
+    s.caps[1].assign((size_t) W->nslots * 64, -1);
+    s.matched.assign(W->nslots, -1);
+    const int64_t rc = s.exec(n, 0, false, ov, ovec_slots);
+    if (poisoned) *poisoned = (int) s.poisoned;
+    return rc;
+}
+
+}

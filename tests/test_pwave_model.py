@@ -1,0 +1,106 @@
+"""The wavefront Pike step's ALGORITHM (sregex_amd/csrc/sre_pwave.cpp static closure lists +
+sre_hip_pwave.hip's step), checked on the CPU through a test-only sequential model
+(tests/pwave_sim.cpp) against the reference goldens and the oracle: rc, regex id and every ovector
+slot of a whole-buffer exec, for every reference program that has the wave form."""
+import ctypes
+import os
+import random
+import subprocess
+
+import pytest
+
+import sregex_amd as S
+import harness
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+_vp, _i64 = ctypes.c_void_p, ctypes.c_int64
+
+
+@pytest.fixture(scope="module")
+def sim(lib):
+    out = os.path.join(HERE, "_build")
+    os.makedirs(out, exist_ok=True)
+    so = os.path.join(out, "libpwavesim.so")
+    srcs = [os.path.join(HERE, "pwave_sim.cpp"), os.path.join(ROOT, "sregex_amd", "csrc", "sre_pwave.cpp")]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.check_call(["g++", "-O2", "-g", "-std=c++17", "-shared", "-fPIC", "-o", so] + srcs +
+                              ["-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "sregex_amd", "csrc")])
+    L = ctypes.CDLL(so)
+    L.pwave_sim_build.restype = _vp
+    L.pwave_sim_build.argtypes = [_vp]
+    L.pwave_sim_free.argtypes = [_vp]
+    L.pwave_sim_exec.restype = _i64
+    L.pwave_sim_exec.argtypes = [_vp, ctypes.c_char_p, _i64, ctypes.POINTER(_i64), ctypes.c_uint32, ctypes.POINTER(ctypes.c_int)]
+    return L
+
+
+def _exec(sim, h, data, ncaps):
+    nov = 2 * (ncaps + 1)
+    ov = (_i64 * nov)(*([-7] * nov))
+    poisoned = ctypes.c_int(0)
+    rc = sim.pwave_sim_exec(h, bytes(data), len(data), ov, nov, ctypes.byref(poisoned))
+    return rc, list(ov) if rc >= 0 else None, poisoned.value
+
+
+def _oracle(ora, prog, ncaps, data):
+    p = ora.pike(prog, ncaps)
+    rc = p.exec(data, True, want_pending=False)
+    ov = list(p.ovector) if rc >= 0 else None
+    # a poisoned context answers SRE_ERROR to the next exec (sre_vm_pike.c:616-622)
+    poisoned = 1 if rc >= 0 and p.exec(b"", True, want_pending=False) == S.SRE_ERROR else 0
+    p.close()
+    return rc, ov, poisoned
+
+
+def test_wave_step_equals_the_reference_on_reference_blocks(sim, blocks):
+    ora = harness.OracleEngine()
+    n, bad = 0, []
+    for blk in blocks:
+        subject = bytes.fromhex(blk["s"])
+        for name, regexes, flags, multi, ref in harness.block_variants(blk):
+            if ref["rc"] != 0:
+                continue
+            with S.Pool() as pool:
+                prog = S.compile(pool, S.parse(pool, regexes, flags, multi))
+                h = sim.pwave_sim_build(prog.h)
+                if not h:
+                    continue            # look-ahead assertions, > 64 threads or slots: the one-lane VM
+                got = _exec(sim, h, subject, ref["ncaps"])
+                sim.pwave_sim_free(h)
+                nov = 2 * (ref["ncaps"] + 1)
+                line = ("pike match %d%s" % (got[0], harness._fmt_caps(got[1], nov)) if got[0] >= 0 else "pike no match")
+                n += 1
+                if line != ref["res"][4]:
+                    bad.append((blk["file"], blk["name"], name, line, ref["res"][4]))
+    assert not bad, (len(bad), bad[:5])
+    assert n > 1400, n
+
+
+def test_wave_step_random_patterns_vs_oracle(sim):
+    ora = harness.OracleEngine()
+    rng = random.Random(int(os.environ.get("SRE_FUZZ_SEED", "20261004")) + 21)
+    alphabet = b"abcx \n_."
+    n, bad = 0, []
+    for _ in range(1500):
+        nre = 1 if rng.random() < 0.8 else rng.randrange(2, 4)
+        pats = [harness.random_regex(rng) for _ in range(nre)]
+        with S.Pool() as pool:
+            try:
+                re = S.parse(pool, pats)
+            except Exception:
+                continue
+            prog = S.compile(pool, re)
+            h = sim.pwave_sim_build(prog.h)
+            if not h:
+                continue
+            for _ in range(4):
+                d = bytes(rng.choice(alphabet) for _ in range(rng.choice([0, 1, 7, 40, 130, 400])))
+                got = _exec(sim, h, d, re.ncaps)
+                want = _oracle(ora, prog, re.ncaps, d)
+                n += 1
+                if got != want:
+                    bad.append((pats, d, got, want))
+            sim.pwave_sim_free(h)
+    assert not bad, (len(bad), bad[:3])
+    assert n > 1500, n
