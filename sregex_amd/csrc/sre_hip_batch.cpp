@@ -382,6 +382,23 @@ scanner_create(sre_pool_t *pool, sre_program_t *prog, int mode, int engine, int 
         }
     }
     sc->ctx_stride = mode == SRE_HIP_THOMPSON ? dp->thompson_layout.total : dp->pike_layout.total;
+    if (sc->engine == SRE_HIP_ENGINE_VM && mode != SRE_HIP_THOMPSON && getenv("SRE_HIP_NO_PWAVE") == NULL) {
+        /* the exact VM's Pike scans by a wavefront per stream, when the program has the form (sre_pwave.h) */
+        sc->h_pwave = sre_pwave_build(prog);
+        if (sc->h_pwave && !sre_pwave_fits(sc->h_pwave)) {
+            free(sc->h_pwave);
+            sc->h_pwave = NULL;
+        }
+        if (sc->h_pwave
+            && (hipMalloc(&sc->d_pwave, sc->h_pwave->bytes) != hipSuccess
+                || hipMemcpy(sc->d_pwave, sc->h_pwave, sc->h_pwave->bytes, hipMemcpyHostToDevice) != hipSuccess))
+        {
+            if (sc->d_pwave) (void) hipFree(sc->d_pwave);
+            sc->d_pwave = NULL;
+            free(sc->h_pwave);
+            sc->h_pwave = NULL;
+        }
+    }
 
     if (sre_pool_add_cleanup(pool, scanner_release, sc) != SRE_OK) {
         scanner_release(sc);
@@ -443,7 +460,7 @@ sre_hip_scanner_kernel_name(sre_hip_scanner_t *sc)
         } else {
             snprintf(sc->kernel_name, sizeof(sc->kernel_name), "%s",
                      sc->mode == SRE_HIP_THOMPSON ? (sc->dp->has_wave ? "sre_k_thompson_wave_scan" : "sre_k_thompson_scan")
-                                                  : "sre_k_pike_scan");
+                                                  : sc->d_pwave ? "sre_k_pike_scan_wave" : "sre_k_pike_scan");
         }
     }
     return sc->kernel_name;
@@ -942,11 +959,19 @@ sre_hip_scan_enqueue(sre_hip_scanner_t *sc, const void *const *d_streams, const 
     if (sc->engine == SRE_HIP_ENGINE_VM) {
         SRE_HIP_TRY(hipMemcpyAsync(sc->d_in, sc->h_in, 2 * nstreams * sizeof(uint64_t),
                                    hipMemcpyHostToDevice, stream));
-        /* zero-filled state == fresh context */
-        SRE_HIP_TRY(hipMemsetAsync(sc->d_ctx, 0, nstreams * sc->ctx_stride, stream));
-        SRE_HIP_TRY(sre_launch_vm_scan(sc->dp->d_blob, sc->mode, sc->d_ptrs, sc->d_lens,
-                                       (uint32_t) nstreams, sc->d_ctx, sc->ctx_stride,
-                                       sc->d_records, sc->ovec_slots, sc->dp->has_wave, stream));
+        if (sc->d_pwave && nstreams <= 16384) {
+            /* one wavefront per stream: up to ~8000 of them run at once, and a stream's step does not
+             * get slower with the length of its thread list (beyond that many streams one LANE per
+             * stream keeps more of them in flight) */
+            SRE_HIP_TRY(sre_launch_pike_scan_wave(sc->d_pwave, sc->h_pwave, sc->mode, sc->d_ptrs, sc->d_lens,
+                                                  (uint32_t) nstreams, sc->d_records, sc->ovec_slots, stream));
+        } else {
+            /* zero-filled state == fresh context */
+            SRE_HIP_TRY(hipMemsetAsync(sc->d_ctx, 0, nstreams * sc->ctx_stride, stream));
+            SRE_HIP_TRY(sre_launch_vm_scan(sc->dp->d_blob, sc->mode, sc->d_ptrs, sc->d_lens,
+                                           (uint32_t) nstreams, sc->d_ctx, sc->ctx_stride,
+                                           sc->d_records, sc->ovec_slots, sc->dp->has_wave, stream));
+        }
     } else if (sc->engine == SRE_HIP_ENGINE_NFA && sc->cnt != NULL) {
         /* find-all counting: a loop of first-match searches, run by results() (nfa_count_rounds) */
         NfaCount &c = *sc->cnt;

@@ -74,6 +74,7 @@ struct PikeWave {
     uint32_t n, cur, stamp_cur;
     int64_t  processed;
     uint32_t seen_newline, sss, initial_count, has_matched, poisoned;
+    uint32_t empty_capture, ctx_eof;    /* the re-armed context of a find-all iteration (:179-196, :616-628) */
     int64_t  matched_id;
 
     __device__ inline uint32_t ctx_at(int64_t pos) const
@@ -125,6 +126,15 @@ struct PikeWave {
         int64_t       sp = 0;
         bool          no_check_once = false, skip_ran_out = false;
         int64_t       last_matched_pos = -1;
+        if (ctx_eof) return -1;                                 /* :165-168 */
+        if (empty_capture) {                                    /* :179-196 */
+            empty_capture = 0;
+            if (size == 0) {
+                ctx_eof = 1;
+                return PW_RC_DECLINED;
+            }
+            sp = 1;
+        }
         cur = 0;
         n = 0;
         sss = 0;
@@ -245,7 +255,10 @@ struct PikeWave {
             if (at_end) break;
         }
 
-        (void) last_matched_pos;        /* (seen_newline / seen_word of the context: the window's context is not used again) */
+        if (last_matched_pos >= 0) {                            /* :586-601 (seen_word: only look-ahead programs read it) */
+            const int64_t p = last_matched_pos - processed;
+            if (p > 0) seen_newline = pw_uniform(in[p - 1] == '\n' ? 1u : 0u);
+        }
         if (has_matched) {                                      /* :607-636, eof */
             if (matched_id >= (int64_t) W->nregexes) return -1;
             const uint32_t *ncaps = reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(W) + W->multi_ncaps_off);
@@ -255,9 +268,17 @@ struct PikeWave {
             const uint32_t cnt = 2u * (ncaps[matched_id] + 1);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             for (uint32_t k = lane; k < ovec_slots; k += 64) ov[k] = k < cnt ? matched[ofs + k] : (int64_t) -1;
-            if (n > 0) poisoned = 1;                            /* :616-622 */
+            if (n > 0) {
+                poisoned = 1;                                   /* :616-622 */
+                ctx_eof = 1;
+            }
+            /* :624-628 re-arm for the next search on the same context */
+            const int64_t m0 = matched[ofs], m1 = matched[ofs + 1];
+            processed = (int64_t) (((uint64_t) pw_uniform((uint32_t) ((uint64_t) m1 >> 32)) << 32) | pw_uniform((uint32_t) (uint64_t) m1));
+            empty_capture = pw_uniform(m0 == m1 ? 1u : 0u);
             return matched_id;
         }
+        ctx_eof = 1;
         return PW_RC_DECLINED;                                  /* :660-666 */
     }
 };
@@ -280,22 +301,12 @@ pwave_lds_bytes(const sre_pwave_hdr_t *h, bool *ents_in_lds)
     return (b + 15) & ~(size_t) 15;
 }
 
-extern "C" __global__ __launch_bounds__(64) void
-sre_k_pike_window_wave(const sre_pwave_hdr_t *__restrict__ Wg, const uint8_t *const *__restrict__ streams,
-                       const uint64_t *__restrict__ lens, uint32_t nstreams, int64_t *__restrict__ records,
-                       uint32_t ovec_slots, sre_nfa_window_t *__restrict__ win, const int64_t *__restrict__ lo,
-                       const sre_nfa_count_req_t *__restrict__ creq, uint32_t ents_in_lds)
+/* carve the wave's LDS and copy the program's tables into it */
+__device__ inline void
+pwave_setup(PikeWave &vm, const sre_pwave_hdr_t *Wg, uint8_t *lds, uint32_t lane, uint32_t ents_in_lds)
 {
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    const uint32_t i = blockIdx.x;
-    if (i >= nstreams) return;
-    if (lo != nullptr && lo[i] < 0) return;     /* settled in an earlier round */
-    if (!win[i].done || win[i].ev_pos < 0) return;
-    const uint32_t lane = threadIdx.x;
     const uint32_t nslots = Wg->nslots;
-
-    PikeWave vm;
-    uint8_t *p = lds;
+    uint8_t       *p = lds;
     vm.caps[0] = reinterpret_cast<int64_t *>(p);    p += (size_t) nslots * 64 * 8;
     vm.caps[1] = reinterpret_cast<int64_t *>(p);    p += (size_t) nslots * 64 * 8;
     vm.matched = reinterpret_cast<int64_t *>(p);    p += 64 * 8;
@@ -332,9 +343,70 @@ sre_k_pike_window_wave(const sre_pwave_hdr_t *__restrict__ Wg, const uint8_t *co
     vm.tid_match = tid_match;
     vm.nslots = nslots;
     vm.lane = lane;
+    vm.processed = 0;
+    vm.seen_newline = 0;
+    vm.empty_capture = 0;
+    vm.ctx_eof = 0;
+}
+
+/*
+ * ENGINE_VM, Pike: whole streams, one wavefront each — first match, or the find-all iteration of the
+ * reference's caller on one re-armed context (exec from the previous match's end until SRE_DECLINED,
+ * sre_vm_pike.c:179-196, :586-636), as sre_hip_vm.hip sre_k_pike_scan does with one lane per stream.
+ */
+extern "C" __global__ __launch_bounds__(64) void
+sre_k_pike_scan_wave(const sre_pwave_hdr_t *__restrict__ Wg, const uint8_t *const *__restrict__ streams,
+                     const uint64_t *__restrict__ lens, uint32_t nstreams, int64_t *__restrict__ records,
+                     uint32_t ovec_slots, int mode, uint32_t ents_in_lds)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const uint32_t i = blockIdx.x;
+    if (i >= nstreams) return;
+    const uint32_t lane = threadIdx.x;
+    PikeWave vm;
+    pwave_setup(vm, Wg, lds, lane, ents_in_lds);
+    int64_t       *rec = records + (size_t) i * (2 + ovec_slots);
+    const uint8_t *s = streams[i];
+    const uint64_t n = lens[i];
+    uint64_t       off = 0;
+    int64_t        count = 0, rc, last_rc = PW_RC_DECLINED;
+    for (uint32_t k = lane; k < ovec_slots; k += 64) rec[2 + k] = -1;
+    for (;;) {
+        vm.in = s + off;
+        rc = vm.exec((int64_t) (n - off), 0, false, rec + 2, ovec_slots);
+        if (rc < 0) break;
+        count++;
+        last_rc = rc;
+        if (mode != 2) break;
+        off = (uint64_t) vm.processed;      /* == ovector[1] of this match */
+    }
+    /* the final SRE_DECLINED leaves the ovector of the last match in place (:660-666 writes nothing) */
+    if (lane == 0) {
+        rec[0] = rc == -1 ? rc : (count > 0 ? last_rc : rc);
+        rec[1] = count;
+    }
+}
+
+extern "C" __global__ __launch_bounds__(64) void
+sre_k_pike_window_wave(const sre_pwave_hdr_t *__restrict__ Wg, const uint8_t *const *__restrict__ streams,
+                       const uint64_t *__restrict__ lens, uint32_t nstreams, int64_t *__restrict__ records,
+                       uint32_t ovec_slots, sre_nfa_window_t *__restrict__ win, const int64_t *__restrict__ lo,
+                       const sre_nfa_count_req_t *__restrict__ creq, uint32_t ents_in_lds)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const uint32_t i = blockIdx.x;
+    if (i >= nstreams) return;
+    if (lo != nullptr && lo[i] < 0) return;     /* settled in an earlier round */
+    if (!win[i].done || win[i].ev_pos < 0) return;
+    const uint32_t lane = threadIdx.x;
+
+    PikeWave vm;
+    pwave_setup(vm, Wg, lds, lane, ents_in_lds);
     vm.in = streams[i];
     vm.processed = 0;
     vm.seen_newline = 0;
+    vm.empty_capture = 0;
+    vm.ctx_eof = 0;
 
     int64_t *rec = records + (size_t) i * (2 + ovec_slots);
     uint64_t len = lens[i];
@@ -385,6 +457,26 @@ sre_launch_pike_window_wave(const void *d_wave_v, const void *h_wave_v, const vo
     hipLaunchKernelGGL(sre_k_pike_window_wave, dim3(nstreams), dim3(64), bytes, stream, d_wave,
                        reinterpret_cast<const uint8_t *const *>(d_streams), d_lens, nstreams, d_records, ovec_slots,
                        d_win, d_lo, d_creq, in_lds ? 1u : 0u);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t
+sre_launch_pike_scan_wave(const void *d_wave_v, const void *h_wave_v, int mode, const void *const *d_streams,
+                          const uint64_t *d_lens, uint32_t nstreams, int64_t *d_records, uint32_t ovec_slots,
+                          hipStream_t stream)
+{
+    const sre_pwave_hdr_t *d_wave = static_cast<const sre_pwave_hdr_t *>(d_wave_v);
+    const sre_pwave_hdr_t *h_wave = static_cast<const sre_pwave_hdr_t *>(h_wave_v);
+    bool         in_lds = false;
+    const size_t bytes = pwave_lds_bytes(h_wave, &in_lds);
+    if (bytes > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sre_k_pike_scan_wave),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(sre_k_pike_scan_wave, dim3(nstreams), dim3(64), bytes, stream, d_wave,
+                       reinterpret_cast<const uint8_t *const *>(d_streams), d_lens, nstreams, d_records, ovec_slots, mode,
+                       in_lds ? 1u : 0u);
     return hipGetLastError();
 }
 

@@ -27,6 +27,7 @@ struct Sim {
     uint32_t                 nslots, n = 0, cur = 0, stamp_cur = 0;
     int64_t                  processed = 0;
     uint32_t                 seen_newline = 0, sss = 0, initial_count = 0, has_matched = 0, poisoned = 0;
+    uint32_t                 empty_capture = 0, ctx_eof = 0;
     int64_t                  matched_id = -1;
     std::vector<int64_t>     caps[2], matched;
     uint16_t                 tidv[2][64], initial[64];
@@ -59,8 +60,23 @@ struct Sim {
     int64_t exec(int64_t size, int64_t start, bool skip_target, int64_t *ov, uint32_t ovec_slots)
     {
         const int64_t last = size;
-        int64_t       sp = 0;
+        int64_t       sp = 0, last_matched_pos = -1;
         bool          no_check_once = false, skip_ran_out = false;
+        if (ctx_eof) return -1;
+        if (empty_capture) {
+            empty_capture = 0;
+            if (size == 0) {
+                ctx_eof = 1;
+                return -5;
+            }
+            sp = 1;
+        }
+        cur = 0;
+        n = 0;
+        sss = 0;
+        has_matched = 0;
+        poisoned = 0;
+        stamp_cur = 0;
         memset(stamp, 0, sizeof(stamp));
         seed(sp);
         initial_count = n;
@@ -145,10 +161,17 @@ struct Sim {
                 matched_id = (int64_t) W->tid_match[tidv[cur][m]] - 1;
                 done = true;
             }
-            if (done) has_matched = 1;
+            if (done) {
+                has_matched = 1;
+                last_matched_pos = matched[1];
+            }
             cur = nxt;
             n = nn;
             if (at_end) break;
+        }
+        if (last_matched_pos >= 0) {
+            const int64_t p = last_matched_pos - processed;
+            if (p > 0) seen_newline = in[p - 1] == '\n';
         }
         if (has_matched) {
             if (matched_id >= (int64_t) W->nregexes) return -1;
@@ -158,9 +181,15 @@ struct Sim {
             ofs *= 2;
             const uint32_t cnt = 2u * (ncaps[matched_id] + 1);
             for (uint32_t k = 0; k < ovec_slots; k++) ov[k] = k < cnt ? matched[ofs + k] : -1;
-            if (n > 0) poisoned = 1;
+            if (n > 0) {
+                poisoned = 1;
+                ctx_eof = 1;
+            }
+            processed = matched[ofs + 1];
+            empty_capture = matched[ofs] == matched[ofs + 1];
             return matched_id;
         }
+        ctx_eof = 1;
         return -5;
     }
 };
@@ -188,6 +217,32 @@ int64_t pwave_sim_exec(void *h, const uint8_t *data, int64_t n, int64_t *ov, uin
     const int64_t rc = s.exec(n, 0, false, ov, ovec_slots);
     if (poisoned) *poisoned = (int) s.poisoned;
     return rc;
+}
+
+/* the find-all iteration of sre_k_pike_scan_wave: rec[0] = last rc / final error, rec[1] = count, rec[2..] = last ovector */
+void pwave_sim_count(void *h, const uint8_t *data, int64_t n, int64_t *rec, uint32_t ovec_slots)
+{
+    const sre_pwave_hdr_t *W = static_cast<const sre_pwave_hdr_t *>(h);
+    Sim s;
+    s.W = W;
+    s.lists = reinterpret_cast<const sre_pwave_list_t *>(reinterpret_cast<const uint8_t *>(W) + W->off_lists);
+    s.ents = reinterpret_cast<const sre_pwave_entry_t *>(reinterpret_cast<const uint8_t *>(W) + W->off_entries);
+    s.nslots = W->nslots;
+    s.caps[0].assign((size_t) W->nslots * 64, -1);
+    s.caps[1].assign((size_t) W->nslots * 64, -1);
+    s.matched.assign(W->nslots, -1);
+    int64_t off = 0, count = 0, rc, last_rc = -5;
+    for (uint32_t k = 0; k < ovec_slots; k++) rec[2 + k] = -1;
+    for (;;) {
+        s.in = data + off;
+        rc = s.exec(n - off, 0, false, rec + 2, ovec_slots);
+        if (rc < 0) break;
+        count++;
+        last_rc = rc;
+        off = s.processed;
+    }
+    rec[0] = rc == -1 ? rc : (count > 0 ? last_rc : rc);
+    rec[1] = count;
 }
 
 }

@@ -32,6 +32,7 @@ def sim(lib):
     L.pwave_sim_free.argtypes = [_vp]
     L.pwave_sim_exec.restype = _i64
     L.pwave_sim_exec.argtypes = [_vp, ctypes.c_char_p, _i64, ctypes.POINTER(_i64), ctypes.c_uint32, ctypes.POINTER(ctypes.c_int)]
+    L.pwave_sim_count.argtypes = [_vp, ctypes.c_char_p, _i64, ctypes.POINTER(_i64), ctypes.c_uint32]
     return L
 
 
@@ -104,3 +105,49 @@ def test_wave_step_random_patterns_vs_oracle(sim):
             sim.pwave_sim_free(h)
     assert not bad, (len(bad), bad[:3])
     assert n > 1500, n
+
+
+def _count_want(ora, prog, ncaps, data):
+    """the record the batched API's PIKE_COUNT returns (tests/test_gpu_parity.py _expect)"""
+    nov = 2 * (ncaps + 1)
+    allm = harness.findall(ora, prog, ncaps, data)
+    final, matches = allm[-1][0], allm[:-1]
+    if matches:
+        return [S.SRE_ERROR if final == S.SRE_ERROR else matches[-1][0], len(matches)] + matches[-1][1:]
+    return [final, 0] + [-1] * nov
+
+
+def test_wave_find_all_iteration_vs_oracle(sim):
+    """the re-armed context of the find-all iteration (empty matches skip a byte, ^ goes by the byte in
+    front of the previous match's end, a poisoned context ends it with SRE_ERROR)"""
+    ora = harness.OracleEngine()
+    rng = random.Random(int(os.environ.get("SRE_FUZZ_SEED", "20261004")) + 22)
+    alphabet = b"abcx \n_."
+    cases = []
+    for rec in harness.load_jsonl("findall.jsonl"):
+        cases.append(([bytes.fromhex(h) for h in rec["re"]], bytes.fromhex(rec["s"])))
+    for _ in range(600):
+        nre = 1 if rng.random() < 0.8 else rng.randrange(2, 4)
+        pats = [harness.random_regex(rng) for _ in range(nre)]
+        cases.append((pats, bytes(rng.choice(alphabet) for _ in range(rng.choice([0, 1, 7, 40, 130])))))
+    n, bad = 0, []
+    for pats, data in cases:
+        with S.Pool() as pool:
+            try:
+                re = S.parse(pool, pats)
+            except Exception:
+                continue
+            prog = S.compile(pool, re)
+            h = sim.pwave_sim_build(prog.h)
+            if not h:
+                continue
+            nov = 2 * (re.ncaps + 1)
+            rec = (_i64 * (2 + nov))()
+            sim.pwave_sim_count(h, bytes(data), len(data), rec, nov)
+            sim.pwave_sim_free(h)
+            want = _count_want(ora, prog, re.ncaps, data)
+            n += 1
+            if list(rec) != want:
+                bad.append((pats, data, list(rec), want))
+    assert not bad, (len(bad), bad[:3])
+    assert n > 300, n
