@@ -68,6 +68,7 @@ struct PikeWave {
     uint16_t *tidv[2];      /* [64] */
     uint32_t *stamp;        /* [64] */
     uint16_t *initial;      /* [64] */
+    uint8_t  *inl;          /* [16] */
     /* uniform state */
     const uint8_t *in;
     uint32_t nslots, lane;
@@ -75,6 +76,7 @@ struct PikeWave {
     int64_t  processed;
     uint32_t seen_newline, sss, initial_count, has_matched, poisoned;
     uint32_t empty_capture, ctx_eof;    /* the re-armed context of a find-all iteration (:179-196, :616-628) */
+    uint32_t first_buf, seen_word;      /* a context fed in chunks (exec_chunk) */
     int64_t  matched_id;
 
     __device__ inline uint32_t ctx_at(int64_t pos) const
@@ -116,6 +118,90 @@ struct PikeWave {
             pos += 64;
         }
         return last;
+    }
+
+    /* slot 1 of the match just recorded (last_matched_pos, :530-532, :895) */
+    __device__ inline int64_t matched_end() const
+    {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        const int64_t m1 = matched[1];
+        return (int64_t) (((uint64_t) pw_uniform((uint32_t) ((uint64_t) m1 >> 32)) << 32) | pw_uniform((uint32_t) (uint64_t) m1));
+    }
+
+    /* one byte step at `sp` (:312-581); returns whether a MATCH was reached */
+    __device__ inline bool step(int64_t sp, int64_t last)
+    {
+        const bool     at_end = sp == last;
+        const uint32_t c = at_end ? 0u : pw_uniform((uint32_t) in[sp]);
+        const uint32_t nxt = cur ^ 1u;
+        const int64_t  pos1 = processed + sp + 1;
+        uint32_t       t = 0, is_m = 0, acc = 0;
+        uint32_t       l_off = 0, l_len = 0, l_done = 0, l_sss = 0;
+        if (lane < n) {
+            t = tidv[cur][lane];
+            is_m = tid_match[t];
+            if (!at_end && !is_m) {
+                acc = (accw[t * 8 + (c >> 5)] >> (c & 31)) & 1u;
+                if (acc) {
+                    /* ^ behind the byte goes by the byte (:851-860); \A never holds there */
+                    const sre_pwave_list_t L = lists[(uint32_t) tid_list[t] * SRE_PWAVE_NCTX + (c == '\n' ? 1u : 0u)];
+                    l_off = L.off;
+                    l_len = L.len;
+                    l_done = L.done;
+                    l_sss = L.sss;
+                }
+            }
+        }
+        const uint64_t mm = __builtin_amdgcn_ballot_w64(is_m != 0);
+        const uint32_t m = mm ? (uint32_t) __builtin_ctzll(mm) : 64u;
+        uint64_t       src = __builtin_amdgcn_ballot_w64(acc != 0);
+        if (m < 64) src &= (1ull << m) - 1;                 /* a listed MATCH cuts what is behind it (:530-553) */
+        const uint64_t dm = __builtin_amdgcn_ballot_w64(l_done != 0) & src;
+        const uint32_t d = dm ? (uint32_t) __builtin_ctzll(dm) : 64u;
+        if (d < 63) src &= (2ull << d) - 1;                 /* SRE_DONE ends the step behind its source (:895-898) */
+        stamp_cur++;
+        uint32_t nn = 0;
+        bool     done = false;
+        for (uint64_t rem = src; rem; rem &= rem - 1) {
+            const uint32_t i = (uint32_t) __builtin_ctzll(rem);
+            const uint32_t off = pw_readlane(l_off, i), len = pw_readlane(l_len, i);
+            if (pw_readlane(l_sss, i)) sss = 1;
+            const bool        valid = lane < len;
+            sre_pwave_entry_t e;
+            e.tid = 0;
+            e.saves = 0;
+            if (valid) e = ents[off + lane];
+            const bool     keep = valid && stamp[e.tid] != stamp_cur;       /* first arrival wins (:770) */
+            const uint64_t km = __builtin_amdgcn_ballot_w64(keep);
+            const uint32_t rank = nn + pw_lane_rank(km);
+            if (keep) {
+                stamp[e.tid] = stamp_cur;
+                tidv[nxt][rank] = e.tid;
+            }
+            /* the source's capture vector, broadcast slot by slot */
+            for (uint32_t s = 0; s < nslots; s++) {
+                const int64_t v = caps[cur][s * 64 + i];
+                if (keep) caps[nxt][s * 64 + rank] = ((e.saves >> s) & 1) ? pos1 : v;
+            }
+            nn += (uint32_t) __builtin_popcountll(km);
+            if (i == d) {
+                /* the closure reached MATCH behind its listed targets: the match (:895-898) */
+                const sre_pwave_entry_t me = ents[off + len];
+                if (lane < nslots) matched[lane] = ((me.saves >> lane) & 1) ? pos1 : caps[cur][lane * 64 + i];
+                matched_id = (int64_t) pw_uniform(tid_match[me.tid]) - 1;
+                done = true;
+            }
+        }
+        if (!done && m < 64) {
+            /* the listed MATCH thread is reached (:530-553) */
+            if (lane < nslots) matched[lane] = caps[cur][lane * 64 + m];
+            matched_id = (int64_t) pw_readlane(is_m, m) - 1;
+            done = true;
+        }
+        if (done) has_matched = 1;
+        cur = nxt;
+        n = nn;
+        return done;
     }
 
     /* one whole-buffer exec() of a fresh (possibly re-armed) context with eof, picked up at `start`
@@ -176,83 +262,8 @@ struct PikeWave {
                     }
                 }
             }
-            /* ---- the step (:312-581) */
-            const bool     at_end = sp == last;
-            const uint32_t c = at_end ? 0u : pw_uniform((uint32_t) in[sp]);
-            const uint32_t nxt = cur ^ 1u;
-            const int64_t  pos1 = processed + sp + 1;
-            uint32_t       t = 0, is_m = 0, acc = 0;
-            uint32_t       l_off = 0, l_len = 0, l_done = 0, l_sss = 0;
-            if (lane < n) {
-                t = tidv[cur][lane];
-                is_m = tid_match[t];
-                if (!at_end && !is_m) {
-                    acc = (accw[t * 8 + (c >> 5)] >> (c & 31)) & 1u;
-                    if (acc) {
-                        /* ^ behind the byte goes by the byte (:851-860); \A never holds there */
-                        const sre_pwave_list_t L = lists[(uint32_t) tid_list[t] * SRE_PWAVE_NCTX + (c == '\n' ? 1u : 0u)];
-                        l_off = L.off;
-                        l_len = L.len;
-                        l_done = L.done;
-                        l_sss = L.sss;
-                    }
-                }
-            }
-            const uint64_t mm = __builtin_amdgcn_ballot_w64(is_m != 0);
-            const uint32_t m = mm ? (uint32_t) __builtin_ctzll(mm) : 64u;
-            uint64_t       src = __builtin_amdgcn_ballot_w64(acc != 0);
-            if (m < 64) src &= (1ull << m) - 1;                 /* a listed MATCH cuts what is behind it (:530-553) */
-            const uint64_t dm = __builtin_amdgcn_ballot_w64(l_done != 0) & src;
-            const uint32_t d = dm ? (uint32_t) __builtin_ctzll(dm) : 64u;
-            if (d < 63) src &= (2ull << d) - 1;                 /* SRE_DONE ends the step behind its source (:895-898) */
-            stamp_cur++;
-            uint32_t nn = 0;
-            bool     done = false;
-            for (uint64_t rem = src; rem; rem &= rem - 1) {
-                const uint32_t i = (uint32_t) __builtin_ctzll(rem);
-                const uint32_t off = pw_readlane(l_off, i), len = pw_readlane(l_len, i);
-                if (pw_readlane(l_sss, i)) sss = 1;
-                const bool        valid = lane < len;
-                sre_pwave_entry_t e;
-                e.tid = 0;
-                e.saves = 0;
-                if (valid) e = ents[off + lane];
-                const bool     keep = valid && stamp[e.tid] != stamp_cur;       /* first arrival wins (:770) */
-                const uint64_t km = __builtin_amdgcn_ballot_w64(keep);
-                const uint32_t rank = nn + pw_lane_rank(km);
-                if (keep) {
-                    stamp[e.tid] = stamp_cur;
-                    tidv[nxt][rank] = e.tid;
-                }
-                /* the source's capture vector, broadcast slot by slot */
-                for (uint32_t s = 0; s < nslots; s++) {
-                    const int64_t v = caps[cur][s * 64 + i];
-                    if (keep) caps[nxt][s * 64 + rank] = ((e.saves >> s) & 1) ? pos1 : v;
-                }
-                nn += (uint32_t) __builtin_popcountll(km);
-                if (i == d) {
-                    /* the closure reached MATCH behind its listed targets: the match (:895-898) */
-                    const sre_pwave_entry_t me = ents[off + len];
-                    if (lane < nslots) matched[lane] = ((me.saves >> lane) & 1) ? pos1 : caps[cur][lane * 64 + i];
-                    matched_id = (int64_t) pw_uniform(tid_match[me.tid]) - 1;
-                    done = true;
-                }
-            }
-            if (!done && m < 64) {
-                /* the listed MATCH thread is reached (:530-553) */
-                if (lane < nslots) matched[lane] = caps[cur][lane * 64 + m];
-                matched_id = (int64_t) pw_readlane(is_m, m) - 1;
-                done = true;
-            }
-            if (done) {
-                has_matched = 1;
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                last_matched_pos = (int64_t) (((uint64_t) pw_uniform((uint32_t) ((uint64_t) matched[1] >> 32)) << 32)
-                                              | pw_uniform((uint32_t) (uint64_t) matched[1]));
-            }
-            cur = nxt;
-            n = nn;
-            if (at_end) break;
+            if (step(sp, last)) last_matched_pos = matched_end();
+            if (sp == last) break;
         }
 
         if (last_matched_pos >= 0) {                            /* :586-601 (seen_word: only look-ahead programs read it) */
@@ -281,6 +292,129 @@ struct PikeWave {
         ctx_eof = 1;
         return PW_RC_DECLINED;                                  /* :660-666 */
     }
+
+    /*
+     * One exec() of a context fed in CHUNKS (sre_vm_pike.c:148-689 with or without eof), as
+     * sre_hip_vm.hip Pike::exec takes it with one lane: the list and its capture columns stay in the
+     * context between calls; without a decision the call answers SRE_AGAIN with the range a match
+     * could still span (:692-735) and the pending match (:640-658).
+     */
+    __device__ int64_t exec_chunk(int64_t size, bool eof, bool want_pending, int64_t *ov, uint32_t ovec_slots,
+                                  int64_t *has_pending, int64_t *pending, int64_t *consumed)
+    {
+        const int64_t last = size;
+        int64_t       sp = 0, last_matched_pos = -1;
+        *has_pending = 0;
+        *consumed = 0;
+        if (ctx_eof) return -1;                                 /* :165-168 */
+        if (empty_capture) {                                    /* :179-196 */
+            empty_capture = 0;
+            if (size == 0) {
+                if (eof) {
+                    ctx_eof = 1;
+                    return PW_RC_DECLINED;
+                }
+                return -2;
+            }
+            sp = 1;
+        }
+        stamp_cur = 0;
+        stamp[lane] = 0;
+        if (first_buf) {                                        /* :202-233 */
+            first_buf = 0;
+            sss = 0;
+            seed(sp);
+            initial_count = n;
+            if (lane + 1 < n) initial[lane] = tidv[cur][lane];
+        }
+        for (; sp < last || (eof && sp == last); sp++) {        /* :235 */
+            if (n == 0) break;
+            if (W->nleading && sss) {                           /* :256-309 */
+                sss = 0;
+                bool same = (sp != last) && (n == initial_count);
+                if (same) {
+                    const bool diff = lane + 1 < n && tidv[cur][lane] != initial[lane];
+                    same = __builtin_amdgcn_ballot_w64(diff) == 0;
+                }
+                if (same) {
+                    const int64_t p = find_first_byte(sp, last);
+                    if (p > sp) {
+                        sp = p;
+                        seed(sp);
+                        if (sp == last) break;
+                    }
+                }
+            }
+            if (step(sp, last)) last_matched_pos = matched_end();
+            if (sp == last) break;
+        }
+        *consumed = sp;
+
+        if (last_matched_pos >= 0) {                            /* :586-601 */
+            const int64_t p = last_matched_pos - processed;
+            if (p > 0) {
+                const uint32_t b = pw_uniform((uint32_t) in[p - 1]);
+                seen_newline = b == '\n';
+                seen_word = (b - '0' < 10u) || (b - 'A' < 26u) || (b - 'a' < 26u) || b == '_';
+            }
+        }
+        const uint32_t *ncaps = reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(W) + W->multi_ncaps_off);
+        if (has_matched) {                                      /* :607-658 */
+            if (matched_id >= (int64_t) W->nregexes) return -1;
+            uint32_t ofs = 0;
+            for (int64_t r = 0; r < matched_id; r++) ofs += ncaps[r] + 1;
+            ofs *= 2;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            const int64_t m0 = matched[ofs], m1r = matched[ofs + 1];
+            const int64_t m1 = (int64_t) (((uint64_t) pw_uniform((uint32_t) ((uint64_t) m1r >> 32)) << 32)
+                                          | pw_uniform((uint32_t) (uint64_t) m1r));
+            if (eof || n == 0) {
+                const uint32_t cnt = 2u * (ncaps[matched_id] + 1);
+                for (uint32_t k = lane; k < ovec_slots; k += 64) ov[k] = k < cnt ? matched[ofs + k] : (int64_t) -1;
+                if (n > 0) {
+                    n = 0;                                      /* :616-622 */
+                    ctx_eof = 1;
+                }
+                processed = m1;                                 /* :624-628 */
+                empty_capture = pw_uniform(m0 == m1r ? 1u : 0u);
+                has_matched = 0;
+                first_buf = 1;
+                return matched_id;
+            }
+            if (want_pending) {
+                *has_pending = 1;
+                pending[0] = m0;
+                pending[1] = m1;
+            }
+        } else if (eof) {                                       /* :660-666 */
+            ctx_eof = 1;
+            return PW_RC_DECLINED;
+        }
+        processed += sp;                                        /* :673-688 */
+        if (ovec_slots >= 2) {
+            /* :692-735 (end offset read without the per-regex offset, :721) */
+            int64_t a0 = INT64_MAX, a1 = -1;
+            if (lane < n) {
+                uint32_t ofs = 0;
+                for (uint32_t r = 0; r < W->nregexes; r++) {
+                    const int64_t b = caps[cur][ofs * 64 + lane];
+                    if (b != -1 && b < a0) a0 = b;
+                    ofs += 2 * (ncaps[r] + 1);
+                }
+                a1 = caps[cur][1 * 64 + lane];
+            }
+            for (int d = 32; d > 0; d >>= 1) {
+                const int64_t o0 = __shfl_xor(a0, d), o1 = __shfl_xor(a1, d);
+                a0 = o0 < a0 ? o0 : a0;
+                a1 = o1 > a1 ? o1 : a1;
+            }
+            if (lane == 0) {
+                ov[0] = a0 == INT64_MAX ? (int64_t) -1 : a0;
+                ov[1] = a1;
+            }
+        }
+        return -2;
+    }
 };
 
 }  // namespace
@@ -292,6 +426,7 @@ pwave_lds_bytes(const sre_pwave_hdr_t *h, bool *ents_in_lds)
     size_t b = 0;
     b += 2 * (size_t) h->nslots * 64 * 8;       /* caps */
     b += 64 * 8;                                /* matched */
+    b += 16;                                    /* a chunk that travels in the request (sre_k_pike_exec_wave) */
     b += 2 * 64 * 2 + 64 * 4 + 64 * 2;          /* tidv, stamp, initial */
     b += 64 * 8 * 4 + 64 * 2 * 2;               /* accept words, tid_list, tid_match */
     b += (size_t) h->nlists * SRE_PWAVE_NCTX * sizeof(sre_pwave_list_t);
@@ -310,6 +445,7 @@ pwave_setup(PikeWave &vm, const sre_pwave_hdr_t *Wg, uint8_t *lds, uint32_t lane
     vm.caps[0] = reinterpret_cast<int64_t *>(p);    p += (size_t) nslots * 64 * 8;
     vm.caps[1] = reinterpret_cast<int64_t *>(p);    p += (size_t) nslots * 64 * 8;
     vm.matched = reinterpret_cast<int64_t *>(p);    p += 64 * 8;
+    vm.inl = p;                                     p += 16;
     uint32_t *accw = reinterpret_cast<uint32_t *>(p);   p += 64 * 8 * 4;
     vm.stamp = reinterpret_cast<uint32_t *>(p);     p += 64 * 4;
     vm.tidv[0] = reinterpret_cast<uint16_t *>(p);   p += 64 * 2;
@@ -347,6 +483,8 @@ pwave_setup(PikeWave &vm, const sre_pwave_hdr_t *Wg, uint8_t *lds, uint32_t lane
     vm.seen_newline = 0;
     vm.empty_capture = 0;
     vm.ctx_eof = 0;
+    vm.first_buf = 1;
+    vm.seen_word = 0;
 }
 
 /*
@@ -477,6 +615,142 @@ sre_launch_pike_scan_wave(const void *d_wave_v, const void *h_wave_v, int mode, 
     hipLaunchKernelGGL(sre_k_pike_scan_wave, dim3(nstreams), dim3(64), bytes, stream, d_wave,
                        reinterpret_cast<const uint8_t *const *>(d_streams), d_lens, nstreams, d_records, ovec_slots, mode,
                        in_lds ? 1u : 0u);
+    return hipGetLastError();
+}
+
+/*
+ * The compat API's streaming VM (sre_vm_pike_exec fed chunk by chunk, sre_vm_api.cpp): one request =
+ * one exec() on one context, taken by a wavefront.  The context between calls (device memory,
+ * zero-filled == fresh): the header below, the current list and its capture columns.
+ */
+#define SRE_PWAVE_CTX_MAGIC 0x50575631u
+
+struct sre_pwave_ctx_t {
+    uint32_t magic, n, sss, initial_count;
+    uint32_t has_matched, first_buf, empty_capture, ctx_eof;
+    uint32_t seen_newline, seen_word, pad[2];
+    int64_t  processed, matched_id;
+    uint16_t tidv[64], initial[64];
+    int64_t  matched[64];
+    /* int64_t caps[nslots][64] follows */
+};
+
+extern "C" size_t
+sre_pwave_ctx_bytes(const void *h_wave)
+{
+    return sizeof(sre_pwave_ctx_t) + (size_t) static_cast<const sre_pwave_hdr_t *>(h_wave)->nslots * 64 * 8;
+}
+
+extern "C" __global__ __launch_bounds__(64) void
+sre_k_pike_exec_wave(const sre_pwave_hdr_t *__restrict__ Wg, const sre_dev_req_t *__restrict__ reqs, uint32_t nreqs,
+                     uint32_t ents_in_lds)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const uint32_t i = blockIdx.x;
+    if (i >= nreqs) return;
+    const sre_dev_req_t rq = reqs[i];
+    const uint32_t      lane = threadIdx.x;
+    PikeWave            vm;
+    pwave_setup(vm, Wg, lds, lane, ents_in_lds);
+    const uint32_t   nslots = vm.nslots;
+    sre_pwave_ctx_t *cx = static_cast<sre_pwave_ctx_t *>(rq.ctx);
+    int64_t         *ccaps = reinterpret_cast<int64_t *>(cx + 1);
+    vm.cur = 0;
+    vm.n = 0;
+    vm.sss = 0;
+    vm.initial_count = 0;
+    vm.has_matched = 0;
+    vm.poisoned = 0;
+    vm.matched_id = 0;
+    if (pw_uniform(cx->magic) != SRE_PWAVE_CTX_MAGIC) {
+        /* fresh context (sre_vm_pike.c:94-145); earlier searches may have run on the scanner */
+        if (rq.preset_valid) {
+            vm.processed = rq.preset_processed;
+            vm.empty_capture = (rq.preset_flags & SRE_PRESET_EMPTY_CAPTURE) ? 1u : 0u;
+            vm.seen_newline = (rq.preset_flags & SRE_PRESET_SEEN_NEWLINE) ? 1u : 0u;
+            vm.seen_word = (rq.preset_flags & SRE_PRESET_SEEN_WORD) ? 1u : 0u;
+            vm.ctx_eof = (rq.preset_flags & SRE_PRESET_EOF) ? 1u : 0u;
+        }
+    } else {
+        vm.n = pw_uniform(cx->n);
+        vm.sss = pw_uniform(cx->sss);
+        vm.initial_count = pw_uniform(cx->initial_count);
+        vm.has_matched = pw_uniform(cx->has_matched);
+        vm.first_buf = pw_uniform(cx->first_buf);
+        vm.empty_capture = pw_uniform(cx->empty_capture);
+        vm.ctx_eof = pw_uniform(cx->ctx_eof);
+        vm.seen_newline = pw_uniform(cx->seen_newline);
+        vm.seen_word = pw_uniform(cx->seen_word);
+        vm.processed = cx->processed;
+        vm.matched_id = cx->matched_id;
+        vm.tidv[0][lane] = cx->tidv[lane];
+        vm.initial[lane] = cx->initial[lane];
+        vm.matched[lane] = cx->matched[lane];
+        if (lane < vm.n) {
+            for (uint32_t s = 0; s < nslots; s++) vm.caps[0][s * 64 + lane] = ccaps[s * 64 + lane];
+        }
+    }
+    /* a chunk of up to 8 bytes travels in the request */
+    if (rq.input == nullptr) {
+        if (lane < 8) vm.inl[lane] = (uint8_t) (rq.inline_bytes >> (8 * lane));
+        vm.in = vm.inl;
+    } else {
+        vm.in = rq.input;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+
+    sre_dev_result_t *res = static_cast<sre_dev_result_t *>(rq.result);
+    int64_t          *ov = reinterpret_cast<int64_t *>(res + 1);
+    int64_t           has_pending = 0, pending[2] = {0, 0}, consumed = 0;
+    const int64_t     rc = vm.exec_chunk((int64_t) rq.size, rq.eof != 0, rq.want_pending != 0, ov, (uint32_t) rq.ovec_slots,
+                                         &has_pending, pending, &consumed);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    /* the context for the next call */
+    cx->tidv[lane] = vm.tidv[vm.cur][lane];
+    cx->initial[lane] = vm.initial[lane];
+    cx->matched[lane] = vm.matched[lane];
+    if (lane < vm.n) {
+        for (uint32_t s = 0; s < nslots; s++) ccaps[s * 64 + lane] = vm.caps[vm.cur][s * 64 + lane];
+    }
+    if (lane == 0) {
+        cx->magic = SRE_PWAVE_CTX_MAGIC;
+        cx->n = vm.n;
+        cx->sss = vm.sss;
+        cx->initial_count = vm.initial_count;
+        cx->has_matched = vm.has_matched;
+        cx->first_buf = vm.first_buf;
+        cx->empty_capture = vm.empty_capture;
+        cx->ctx_eof = vm.ctx_eof;
+        cx->seen_newline = vm.seen_newline;
+        cx->seen_word = vm.seen_word;
+        cx->processed = vm.processed;
+        cx->matched_id = vm.matched_id;
+        res->has_pending = has_pending;
+        res->pending[0] = pending[0];
+        res->pending[1] = pending[1];
+        res->consumed = consumed;
+        /* what the context holds between two searches (sre_hip_vm.hip sre_k_pike_exec) */
+        res->pad[0] = 16 | (vm.empty_capture ? SRE_PRESET_EMPTY_CAPTURE : 0) | (vm.seen_newline ? SRE_PRESET_SEEN_NEWLINE : 0)
+                      | (vm.seen_word ? SRE_PRESET_SEEN_WORD : 0) | (vm.ctx_eof ? SRE_PRESET_EOF : 0);
+        res->pad[1] = vm.processed;
+        res->rc = rc;
+    }
+}
+
+extern "C" hipError_t
+sre_launch_pike_exec_wave(const void *d_wave_v, const void *h_wave_v, const sre_dev_req_t *d_reqs, uint32_t nreqs,
+                          hipStream_t stream)
+{
+    const sre_pwave_hdr_t *d_wave = static_cast<const sre_pwave_hdr_t *>(d_wave_v);
+    const sre_pwave_hdr_t *h_wave = static_cast<const sre_pwave_hdr_t *>(h_wave_v);
+    bool         in_lds = false;
+    const size_t bytes = pwave_lds_bytes(h_wave, &in_lds);
+    if (bytes > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sre_k_pike_exec_wave),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(sre_k_pike_exec_wave, dim3(nreqs), dim3(64), bytes, stream, d_wave, d_reqs, nreqs, in_lds ? 1u : 0u);
     return hipGetLastError();
 }
 

@@ -3,6 +3,7 @@
  * of a compiled program.
  */
 #include "sre_hip_runtime.h"
+#include "sre_pwave.h"
 #include "sre_dfa.h"
 #include "sre_nfa.h"
 #include <stdio.h>
@@ -62,7 +63,30 @@ free_program_image(void *data)
     }
     sre_dfa_free(dp->dfa_pike);
     sre_dfa_free(dp->dfa_thompson);
+    if (dp->d_pwave) (void) hipFree(dp->d_pwave);
+    free(dp->h_pwave);
     free(dp);
+}
+
+extern "C" void *
+sre_hip_program_pwave(struct sre_hip_program_s *dp, sre_program_t *prog)
+{
+    if (dp->pwave_tried) return dp->d_pwave;
+    dp->pwave_tried = 1;
+    if (getenv("SRE_HIP_NO_PWAVE") != NULL) return NULL;
+    sre_pwave_hdr_t *h = sre_pwave_build(prog);
+    if (h == NULL) return NULL;
+    void *d = NULL;
+    if (!sre_pwave_fits(h) || hipMalloc(&d, h->bytes) != hipSuccess
+        || hipMemcpy(d, h, h->bytes, hipMemcpyHostToDevice) != hipSuccess)
+    {
+        if (d) (void) hipFree(d);
+        free(h);
+        return NULL;
+    }
+    dp->h_pwave = h;
+    dp->d_pwave = d;
+    return d;
 }
 
 extern "C" struct sre_hip_program_s *

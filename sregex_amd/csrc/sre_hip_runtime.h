@@ -28,6 +28,9 @@ struct sre_hip_program_s {
     /* throughput scanners of the compat path (sre_vm_api.cpp), [0] Thompson [1] Pike first match */
     struct sre_hip_scanner_s *compat_scanner[4];     /* Thompson, Pike first match, and their chunked forms (look-ahead programs) */
     int         compat_tried[4];
+    /* the wave form of the exact Pike step (sre_pwave.h) for the streaming VM, built on first use */
+    void       *h_pwave, *d_pwave;
+    int         pwave_tried;
 };
 
 #ifdef __cplusplus
@@ -46,6 +49,9 @@ SRE_NOAPI int sre_hip_fail(const char *what, hipError_t err);
 
 /* build (once) and return the device image of `prog`, or NULL */
 SRE_NOAPI struct sre_hip_program_s *sre_hip_program_get(sre_program_t *prog);
+
+/* the wave form of `prog`'s Pike step on the device (dp->d_pwave), or NULL when the program has none */
+SRE_NOAPI void *sre_hip_program_pwave(struct sre_hip_program_s *dp, sre_program_t *prog);
 
 #define SRE_HIP_TRY(expr)                                                     \
     do {                                                                      \

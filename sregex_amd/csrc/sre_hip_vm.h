@@ -68,6 +68,10 @@ hipError_t sre_launch_pike_window_wave(const void *d_wave, const void *h_wave, c
     const uint64_t *d_lens, uint32_t nstreams, int64_t *d_records, uint32_t ovec_slots,
     sre_nfa_window_t *d_win, const int64_t *d_lo, const sre_nfa_count_req_t *d_creq, hipStream_t stream);
 int sre_pwave_fits(const void *h_wave);
+/* the compat API's streaming VM by a wavefront: context bytes, and one exec() per request */
+size_t sre_pwave_ctx_bytes(const void *h_wave);
+hipError_t sre_launch_pike_exec_wave(const void *d_wave, const void *h_wave, const sre_dev_req_t *d_reqs, uint32_t nreqs,
+                                     hipStream_t stream);
 /* ENGINE_VM Pike scans by the same step: whole streams, first match or the find-all iteration */
 hipError_t sre_launch_pike_scan_wave(const void *d_wave, const void *h_wave, int mode, const void *const *d_streams,
     const uint64_t *d_lens, uint32_t nstreams, int64_t *d_records, uint32_t ovec_slots, hipStream_t stream);

@@ -244,7 +244,12 @@ device_stream_exec(DeviceStream *ds, const sre_char *input, size_t len, unsigned
     }
     ds->h_blk->res.rc = SRE_ERROR;
 
-    SRE_HIP_TRY(launch(ds->dp->d_blob, ds->dp->blob_bytes, &ds->d_blk->req, 1, ds->ctx_bytes, ds->stream));
+    if (launch == sre_launch_pike_exec && ds->dp->d_pwave != NULL) {
+        /* the exact step by a wavefront (sre_hip_pwave.hip) */
+        SRE_HIP_TRY(sre_launch_pike_exec_wave(ds->dp->d_pwave, ds->dp->h_pwave, &ds->d_blk->req, 1, ds->stream));
+    } else {
+        SRE_HIP_TRY(launch(ds->dp->d_blob, ds->dp->blob_bytes, &ds->d_blk->req, 1, ds->ctx_bytes, ds->stream));
+    }
     SRE_HIP_TRY(hipStreamSynchronize(ds->stream));
     return 0;
 
@@ -800,7 +805,9 @@ sre_vm_pike_exec(sre_vm_pike_ctx_t *ctx, sre_char *input, size_t len, unsigned e
     if (ctx->ds == NULL) {
         sre_hip_program_s *dp = sre_hip_program_get(ctx->prog);
         if (dp == NULL) return SRE_ERROR;
-        ctx->ds = device_stream_open(ctx->pool, ctx->prog, dp->pike_layout.total, ctx->ovec_slots);
+        size_t ctx_bytes = dp->pike_layout.total;
+        if (sre_hip_program_pwave(dp, ctx->prog) != NULL) ctx_bytes = sre_pwave_ctx_bytes(dp->h_pwave);
+        ctx->ds = device_stream_open(ctx->pool, ctx->prog, ctx_bytes, ctx->ovec_slots);
         if (ctx->ds == NULL) return SRE_ERROR;
     }
     DeviceStream *ds = ctx->ds;

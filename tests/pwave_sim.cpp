@@ -27,7 +27,7 @@ struct Sim {
     uint32_t                 nslots, n = 0, cur = 0, stamp_cur = 0;
     int64_t                  processed = 0;
     uint32_t                 seen_newline = 0, sss = 0, initial_count = 0, has_matched = 0, poisoned = 0;
-    uint32_t                 empty_capture = 0, ctx_eof = 0;
+    uint32_t                 empty_capture = 0, ctx_eof = 0, first_buf = 1;
     int64_t                  matched_id = -1;
     std::vector<int64_t>     caps[2], matched;
     uint16_t                 tidv[2][64], initial[64];
@@ -192,6 +192,164 @@ struct Sim {
         ctx_eof = 1;
         return -5;
     }
+
+    /* the same context fed in CHUNKS (sre_vm_pike.c:148-689 with eof == 0: SRE_AGAIN, the temporary
+     * match range and the pending match, :640-735) — what sre_k_pike_exec's wave path does */
+    int64_t exec_chunk(int64_t size, bool eof, int64_t *ov, uint32_t ovec_slots, int *has_pending, int64_t *pending)
+    {
+        const int64_t last = size;
+        int64_t       sp = 0, last_matched_pos = -1;
+        *has_pending = 0;
+        if (ctx_eof) return -1;
+        if (empty_capture) {
+            empty_capture = 0;
+            if (size == 0) {
+                if (eof) {
+                    ctx_eof = 1;
+                    return -5;
+                }
+                return -2;
+            }
+            sp = 1;
+        }
+        if (first_buf) {
+            first_buf = 0;
+            memset(stamp, 0, sizeof(stamp));
+            stamp_cur = 0;
+            sss = 0;
+            seed(sp);
+            initial_count = n;
+            for (uint32_t k = 0; k + 1 < n; k++) initial[k] = tidv[cur][k];
+        }
+        for (; sp < last || (eof && sp == last); sp++) {
+            if (n == 0) break;
+            if (W->nleading && sss) {
+                sss = 0;
+                bool same = (sp != last) && (n == initial_count);
+                for (uint32_t k = 0; same && k + 1 < n; k++) same = tidv[cur][k] == initial[k];
+                if (same) {
+                    const int64_t p = find_first_byte(sp, last);
+                    if (p > sp) {
+                        sp = p;
+                        seed(sp);
+                        if (sp == last) break;
+                    }
+                }
+            }
+            if (step(sp, last)) last_matched_pos = matched[1];
+            if (sp == last) break;
+        }
+        if (last_matched_pos >= 0) {
+            const int64_t p = last_matched_pos - processed;
+            if (p > 0) seen_newline = in[p - 1] == '\n';
+        }
+        const uint32_t *ncaps = reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(W) + W->multi_ncaps_off);
+        if (has_matched) {
+            if (matched_id >= (int64_t) W->nregexes) return -1;
+            uint32_t ofs = 0;
+            for (int64_t r = 0; r < matched_id; r++) ofs += ncaps[r] + 1;
+            ofs *= 2;
+            if (eof || n == 0) {
+                const uint32_t cnt = 2u * (ncaps[matched_id] + 1);
+                for (uint32_t k = 0; k < ovec_slots; k++) ov[k] = k < cnt ? matched[ofs + k] : -1;
+                if (n > 0) {
+                    n = 0;
+                    ctx_eof = 1;
+                }
+                processed = matched[ofs + 1];
+                empty_capture = matched[ofs] == matched[ofs + 1];
+                has_matched = 0;
+                first_buf = 1;
+                return matched_id;
+            }
+            *has_pending = 1;
+            pending[0] = matched[ofs];
+            pending[1] = matched[ofs + 1];
+        } else if (eof) {
+            ctx_eof = 1;
+            return -5;
+        }
+        processed += sp;
+        if (ovec_slots >= 2) {
+            /* :692-735: the range any listed thread's match could still span (end offset read without
+             * the per-regex offset, :721) */
+            int64_t a0 = -1, a1 = -1;
+            for (uint32_t i = 0; i < n; i++) {
+                uint32_t ofs = 0;
+                for (uint32_t r = 0; r < W->nregexes; r++) {
+                    int64_t b = caps[cur][ofs * 64 + i];
+                    if (b != -1 && (a0 == -1 || b < a0)) a0 = b;
+                    b = caps[cur][1 * 64 + i];
+                    if (b != -1 && (a1 == -1 || b > a1)) a1 = b;
+                    ofs += 2 * (ncaps[r] + 1);
+                }
+            }
+            ov[0] = a0;
+            ov[1] = a1;
+        }
+        return -2;
+    }
+
+    /* one byte step at sp (sre_vm_pike.c:312-581); returns whether a MATCH was reached */
+    bool step(int64_t sp, int64_t last)
+    {
+        const bool     at_end = sp == last;
+        const uint32_t c = at_end ? 0u : in[sp];
+        const uint32_t nxt = cur ^ 1u;
+        const int64_t  pos1 = processed + sp + 1;
+        uint32_t       m = 64, d = 64;
+        uint64_t       src = 0;
+        sre_pwave_list_t Ls[64];
+        for (uint32_t i = 0; i < n; i++) {
+            const uint32_t t = tidv[cur][i];
+            if (W->tid_match[t]) {
+                if (m == 64) m = i;
+                continue;
+            }
+            if (at_end || !((W->accept[t][c >> 5] >> (c & 31)) & 1)) continue;
+            src |= 1ull << i;
+            Ls[i] = lists[(uint32_t) W->tid_list[t] * SRE_PWAVE_NCTX + (c == '\n' ? 1u : 0u)];
+        }
+        if (m < 64) src &= (1ull << m) - 1;
+        for (uint32_t i = 0; i < 64; i++) {
+            if (((src >> i) & 1) && Ls[i].done) {
+                d = i;
+                break;
+            }
+        }
+        if (d < 63) src &= (2ull << d) - 1;
+        stamp_cur++;
+        uint32_t nn = 0;
+        bool     done = false;
+        for (uint32_t i = 0; i < 64; i++) {
+            if (!((src >> i) & 1)) continue;
+            const sre_pwave_list_t L = Ls[i];
+            if (L.sss) sss = 1;
+            for (uint32_t k = 0; k < L.len; k++) {
+                const sre_pwave_entry_t e = ents[L.off + k];
+                if (stamp[e.tid] == stamp_cur) continue;
+                stamp[e.tid] = stamp_cur;
+                tidv[nxt][nn] = e.tid;
+                for (uint32_t s = 0; s < nslots; s++) caps[nxt][s * 64 + nn] = ((e.saves >> s) & 1) ? pos1 : caps[cur][s * 64 + i];
+                nn++;
+            }
+            if (i == d) {
+                const sre_pwave_entry_t me = ents[L.off + L.len];
+                for (uint32_t s = 0; s < nslots; s++) matched[s] = ((me.saves >> s) & 1) ? pos1 : caps[cur][s * 64 + i];
+                matched_id = (int64_t) W->tid_match[me.tid] - 1;
+                done = true;
+            }
+        }
+        if (!done && m < 64) {
+            for (uint32_t s = 0; s < nslots; s++) matched[s] = caps[cur][s * 64 + m];
+            matched_id = (int64_t) W->tid_match[tidv[cur][m]] - 1;
+            done = true;
+        }
+        if (done) has_matched = 1;
+        cur = nxt;
+        n = nn;
+        return done;
+    }
 };
 
 }  // namespace
@@ -217,6 +375,29 @@ int64_t pwave_sim_exec(void *h, const uint8_t *data, int64_t n, int64_t *ov, uin
     const int64_t rc = s.exec(n, 0, false, ov, ovec_slots);
     if (poisoned) *poisoned = (int) s.poisoned;
     return rc;
+}
+
+/* a context fed in chunks */
+void *pwave_sim_ctx_new(void *h)
+{
+    const sre_pwave_hdr_t *W = static_cast<const sre_pwave_hdr_t *>(h);
+    Sim *s = new Sim();
+    s->W = W;
+    s->lists = reinterpret_cast<const sre_pwave_list_t *>(reinterpret_cast<const uint8_t *>(W) + W->off_lists);
+    s->ents = reinterpret_cast<const sre_pwave_entry_t *>(reinterpret_cast<const uint8_t *>(W) + W->off_entries);
+    s->nslots = W->nslots;
+    s->caps[0].assign((size_t) W->nslots * 64, -1);
+    s->caps[1].assign((size_t) W->nslots * 64, -1);
+    s->matched.assign(W->nslots, -1);
+    return s;
+}
+void pwave_sim_ctx_free(void *c) { delete static_cast<Sim *>(c); }
+int64_t pwave_sim_ctx_exec(void *c, const uint8_t *data, int64_t n, int eof, int64_t *ov, uint32_t ovec_slots,
+                           int *has_pending, int64_t *pending)
+{
+    Sim *s = static_cast<Sim *>(c);
+    s->in = data;
+    return s->exec_chunk(n, eof != 0, ov, ovec_slots, has_pending, pending);
 }
 
 /* the find-all iteration of sre_k_pike_scan_wave: rec[0] = last rc / final error, rec[1] = count, rec[2..] = last ovector */

@@ -33,6 +33,12 @@ def sim(lib):
     L.pwave_sim_exec.restype = _i64
     L.pwave_sim_exec.argtypes = [_vp, ctypes.c_char_p, _i64, ctypes.POINTER(_i64), ctypes.c_uint32, ctypes.POINTER(ctypes.c_int)]
     L.pwave_sim_count.argtypes = [_vp, ctypes.c_char_p, _i64, ctypes.POINTER(_i64), ctypes.c_uint32]
+    L.pwave_sim_ctx_new.restype = _vp
+    L.pwave_sim_ctx_new.argtypes = [_vp]
+    L.pwave_sim_ctx_free.argtypes = [_vp]
+    L.pwave_sim_ctx_exec.restype = _i64
+    L.pwave_sim_ctx_exec.argtypes = [_vp, ctypes.c_char_p, _i64, ctypes.c_int, ctypes.POINTER(_i64), ctypes.c_uint32,
+                                     ctypes.POINTER(ctypes.c_int), ctypes.POINTER(_i64)]
     return L
 
 
@@ -151,3 +157,96 @@ def test_wave_find_all_iteration_vs_oracle(sim):
                 bad.append((pats, data, list(rec), want))
     assert not bad, (len(bad), bad[:3])
     assert n > 300, n
+
+
+def _feed_sim(sim, h, data, sizes, nov):
+    """the chunked call sequence of tests/test_gpu_parity.py _feed on the model"""
+    c = sim.pwave_sim_ctx_new(h)
+    out, off = [], 0
+    sizes = list(sizes)
+    ov = (_i64 * max(nov, 2))(*([0] * max(nov, 2)))
+    pend = (_i64 * 2)()
+    hp = ctypes.c_int(0)
+    keep = []
+    while True:
+        n = sizes.pop(0) if sizes else len(data) - off
+        n = min(n, len(data) - off)
+        eof = off + n >= len(data) and not sizes
+        chunk = bytes(data[off:off + n])
+        keep.append(chunk)
+        rc = sim.pwave_sim_ctx_exec(c, chunk, n, 1 if eof else 0, ov, nov, ctypes.byref(hp), pend)
+        off += n
+        if rc == S.SRE_AGAIN:
+            out.append((rc, tuple(ov[:2]), (pend[0], pend[1]) if hp.value else None))
+            continue
+        out.append((rc, tuple(ov[:nov]) if rc >= 0 else None, None))
+        break
+    sim.pwave_sim_ctx_free(c)
+    return out
+
+
+def _feed_oracle(ctx, data, sizes, nov):
+    out, off = [], 0
+    sizes = list(sizes)
+    while True:
+        n = sizes.pop(0) if sizes else len(data) - off
+        n = min(n, len(data) - off)
+        eof = off + n >= len(data) and not sizes
+        rc = ctx.exec(data[off:off + n], eof, want_pending=True)
+        off += n
+        if rc == S.SRE_AGAIN:
+            out.append((rc, tuple(ctx.ovector[:2]), ctx.pending))
+            continue
+        out.append((rc, tuple(ctx.ovector[:nov]) if rc >= 0 else None, None))
+        return out
+
+
+def test_wave_step_chunked_feeding_vs_oracle(sim, blocks):
+    """sre_vm_pike_exec fed in chunks down to one byte per call (the CLI's "splitted pike" mode and
+    random chunkings): SRE_AGAIN with its temporary match range and pending match (sre_vm_pike.c:640-735),
+    then the match — on the model of the wavefront step, against the oracle fed the same way."""
+    ora = harness.OracleEngine()
+    rng = random.Random(int(os.environ.get("SRE_FUZZ_SEED", "20261004")) + 23)
+    n, bad = 0, []
+    for blk in blocks[::3]:
+        subject = bytes.fromhex(blk["s"])
+        for name, regexes, flags, multi, ref in harness.block_variants(blk):
+            if ref["rc"] != 0:
+                continue
+            with S.Pool() as pool:
+                prog = S.compile(pool, S.parse(pool, regexes, flags, multi))
+                h = sim.pwave_sim_build(prog.h)
+                if not h:
+                    continue
+                nov = 2 * (ref["ncaps"] + 1)
+                for sizes in ([1] * len(subject), [rng.choice([0, 1, 2, 3, 7]) for _ in range(12)]):
+                    want = _feed_oracle(ora.pike(prog, ref["ncaps"]), subject, sizes, nov)
+                    got = _feed_sim(sim, h, subject, sizes, nov)
+                    n += 1
+                    if got != want:
+                        bad.append((regexes, subject[:40], sizes[:8], got[-2:], want[-2:]))
+                sim.pwave_sim_free(h)
+    alphabet = b"abcx \n_."
+    for _ in range(500):
+        pats = [harness.random_regex(rng) for _ in range(1 if rng.random() < 0.8 else 2)]
+        with S.Pool() as pool:
+            try:
+                re = S.parse(pool, pats)
+            except Exception:
+                continue
+            prog = S.compile(pool, re)
+            h = sim.pwave_sim_build(prog.h)
+            if not h:
+                continue
+            nov = 2 * (re.ncaps + 1)
+            for _ in range(3):
+                d = bytes(rng.choice(alphabet) for _ in range(rng.choice([1, 7, 40, 130])))
+                sizes = [rng.choice([0, 1, 2, 5, 9, 20]) for _ in range(rng.randrange(1, 10))]
+                want = _feed_oracle(ora.pike(prog, re.ncaps), d, sizes, nov)
+                got = _feed_sim(sim, h, d, sizes, nov)
+                n += 1
+                if got != want:
+                    bad.append((pats, d, sizes, got[-2:], want[-2:]))
+            sim.pwave_sim_free(h)
+    assert not bad, (len(bad), bad[:3])
+    assert n > 1500, n
