@@ -1229,8 +1229,17 @@ sre_hip_scan_one(sre_hip_scanner_t *sc, const void *d_buf, size_t len, int init_
 extern "C" int
 sre_hip_scan_stream_chunk(sre_hip_scanner_t *sc, const void *d_buf, size_t len, int init_variant,
     int continues, uint32_t entry_state, int eof, int64_t base, sre_stream_ctx_t *d_ctx,
-    sre_stream_result_t *d_res, const sre_stream_result_t *h_res, uint32_t ovec_slots, hipStream_t stream)
+    sre_stream_result_t *d_res, const sre_stream_result_t *h_res, uint32_t ovec_slots, hipStream_t stream,
+    void (*midway)(void *), void *midway_arg)
 {
+    /* (midway: what the caller still has to do for the chunk to arrive — it runs after the
+     * launches, and on every way out) */
+    struct Midway {
+        void (*fn)(void *);
+        void  *arg;
+        void   run() { if (fn) fn(arg); fn = nullptr; }
+        ~Midway() { run(); }
+    } mid{midway, midway_arg};
     if (sc->engine != SRE_HIP_ENGINE_SCAN || sc->mode == SRE_HIP_PIKE_COUNT) return -1;
     sc->fixup_rounds = 0;
     sc->exact_passes = 0;
@@ -1254,6 +1263,7 @@ sre_hip_scan_stream_chunk(sre_hip_scanner_t *sc, const void *d_buf, size_t len, 
         SRE_HIP_TRY(sre_launch_stream_tail(sc->tab->d_tab, sc->tab->h, sc->geom, sc->d_sum, sc->d_status,
                                            sc->d_scratch, d_ctx, d_res, base, eof, ovec_slots, fused, stream));
     }
+    mid.run();
     /* the result lands in host-visible memory, rc last: watching that word costs less than
      * the runtime's wait (an interrupt and a wake-up) — for as long as a chunk of this size
      * can reasonably take, then the ordinary wait */

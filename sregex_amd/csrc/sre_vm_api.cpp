@@ -22,6 +22,9 @@
 #include <stddef.h>
 #include <stdio.h>
 #include <atomic>
+#if defined(__x86_64__)
+#include <emmintrin.h>
+#endif
 #include <chrono>
 #include <condition_variable>
 #include <mutex>
@@ -35,7 +38,8 @@ extern "C" int sre_hip_scan_one(sre_hip_scanner_t *sc, const void *d_buf, size_t
     int init_variant, sre_int_t *rec, int *poisoned, hipStream_t stream);
 extern "C" int sre_hip_scan_stream_chunk(sre_hip_scanner_t *sc, const void *d_buf, size_t len,
     int init_variant, int continues, uint32_t entry_state, int eof, int64_t base, sre_stream_ctx_t *d_ctx,
-    sre_stream_result_t *d_res, const sre_stream_result_t *h_res, uint32_t ovec_slots, hipStream_t stream);
+    sre_stream_result_t *d_res, const sre_stream_result_t *h_res, uint32_t ovec_slots, hipStream_t stream,
+    void (*midway)(void *), void *midway_arg);
 extern "C" int sre_hip_scanner_streams(sre_hip_scanner_t *sc);
 extern "C" sre_hip_scanner_t *sre_hip_scanner_create_chunked(sre_pool_t *pool, sre_program_t *prog, int mode);
 extern "C" uint32_t sre_hip_scanner_chunk_entry(sre_hip_scanner_t *sc, uint32_t state, int flags);
@@ -78,9 +82,6 @@ struct DeviceStream {
      * (pinned, device-visible), allocated on first use */
     sre_stream_ctx_t    *d_sctx;
     sre_stream_result_t *h_sres, *d_sres;
-    /* large chunks: a ring of pinned pieces the copy pool fills while the DMA engine drains it */
-    uint8_t            *h_ring;             /* SRE_RING_SLOTS x SRE_RING_PIECE, hipHostMallocNonCoherent */
-    hipEvent_t          ev_ring[4];
     /* pinned double buffer of stage_input */
     uint8_t            *h_stage[2];
     uint8_t            *d_stage;            /* device view of h_stage[0] */
@@ -105,7 +106,7 @@ struct DeviceStream {
  * generation tags: its contexts share the program's scanners here.)
  */
 #define SRE_STREAM_CACHE_MAX 32
-#define SRE_PARK_KEEP_BYTES  (8u << 20)
+#define SRE_PARK_KEEP_BYTES  (24u << 20)
 std::mutex    g_mutex;
 DeviceStream *g_parked[SRE_STREAM_CACHE_MAX];
 int           g_nparked = 0;
@@ -118,10 +119,6 @@ device_stream_destroy(DeviceStream *ds)
     for (int b = 0; b < 2; b++) {
         if (ds->h_stage[b]) (void) hipHostFree(ds->h_stage[b]);
         if (ds->ev_stage[b]) (void) hipEventDestroy(ds->ev_stage[b]);
-    }
-    if (ds->h_ring) (void) hipHostFree(ds->h_ring);
-    for (int b = 0; b < 4; b++) {
-        if (ds->ev_ring[b]) (void) hipEventDestroy(ds->ev_ring[b]);
     }
     if (ds->d_sctx) (void) hipFree(ds->d_sctx);
     if (ds->h_sres) (void) hipHostFree(ds->h_sres);
@@ -140,10 +137,6 @@ device_stream_release(void *data)
             (void) hipFree(ds->d_in);
             ds->d_in = NULL;
             ds->in_cap = 0;
-        }
-        if (ds->h_ring) {
-            (void) hipHostFree(ds->h_ring);     /* 16 MiB of pinned memory: not kept by a parked stream */
-            ds->h_ring = NULL;
         }
         std::lock_guard<std::mutex> lock(g_mutex);
         if (g_nparked < SRE_STREAM_CACHE_MAX) {
@@ -306,166 +299,389 @@ sre_k_pull(const uint4 *__restrict__ src, uint4 *__restrict__ dst, uint32_t n16)
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n16; i += gridDim.x * 256u) dst[i] = src[i];
 }
 
+/*
+ * The fetch of a chunk that is still being copied into the pinned ring (ring_upload): ONE launch
+ * per chunk, in flight while the CPUs copy.  The grid is SRE_FETCH_GROUPS groups of
+ * SRE_FETCH_GROUP_WGS workgroups; group g takes units g, g + GROUPS, ...: in front of a unit lane
+ * 0 of each of its workgroups waits for the unit's flag in host memory (the CPU publishes it behind
+ * the unit's last store), then the group copies the unit, four 16-byte loads in flight per lane.
+ * The groups wait for DIFFERENT units at the same time, so a flag's round trip over the link is
+ * paid once per GROUPS units, not once per unit (a first version walked the units one after the
+ * other with the whole grid: 6 us per unit, as slow as a launch per unit).  The last workgroup of
+ * a group to finish a unit says so in host memory (`ctl->done[slot]`): that frees the unit's ring
+ * slot for chunks longer than the ring.  Every wait is bounded (SRE_RING_WAIT_TICKS of the
+ * 100 MHz clock): a workgroup that gives up sets ctl->timed_out and every workgroup leaves at its
+ * next wait — the grid always drains, and the host fails the stream.
+ */
+struct sre_ring_ctl_t {
+    uint64_t flag[64];          /* per ring slot: (epoch << 32) | unit, written by the CPU when the unit is in the ring */
+    uint64_t done[64];          /* per ring slot: the same tag, written by the GPU when the unit has been fetched */
+    uint64_t timed_out;         /* set by the GPU */
+};
+#define SRE_RING_WAIT_TICKS  200000000ull   /* 2 s */
+#define SRE_FETCH_GROUPS     8u
+#define SRE_FETCH_GROUP_WGS  8u
+
+__global__ __launch_bounds__(256) void
+sre_k_ring_fetch(const uint8_t *__restrict__ ring, uint8_t *__restrict__ dst, sre_ring_ctl_t *ctl, uint32_t *__restrict__ counters,
+                 uint64_t len, uint32_t unit, uint32_t nunits, uint32_t ring_units, uint32_t epoch)
+{
+    __shared__ uint32_t sh_go;
+    const uint32_t group = blockIdx.x / SRE_FETCH_GROUP_WGS, member = blockIdx.x % SRE_FETCH_GROUP_WGS;
+    const uint32_t stride = SRE_FETCH_GROUP_WGS * 256u;
+    for (uint32_t u = group; u < nunits; u += SRE_FETCH_GROUPS) {
+        const uint32_t slot = u % ring_units;
+        const uint64_t tag = ((uint64_t) epoch << 32) | u;
+        if (threadIdx.x == 0) {
+            const uint64_t t0 = wall_clock64();
+            uint32_t       go = 1;
+            while (__hip_atomic_load(&ctl->flag[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != tag) {
+                if (__hip_atomic_load(&ctl->timed_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0
+                    || wall_clock64() - t0 > SRE_RING_WAIT_TICKS)
+                {
+                    __hip_atomic_store(&ctl->timed_out, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    go = 0;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(4);
+            }
+            sh_go = go;
+        }
+        __syncthreads();
+        if (!sh_go) return;
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);        /* nothing of the slot's previous content is kept */
+        const uint64_t off = (uint64_t) u * unit;
+        const uint32_t n16 = (uint32_t) (((len - off < unit ? len - off : unit) + 15) / 16);
+        const uint4   *s = reinterpret_cast<const uint4 *>(ring + (size_t) slot * unit);
+        uint4         *d = reinterpret_cast<uint4 *>(dst + off);
+        uint32_t       i = member * 256u + threadIdx.x;
+        for (; i + 3 * stride < n16; i += 4 * stride) {
+            const uint4 a = s[i], b = s[i + stride], c = s[i + 2 * stride], e = s[i + 3 * stride];
+            d[i] = a;
+            d[i + stride] = b;
+            d[i + 2 * stride] = c;
+            d[i + 3 * stride] = e;
+        }
+        for (; i < n16; i += stride) d[i] = s[i];
+        if (nunits > ring_units) {
+            /* the slot is reused: say when the whole group is through with the unit */
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                __threadfence();
+                if (atomicAdd(&counters[slot], 1u) == SRE_FETCH_GROUP_WGS - 1) {
+                    counters[slot] = 0;
+                    __hip_atomic_store(&ctl->done[slot], tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            }
+        }
+    }
+}
+
 #define SRE_STAGE_PIECE   (2u << 20)
 #define SRE_STAGE_MIN     (64u << 10)
-#define SRE_RING_SLOTS    4u
-#define SRE_RING_PIECE    (4u << 20)        /* one transfer: the link reaches its rate from ~4 MiB on (2 MiB: 45 GB/s) */
-#define SRE_RING_UNIT     (1u << 20)        /* one thread's copy: a transfer's four units are copied side by side */
-#define SRE_RING_MIN      (8u << 20)        /* chunks from here on go through the ring */
+#define SRE_RING_BYTES    (16u << 20)       /* the process-wide pinned ring */
+#define SRE_RING_MIN      (512u << 10)      /* chunks from here on go through it */
+#define SRE_RING_SPIN_US  300               /* a helper polls this long for the next chunk before it sleeps */
 
 /*
- * Large chunks (round 3).  The runtime's own path for a pageable source is erratic on this pool —
- * 55 GB/s in a copy loop of its own (tools/exp/h2d_ring.cpp), 4-27 GB/s inside a stream's calls
- * (profiles/r02_stream_rate.json, r03) — so the chunk travels through a ring of pinned 4 MiB
- * buffers: helper threads copy 1 MiB units into the slots (one core copies ~30 GB/s, four ~55)
- * while the DMA engine drains the slots that are complete on the context's stream — the copy of
- * the chunk's tail overlaps the transfer of its head inside ONE synchronous call.  The pool is
- * process-wide, started on first use, and sleeps between calls.
+ * Larger chunks (round 3).  A chunk in the caller's pageable memory has to be copied once by
+ * the CPU (one core: 22-30 GB/s) and fetched once over the link (~54 GB/s); done one after the
+ * other, and in front of the scan, that was 9 GB/s for 1 MiB chunks and 22 GB/s for 16 MiB
+ * (profiles/r03_stream_rate.json, first build; the runtime's own path for pageable sources is
+ * erratic on this pool: 55 GB/s in a loop of its own, 4-27 GB/s inside a stream's calls).  Now
+ * the chunk is cut into UNITS (128 KiB .. 1 MiB): sre_k_ring_fetch is launched FIRST, then a
+ * small pool of helper threads and the caller copy units side by side into ONE process-wide
+ * pinned ring and publish a flag per unit; the kernel fetches every unit as soon as its flag is
+ * up — the GPU fetches the head of the chunk while the CPUs copy its tail, one launch per chunk,
+ * on the context's own queue in front of the scan.  (A launch per unit: ~6 us each, in a row; the
+ * DMA engine: ~10 us per transfer and a queue-to-engine dependency in front of the scan.)  A ring
+ * slot is reused (chunks above 16 MiB) when the kernel reports the unit it held as fetched.  The
+ * helpers poll for the next chunk for SRE_RING_SPIN_US after one (a stream's calls come
+ * back-to-back; waking a sleeping thread costs 30-60 us, a 1 MiB chunk's whole budget), then
+ * sleep; SRE_HIP_COPY_THREADS=0 leaves everything to the caller's thread.  One chunk at a time
+ * goes through the ring (g_copy_mutex); a chunk of ANOTHER context first waits for the fetch of
+ * the previous one (last_ev).
  */
 namespace {
 
+/* host copy into a pinned buffer the GPU reads next: streaming stores, so that the lines go to
+ * memory instead of sitting dirty in this core's cache (the device's reads of freshly written
+ * lines were served out of the CPU caches at ~36 GB/s; from memory the link runs at ~50) and
+ * are not read first (no read-for-ownership).  dst is 64-byte aligned. */
+inline void
+copy_streaming(uint8_t *dst, const uint8_t *src, size_t n)
+{
+#if defined(__x86_64__)
+    size_t i = 0;
+    for (; i + 64 <= n; i += 64) {
+        const __m128i a = _mm_loadu_si128(reinterpret_cast<const __m128i *>(src + i));
+        const __m128i b = _mm_loadu_si128(reinterpret_cast<const __m128i *>(src + i + 16));
+        const __m128i c = _mm_loadu_si128(reinterpret_cast<const __m128i *>(src + i + 32));
+        const __m128i d = _mm_loadu_si128(reinterpret_cast<const __m128i *>(src + i + 48));
+        _mm_stream_si128(reinterpret_cast<__m128i *>(dst + i), a);
+        _mm_stream_si128(reinterpret_cast<__m128i *>(dst + i + 16), b);
+        _mm_stream_si128(reinterpret_cast<__m128i *>(dst + i + 32), c);
+        _mm_stream_si128(reinterpret_cast<__m128i *>(dst + i + 48), d);
+    }
+    if (i < n) memcpy(dst + i, src + i, n - i);
+    _mm_sfence();
+#else
+    memcpy(dst, src, n);
+#endif
+}
+
+struct CopyJob {
+    const uint8_t *src;
+    size_t         len, unit, nunits, ring_units;
+    uint32_t       epoch;
+};
+
 struct CopyPool {
-    std::mutex              m;
-    std::condition_variable cv_work;
+    std::mutex               m;
+    std::condition_variable  cv_work;
     std::vector<std::thread> threads;
-    /* the job in flight (one at a time: g_copy_mutex) */
-    const uint8_t          *src = nullptr;
-    uint8_t                *ring = nullptr;
-    size_t                  len = 0, nunits = 0;
-    std::atomic<size_t>     next{0};            /* next unit to copy */
-    std::atomic<size_t>     freed{0};           /* transfers whose slot may be overwritten: piece < freed + SLOTS */
-    std::atomic<uint64_t>   ready[64];          /* per unit (mod 64): (epoch, unit) once its copy is complete */
-    uint32_t                epoch = 0;
-    bool                    stop = false;
-    uint64_t                generation = 0;
+    CopyJob                  job{};                 /* written under m */
+    std::atomic<uint64_t>    generation{0};
+    std::atomic<int>         parked{0};
+    std::atomic<uint64_t>    next{0};               /* (epoch << 32) | next unit to copy */
+    bool                     stop = false;
+    uint8_t                 *h_ring = nullptr, *d_ring = nullptr;
+    sre_ring_ctl_t          *h_ctl = nullptr, *d_ctl = nullptr;     /* pinned: unit flags (CPU -> GPU), progress (GPU -> CPU) */
+    uint32_t                *d_counters = nullptr;                  /* per slot: workgroups through with the unit */
+    int                      device = -1;
+    hipEvent_t               last_ev = nullptr;     /* behind the fetch of the previous chunk */
+    bool                     last_ev_set = false;
+
+    /* may unit u of job j be written into its ring slot?  (the unit that held it has been fetched) */
+    bool slot_free(const CopyJob &j, size_t u) const
+    {
+        return u < j.ring_units
+               || __atomic_load_n(&h_ctl->done[u % j.ring_units], __ATOMIC_ACQUIRE) == (((uint64_t) j.epoch << 32) | (uint32_t) (u - j.ring_units));
+    }
+
+    /* copy units of job `j` until none is left (or `max_units` are done).  helper == false (the
+     * caller's thread, which is also the one that frees slots): never take a unit whose slot is
+     * still being fetched */
+    void run(const CopyJob &j, size_t max_units, bool helper)
+    {
+        for (size_t done = 0; done < max_units; done++) {
+            uint64_t cur = next.load(std::memory_order_acquire);
+            for (;;) {
+                if ((uint32_t) (cur >> 32) != j.epoch || (uint32_t) cur >= j.nunits) return;
+                if (!helper && !slot_free(j, (uint32_t) cur)) return;
+                if (next.compare_exchange_weak(cur, cur + 1, std::memory_order_acq_rel)) break;
+            }
+            const size_t u = (uint32_t) cur;
+            while (!slot_free(j, u)) {
+                /* the slot is still being fetched */
+                if (__atomic_load_n(&h_ctl->timed_out, __ATOMIC_RELAXED)) break;    /* (the chunk is lost anyway) */
+#if defined(__x86_64__)
+                __builtin_ia32_pause();
+#endif
+            }
+            const size_t off = u * j.unit, n = j.len - off < j.unit ? j.len - off : j.unit;
+            copy_streaming(h_ring + (u % j.ring_units) * j.unit, j.src + off, n);
+            __atomic_store_n(&h_ctl->flag[u % j.ring_units], ((uint64_t) j.epoch << 32) | (uint32_t) u, __ATOMIC_RELEASE);
+        }
+    }
 
     void worker()
     {
         uint64_t seen = 0;
         for (;;) {
-            {
-                std::unique_lock<std::mutex> lk(m);
-                cv_work.wait(lk, [&] { return stop || generation != seen; });
-                if (stop) return;
-                seen = generation;
-            }
-            run();
-        }
-    }
-    /* copy units until none is left */
-    void run()
-    {
-        constexpr size_t UPP = SRE_RING_PIECE / SRE_RING_UNIT;
-        for (;;) {
-            const size_t u = next.fetch_add(1);
-            if (u >= nunits) return;
-            while (u / UPP >= freed.load(std::memory_order_acquire) + SRE_RING_SLOTS) {
-                /* the slot is still being drained */
+            const auto t0 = std::chrono::steady_clock::now();
+            uint32_t   polls = 0;
+            while (generation.load(std::memory_order_acquire) == seen) {
 #if defined(__x86_64__)
                 __builtin_ia32_pause();
 #endif
+                if ((++polls & 255u) == 0
+                    && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(SRE_RING_SPIN_US))
+                {
+                    std::unique_lock<std::mutex> lk(m);
+                    parked.fetch_add(1);
+                    cv_work.wait(lk, [&] { return stop || generation.load() != seen; });
+                    parked.fetch_sub(1);
+                    break;
+                }
             }
-            const size_t off = u * (size_t) SRE_RING_UNIT, n = len - off < SRE_RING_UNIT ? len - off : SRE_RING_UNIT;
-            memcpy(ring + off % ((size_t) SRE_RING_SLOTS * SRE_RING_PIECE), src + off, n);
-            ready[u % 64].store(((uint64_t) epoch << 32) | (uint32_t) u, std::memory_order_release);
+            CopyJob j;
+            {
+                std::lock_guard<std::mutex> lk(m);
+                if (stop) return;
+                j = job;
+                seen = generation.load();
+            }
+            run(j, ~(size_t) 0, true);
         }
     }
 };
 
 CopyPool  *g_copy_pool;
-std::mutex g_copy_mutex;        /* one chunk at a time through the pool */
+std::mutex g_copy_mutex;        /* one chunk at a time through the ring */
 
 int
 copy_threads()
 {
     const char *e = getenv("SRE_HIP_COPY_THREADS");
-    /* never more than the machine has to spare */
+    /* never more than the machine has to spare (the caller's thread copies too) */
     const int   hw = (int) std::thread::hardware_concurrency();
-    const int   n = e ? atoi(e) : (hw >= 8 ? 4 : hw >= 4 ? 2 : 1);
+    const int   n = e ? atoi(e) : (hw >= 8 ? 3 : hw >= 4 ? 1 : 0);
     return n < 0 ? 0 : n > 8 ? 8 : n;
 }
 
-/* the chunk -> ds->d_in, queued on ds->stream; returns when every piece has been handed to the DMA engine */
+/* a chunk on its way through the ring: between ring_begin and ring_finish the caller may queue the
+ * kernels that consume ds->d_in behind the fetch (their launch latency passes while the CPUs copy) */
+struct RingTicket {
+    std::unique_lock<std::mutex> lock;      /* g_copy_mutex */
+    CopyJob                      j;
+    DeviceStream                *ds = nullptr;
+    bool                         active = false;
+};
+
+int ring_finish(RingTicket &t);
+
+/* the chunk -> ds->d_in by a kernel queued on ds->stream; the helpers are copying on return.
+ * 0: under way, ring_finish() must follow; 1: not taken; -1: failed */
+int
+ring_begin(DeviceStream *ds, const sre_char *input, size_t len, RingTicket &t)
+{
+    t.lock = std::unique_lock<std::mutex>(g_copy_mutex);
+    if (g_copy_pool == NULL) {
+        CopyPool *P = new CopyPool();
+        /* read by a kernel while the CPU writes other parts of it: the coherent (fine-grained) kind */
+        if (hipHostMalloc(reinterpret_cast<void **>(&P->h_ring), SRE_RING_BYTES, hipHostMallocMapped) != hipSuccess
+            || hipHostGetDevicePointer(reinterpret_cast<void **>(&P->d_ring), P->h_ring, 0) != hipSuccess
+            || hipHostMalloc(reinterpret_cast<void **>(&P->h_ctl), sizeof(sre_ring_ctl_t), hipHostMallocMapped) != hipSuccess
+            || hipHostGetDevicePointer(reinterpret_cast<void **>(&P->d_ctl), P->h_ctl, 0) != hipSuccess
+            || hipMalloc(reinterpret_cast<void **>(&P->d_counters), 64 * sizeof(uint32_t)) != hipSuccess
+            || hipMemset(P->d_counters, 0, 64 * sizeof(uint32_t)) != hipSuccess
+            || hipEventCreateWithFlags(&P->last_ev, hipEventDisableTiming) != hipSuccess)
+        {
+            t.lock.unlock();
+            return -1;      /* (what was allocated stays with the never-used pool object: a dead device) */
+        }
+        memset(P->h_ctl, 0xff, sizeof(P->h_ctl->flag));
+        memset(P->h_ctl->done, 0xff, sizeof(P->h_ctl->done));
+        P->h_ctl->timed_out = 0;
+        P->device = ds->device;
+        g_copy_pool = P;
+        const int nt = copy_threads();
+        for (int i = 0; i < nt; i++) P->threads.emplace_back([P] { P->worker(); });
+    }
+    CopyPool &P = *g_copy_pool;
+    if (P.device != ds->device) {                   /* (one process drives one GPU; another device: the plain path) */
+        t.lock.unlock();
+        return 1;
+    }
+    /* the previous chunk's fetch reads the ring: a chunk of the same context has seen it finish
+     * (exec is synchronous), another context's may still run */
+    if ((P.last_ev_set && hipEventSynchronize(P.last_ev) != hipSuccess)
+        || __atomic_load_n(&P.h_ctl->timed_out, __ATOMIC_RELAXED))            /* a fetch gave up: the ring is not trusted again */
+    {
+        t.lock.unlock();
+        return -1;
+    }
+
+    CopyJob j;
+    j.src = input;
+    j.len = len;
+    /* small units for small chunks: the fetch of the first ones starts while the rest is copied */
+    j.unit = len <= (2u << 20) ? (128u << 10) : len <= (8u << 20) ? (256u << 10) : (1u << 20);
+    j.nunits = (len + j.unit - 1) / j.unit;
+    j.ring_units = SRE_RING_BYTES / j.unit < 64 ? SRE_RING_BYTES / j.unit : 64;
+    {
+        std::lock_guard<std::mutex> lk(P.m);
+        j.epoch = P.job.epoch + 1;
+        P.job = j;
+        P.next.store((uint64_t) j.epoch << 32, std::memory_order_release);
+    }
+    /* the helpers start copying ... */
+    {
+        std::lock_guard<std::mutex> lk(P.m);
+        P.generation.fetch_add(1, std::memory_order_release);
+    }
+    if (P.parked.load() > 0) P.cv_work.notify_all();
+    /* ... while the fetch is launched (it finds the first flags up, or waits for them) */
+    {
+        /* few workgroups walking a unit with a grid stride: 54 GB/s; one 16-byte access per lane
+         * over as many workgroups as that takes: 37-50 GB/s (tools/exp/pull_rate.cpp) */
+        hipLaunchKernelGGL(sre_k_ring_fetch, dim3(SRE_FETCH_GROUPS * SRE_FETCH_GROUP_WGS), dim3(256), 0, ds->stream, P.d_ring,
+                           static_cast<uint8_t *>(ds->d_in), P.d_ctl, P.d_counters, (uint64_t) len, (uint32_t) j.unit,
+                           (uint32_t) j.nunits, (uint32_t) j.ring_units, j.epoch);
+        const bool launched = hipGetLastError() == hipSuccess;
+        P.last_ev_set = launched && hipEventRecord(P.last_ev, ds->stream) == hipSuccess;
+        t.j = j;
+        t.ds = ds;
+        t.active = true;
+        if (!launched) {
+            /* nothing reads the ring: let the copies run dry (they touch the ring and the caller's
+             * chunk only), then give the chunk to the plain path */
+            (void) ring_finish(t);
+            return 1;
+        }
+    }
+    return 0;
+}
+
+/* the caller's share of the copies; returns when every unit is in the ring (the fetch is at most a
+ * few units behind) */
+int
+ring_finish(RingTicket &t)
+{
+    if (!t.active) return 0;
+    CopyPool      &P = *g_copy_pool;
+    const CopyJob &j = t.j;
+    DeviceStream  *ds = t.ds;
+    for (size_t u = 0; u < j.nunits; u++) {
+        /* (a slot's tags only grow within a chunk: the flag of unit u may already be that of unit
+         * u + ring_units when the fetch and the helpers are ahead of this loop) */
+        for (;;) {
+            const uint64_t f = __atomic_load_n(&P.h_ctl->flag[u % j.ring_units], __ATOMIC_ACQUIRE);
+            if ((uint32_t) (f >> 32) == j.epoch && (uint32_t) f >= u) break;
+            P.run(j, 1, false);     /* returns at once when every unit is taken (or none has a free slot) */
+            if (__atomic_load_n(&P.h_ctl->timed_out, __ATOMIC_RELAXED)) break;
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        }
+    }
+    int rc = 0;
+    if (!P.last_ev_set) rc = hipStreamSynchronize(ds->stream) == hipSuccess ? 0 : -1;
+    if (__atomic_load_n(&P.h_ctl->timed_out, __ATOMIC_RELAXED)) {
+        fprintf(stderr, "[sregex-hip] the fetch of a chunk gave up waiting for the host copy\n");
+        (void) hipStreamSynchronize(ds->stream);
+        rc = -1;
+    }
+    t.active = false;
+    t.lock.unlock();
+    return rc;
+}
+
 int
 ring_upload(DeviceStream *ds, const sre_char *input, size_t len)
 {
-    constexpr size_t UPP = SRE_RING_PIECE / SRE_RING_UNIT;
-    if (ds->h_ring == NULL) {
-        if (hipHostMalloc(reinterpret_cast<void **>(&ds->h_ring), (size_t) SRE_RING_SLOTS * SRE_RING_PIECE,
-                          hipHostMallocNonCoherent) != hipSuccess)
-        {
-            ds->h_ring = NULL;
-            return -1;
-        }
-        for (uint32_t b = 0; b < SRE_RING_SLOTS; b++) {
-            if (hipEventCreateWithFlags(&ds->ev_ring[b], hipEventDisableTiming) != hipSuccess) return -1;
-        }
-    }
-    std::lock_guard<std::mutex> job(g_copy_mutex);
-    if (g_copy_pool == NULL) {
-        g_copy_pool = new CopyPool();
-        for (int i = 0; i < 64; i++) g_copy_pool->ready[i].store(~0ull);
-        const int nt = copy_threads();
-        for (int i = 0; i < nt; i++) g_copy_pool->threads.emplace_back([] { g_copy_pool->worker(); });
-    }
-    CopyPool &P = *g_copy_pool;
-    const size_t npieces = (len + SRE_RING_PIECE - 1) / SRE_RING_PIECE;
-    {
-        std::lock_guard<std::mutex> lk(P.m);
-        P.src = input;
-        P.ring = ds->h_ring;
-        P.len = len;
-        P.nunits = (len + SRE_RING_UNIT - 1) / SRE_RING_UNIT;
-        P.epoch++;
-        P.next.store(0);
-        P.freed.store(0);
-        P.generation++;
-    }
-    P.cv_work.notify_all();
-    int    rc = 0;
-    size_t drained = 0;         /* transfers that have completed */
-    for (size_t p = 0; p < npieces; p++) {
-        const size_t u_end = (p + 1) * UPP < P.nunits ? (p + 1) * UPP : P.nunits;
-        for (size_t u = p * UPP; u < u_end; u++) {
-            /* no helpers (SRE_HIP_COPY_THREADS=0): the caller copies */
-            while (P.ready[u % 64].load(std::memory_order_acquire) != (((uint64_t) P.epoch << 32) | (uint32_t) u)) {
-                if (P.threads.empty()) {
-                    P.run();
-                } else {
-#if defined(__x86_64__)
-                    __builtin_ia32_pause();
-#endif
-                }
-            }
-        }
-        const size_t off = p * (size_t) SRE_RING_PIECE, n = len - off < SRE_RING_PIECE ? len - off : SRE_RING_PIECE;
-        if (rc == 0
-            && (hipMemcpyAsync(static_cast<uint8_t *>(ds->d_in) + off, ds->h_ring + (p % SRE_RING_SLOTS) * (size_t) SRE_RING_PIECE,
-                               n, hipMemcpyHostToDevice, ds->stream) != hipSuccess
-                || hipEventRecord(ds->ev_ring[p % SRE_RING_SLOTS], ds->stream) != hipSuccess))
-        {
-            rc = -1;            /* keep the ring turning so that the helpers finish */
-        }
-        /* free the slots whose transfer is over; wait for the oldest one when the ring is full */
-        while (drained <= p) {
-            const size_t q = drained;
-            const bool   must = (p + 1 - drained) >= SRE_RING_SLOTS && p + 1 < npieces;
-            if (rc == 0) {
-                hipError_t e = must ? hipEventSynchronize(ds->ev_ring[q % SRE_RING_SLOTS]) : hipEventQuery(ds->ev_ring[q % SRE_RING_SLOTS]);
-                if (e == hipErrorNotReady) break;
-                if (e != hipSuccess) rc = -1;
-            }
-            drained++;
-            P.freed.store(drained, std::memory_order_release);
-        }
-    }
-    return rc;
+    RingTicket t;
+    const int  r = ring_begin(ds, input, len, t);
+    return r != 0 ? r : ring_finish(t);
+}
+
+/* called by sre_hip_scan_stream_chunk between its launches and its wait */
+void
+ring_midway(void *arg)
+{
+    RingTicket *t = static_cast<RingTicket *>(arg);
+    if (!t->active) return;
+    DeviceStream *ds = t->ds;
+    if (ring_finish(*t) != 0) t->ds = ds + 1;       /* (marks the failure for the caller) */
 }
 
 }  // namespace
 
+/* `ticket`: a chunk that goes through the ring is only STARTED (ring_begin); the caller queues
+ * its kernels and calls ring_finish(*ticket) before it waits for them */
 static int
-stage_input(DeviceStream *ds, const sre_char *input, size_t len)
+stage_input(DeviceStream *ds, const sre_char *input, size_t len, RingTicket *ticket = nullptr)
 {
     if (len > ds->in_cap) {
         if (ds->d_in) (void) hipFree(ds->d_in);
@@ -477,8 +693,12 @@ stage_input(DeviceStream *ds, const sre_char *input, size_t len)
     if (len == 0) return 0;
     static const bool use_ring = getenv("SRE_HIP_NO_RING") == NULL;
     if (len >= SRE_RING_MIN && use_ring) {
-        if (ring_upload(ds, input, len) == 0) return 0;
-        return -1;
+        /* (without helper threads the copies are the caller's alone: they come first — a
+         * device-wide wait inside the scan's set-up would otherwise wait for a fetch that waits
+         * for the caller) */
+        static const bool helpers = copy_threads() > 0;
+        const int r = ticket && helpers ? ring_begin(ds, input, len, *ticket) : ring_upload(ds, input, len);
+        if (r <= 0) return r;
     }
     if (len < SRE_STAGE_MIN || len > SRE_STAGE_PIECE) {
         return hipMemcpyAsync(ds->d_in, input, len, hipMemcpyHostToDevice, ds->stream) == hipSuccess ? 0 : -1;
@@ -497,12 +717,16 @@ stage_input(DeviceStream *ds, const sre_char *input, size_t len)
             return -1;
         }
     }
-    memcpy(ds->h_stage[0], input, len);
+    if (pull) {
+        copy_streaming(ds->h_stage[0], input, len);
+    } else {
+        memcpy(ds->h_stage[0], input, len);
+    }
     if (pull) {
         /* the GPU fetches the buffer itself: a kernel in front of the scan on the same queue
          * instead of a DMA-engine copy the scan has to be synchronised with */
         const uint32_t n16 = (uint32_t) ((len + 15) / 16);
-        hipLaunchKernelGGL(sre_k_pull, dim3((n16 + 1023) / 1024 < 256 ? (n16 + 1023) / 1024 : 256), dim3(256), 0,
+        hipLaunchKernelGGL(sre_k_pull, dim3((n16 + 1023) / 1024 < 64 ? (n16 + 1023) / 1024 : 64), dim3(256), 0,
                            ds->stream, reinterpret_cast<const uint4 *>(ds->d_stage), static_cast<uint4 *>(ds->d_in), n16);
         return hipGetLastError() == hipSuccess ? 0 : -1;
     }
@@ -704,7 +928,9 @@ pike_stream_route(sre_vm_pike_ctx_t *ctx, sre_char *input, size_t len, unsigned 
     }
     static const bool dbg_t = getenv("SRE_HIP_DEBUG_TIMING") != NULL;
     const auto t_a = std::chrono::steady_clock::now();
-    if (stage_input(ds, input, len) != 0) return 0;
+    /* (a chunk that travels through the ring is still being copied when the scan is queued) */
+    RingTicket ticket;
+    if (stage_input(ds, input, len, dbg_t ? nullptr : &ticket) != 0) return 0;
     const auto t_b = std::chrono::steady_clock::now();
     if (dbg_t) {
         (void) hipStreamSynchronize(ds->stream);
@@ -721,7 +947,8 @@ pike_stream_route(sre_vm_pike_ctx_t *ctx, sre_char *input, size_t len, unsigned 
     if (sre_hip_scan_stream_chunk(sc, static_cast<const uint8_t *>(ds->d_in) + skip, len - skip, variant,
                                   ctx->stream_mode, entry, eof ? 1 : 0,
                                   (int64_t) ctx->processed_bytes + (int64_t) skip, ds->d_sctx, ds->d_sres, ds->h_sres,
-                                  (uint32_t) ctx->ovec_slots, ds->stream) != 0)
+                                  (uint32_t) ctx->ovec_slots, ds->stream, ring_midway, &ticket) != 0
+        || ticket.ds == ds + 1)     /* (ring_midway marks a failed copy) */
     {
         ds->failed = 1;
         *prc = SRE_ERROR;
@@ -944,10 +1171,12 @@ thompson_stream_route(sre_vm_thompson_ctx_t *ctx, sre_char *input, size_t len, u
             return 0;
         }
     }
-    if (stage_input(ds, input, len) != 0) return 0;
+    RingTicket ticket;
+    if (stage_input(ds, input, len, &ticket) != 0) return 0;
     ds->h_sres->rc = SRE_STREAM_PENDING;
     if (sre_hip_scan_stream_chunk(sc, ds->d_in, len, 0, ctx->stream_mode, ctx->stream_state, eof ? 1 : 0, 0,
-                                  ds->d_sctx, ds->d_sres, ds->h_sres, 0, ds->stream) != 0)
+                                  ds->d_sctx, ds->d_sres, ds->h_sres, 0, ds->stream, ring_midway, &ticket) != 0
+        || ticket.ds == ds + 1)
     {
         ds->failed = 1;
         *prc = SRE_ERROR;

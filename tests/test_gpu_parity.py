@@ -751,6 +751,52 @@ def test_compat_api_chunked_streams_take_the_scanner(gpu):
             assert res[0] == res[1], (pats, res[0][:3], res[1][:3])
 
 
+def test_compat_api_large_chunks_arrive_intact(gpu):
+    """Chunks of 512 KiB and more travel through the pinned ring (sre_vm_api.cpp ring_upload:
+    units copied by several threads, fetched by the GPU as they complete, slots reused above
+    16 MiB).  A 40 MiB stream with one marker per 256 KiB unit at an offset that differs from
+    unit to unit — the first and last byte of a unit among them — is searched to its end through
+    sre_vm_pike_exec (re-fed from every match end, like the reference's clients): every match
+    position must be the marker's, for chunk sizes that are no multiple of anything, with
+    helper threads and without."""
+    import numpy as np
+    total, unit = 40 << 20, 256 << 10
+    arr = np.full(total, ord("a"), dtype=np.uint8)
+    want = []
+    for k in range(total // unit):
+        o = [0, unit - 1, (k * 7919 + 13) % unit][k % 3] if k % 5 else (k * 104729) % unit
+        if k * unit + o == 0:
+            o = 5
+        arr[k * unit + o] = ord("q")
+        want.append(k * unit + o)
+    data = arr.tobytes()
+    buf = ctypes.create_string_buffer(data, total)
+    for step in ((512 << 10) + 3, (5 << 20) + 1, (17 << 20) + 5, total):
+        with S.Pool() as pool:
+            re = S.parse(pool, [b"q"])
+            prog = S.compile(pool, re)
+            got = []
+            with S.Pool() as ep:
+                ctx = S.PikeCtx(ep, prog, re.ncaps)
+                off = 0                 # absolute offset of the next byte to feed
+                edge = min(step, total) # end of the caller's current chunk
+                while True:
+                    eof = edge >= total
+                    rc = ctx.exec(None, eof, want_pending=False, base=buf, offset=off, length=edge - off)
+                    if rc == S.SRE_AGAIN:
+                        off, edge = edge, min(edge + step, total)
+                        continue
+                    if rc == S.SRE_DECLINED:
+                        break
+                    assert rc == 0, rc
+                    got.append(ctx.ovector[0])
+                    assert ctx.ovector[1] == ctx.ovector[0] + 1
+                    off = ctx.ovector[1]
+                    if off >= edge and not eof:
+                        edge = min(edge + step, total)
+            assert got == want, (step, len(got), len(want), [(a, b) for a, b in zip(got, want) if a != b][:4])
+
+
 def test_compat_api_chunked_stream_rate(gpu):
     """A 256 MiB stream through sre_vm_pike_exec in 1 MiB chunks (host memory): same final
     answer as one whole-buffer call; the sustained rate is printed and written to
@@ -773,15 +819,22 @@ def test_compat_api_chunked_stream_rate(gpu):
                 ctx = S.PikeCtx(ep, prog, re.ncaps)
                 buf = ctypes.create_string_buffer(data, L)
                 t0 = time.perf_counter()
-                off, rc, calls = 0, S.SRE_AGAIN, 0
+                off, rc, calls, per_call = 0, S.SRE_AGAIN, 0, []
                 while rc == S.SRE_AGAIN:
                     n = min(step, L - off)
+                    t1 = time.perf_counter()
                     rc = ctx.exec(None, off + n >= L, want_pending=False, base=buf, offset=off, length=n)
+                    per_call.append(time.perf_counter() - t1)
                     off += n
                     calls += 1
                 dt = time.perf_counter() - t0
                 assert rc == 0 and list(ctx.ovector) == [L - 9, L - 1], (name, rc, list(ctx.ovector))
-                rows[name] = {"calls": calls, "seconds": dt, "GBps": L / dt / 1e9}
+                per_call.sort()
+                med = per_call[len(per_call) // 2]
+                # GBps: the whole stream, the context's set-up (its first call) included; the
+                # steady state of a long stream is the median call
+                rows[name] = {"calls": calls, "seconds": dt, "GBps": L / dt / 1e9, "median_call_us": med * 1e6,
+                              "first_call_us_max": per_call[-1] * 1e6, "GBps_median_call": step / med / 1e9}
                 print(name, rows[name])
     out = os.path.join(harness.ROOT, "gpurun_out")
     os.makedirs(out, exist_ok=True)
