@@ -317,6 +317,7 @@ struct sre_ring_ctl_t {
     uint64_t flag[64];          /* per ring slot: (epoch << 32) | unit, written by the CPU when the unit is in the ring */
     uint64_t done[64];          /* per ring slot: the same tag, written by the GPU when the unit has been fetched */
     uint64_t timed_out;         /* set by the GPU */
+    uint64_t chunk_done;        /* epoch of the last chunk the GPU has fetched completely (or given up on) */
 };
 #define SRE_RING_WAIT_TICKS  200000000ull   /* 2 s */
 #define SRE_FETCH_GROUPS     8u
@@ -329,6 +330,18 @@ sre_k_ring_fetch(const uint8_t *__restrict__ ring, uint8_t *__restrict__ dst, sr
     __shared__ uint32_t sh_go;
     const uint32_t group = blockIdx.x / SRE_FETCH_GROUP_WGS, member = blockIdx.x % SRE_FETCH_GROUP_WGS;
     const uint32_t stride = SRE_FETCH_GROUP_WGS * 256u;
+    /* the last workgroup to leave says that nothing reads the ring any more (another context's
+     * chunk may then use it: ring_begin) */
+    auto leave = [&]() {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence();
+            if (atomicAdd(&counters[64], 1u) == gridDim.x - 1) {
+                counters[64] = 0;
+                __hip_atomic_store(&ctl->chunk_done, (uint64_t) epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    };
     for (uint32_t u = group; u < nunits; u += SRE_FETCH_GROUPS) {
         const uint32_t slot = u % ring_units;
         const uint64_t tag = ((uint64_t) epoch << 32) | u;
@@ -348,7 +361,10 @@ sre_k_ring_fetch(const uint8_t *__restrict__ ring, uint8_t *__restrict__ dst, sr
             sh_go = go;
         }
         __syncthreads();
-        if (!sh_go) return;
+        if (!sh_go) {
+            leave();
+            return;
+        }
         __atomic_thread_fence(__ATOMIC_ACQUIRE);        /* nothing of the slot's previous content is kept */
         const uint64_t off = (uint64_t) u * unit;
         const uint32_t n16 = (uint32_t) (((len - off < unit ? len - off : unit) + 15) / 16);
@@ -375,6 +391,7 @@ sre_k_ring_fetch(const uint8_t *__restrict__ ring, uint8_t *__restrict__ dst, sr
             }
         }
     }
+    leave();
 }
 
 #define SRE_STAGE_PIECE   (2u << 20)
@@ -400,7 +417,7 @@ sre_k_ring_fetch(const uint8_t *__restrict__ ring, uint8_t *__restrict__ dst, sr
  * back-to-back; waking a sleeping thread costs 30-60 us, a 1 MiB chunk's whole budget), then
  * sleep; SRE_HIP_COPY_THREADS=0 leaves everything to the caller's thread.  One chunk at a time
  * goes through the ring (g_copy_mutex); a chunk of ANOTHER context first waits for the fetch of
- * the previous one (last_ev).
+ * the previous one (ctl->chunk_done).
  */
 namespace {
 
@@ -449,8 +466,7 @@ struct CopyPool {
     sre_ring_ctl_t          *h_ctl = nullptr, *d_ctl = nullptr;     /* pinned: unit flags (CPU -> GPU), progress (GPU -> CPU) */
     uint32_t                *d_counters = nullptr;                  /* per slot: workgroups through with the unit */
     int                      device = -1;
-    hipEvent_t               last_ev = nullptr;     /* behind the fetch of the previous chunk */
-    bool                     last_ev_set = false;
+    uint32_t                 last_epoch = 0;        /* the previous chunk's epoch (0: no fetch was launched) */
 
     /* may unit u of job j be written into its ring slot?  (the unit that held it has been fetched) */
     bool slot_free(const CopyJob &j, size_t u) const
@@ -554,9 +570,8 @@ ring_begin(DeviceStream *ds, const sre_char *input, size_t len, RingTicket &t)
             || hipHostGetDevicePointer(reinterpret_cast<void **>(&P->d_ring), P->h_ring, 0) != hipSuccess
             || hipHostMalloc(reinterpret_cast<void **>(&P->h_ctl), sizeof(sre_ring_ctl_t), hipHostMallocMapped) != hipSuccess
             || hipHostGetDevicePointer(reinterpret_cast<void **>(&P->d_ctl), P->h_ctl, 0) != hipSuccess
-            || hipMalloc(reinterpret_cast<void **>(&P->d_counters), 64 * sizeof(uint32_t)) != hipSuccess
-            || hipMemset(P->d_counters, 0, 64 * sizeof(uint32_t)) != hipSuccess
-            || hipEventCreateWithFlags(&P->last_ev, hipEventDisableTiming) != hipSuccess)
+            || hipMalloc(reinterpret_cast<void **>(&P->d_counters), 65 * sizeof(uint32_t)) != hipSuccess
+            || hipMemset(P->d_counters, 0, 65 * sizeof(uint32_t)) != hipSuccess)
         {
             t.lock.unlock();
             return -1;      /* (what was allocated stays with the never-used pool object: a dead device) */
@@ -564,6 +579,7 @@ ring_begin(DeviceStream *ds, const sre_char *input, size_t len, RingTicket &t)
         memset(P->h_ctl, 0xff, sizeof(P->h_ctl->flag));
         memset(P->h_ctl->done, 0xff, sizeof(P->h_ctl->done));
         P->h_ctl->timed_out = 0;
+        P->h_ctl->chunk_done = 0;
         P->device = ds->device;
         g_copy_pool = P;
         const int nt = copy_threads();
@@ -575,10 +591,19 @@ ring_begin(DeviceStream *ds, const sre_char *input, size_t len, RingTicket &t)
         return 1;
     }
     /* the previous chunk's fetch reads the ring: a chunk of the same context has seen it finish
-     * (exec is synchronous), another context's may still run */
-    if ((P.last_ev_set && hipEventSynchronize(P.last_ev) != hipSuccess)
-        || __atomic_load_n(&P.h_ctl->timed_out, __ATOMIC_RELAXED))            /* a fetch gave up: the ring is not trusted again */
-    {
+     * (exec is synchronous), another context's may still run — its last workgroup says when it is
+     * over (no event in the queue: recording one between the fetch and the scan cost 5 us a call) */
+    if (P.last_epoch != 0) {
+        const auto t0 = std::chrono::steady_clock::now();
+        uint32_t   polls = 0;
+        while ((uint32_t) __atomic_load_n(&P.h_ctl->chunk_done, __ATOMIC_ACQUIRE) != P.last_epoch) {
+            if ((++polls & 1023u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(5)) {
+                t.lock.unlock();
+                return -1;
+            }
+        }
+    }
+    if (__atomic_load_n(&P.h_ctl->timed_out, __ATOMIC_RELAXED)) {      /* a fetch gave up: the ring is not trusted again */
         t.lock.unlock();
         return -1;
     }
@@ -610,7 +635,7 @@ ring_begin(DeviceStream *ds, const sre_char *input, size_t len, RingTicket &t)
                            static_cast<uint8_t *>(ds->d_in), P.d_ctl, P.d_counters, (uint64_t) len, (uint32_t) j.unit,
                            (uint32_t) j.nunits, (uint32_t) j.ring_units, j.epoch);
         const bool launched = hipGetLastError() == hipSuccess;
-        P.last_ev_set = launched && hipEventRecord(P.last_ev, ds->stream) == hipSuccess;
+        P.last_epoch = launched ? j.epoch : 0;
         t.j = j;
         t.ds = ds;
         t.active = true;
@@ -647,7 +672,6 @@ ring_finish(RingTicket &t)
         }
     }
     int rc = 0;
-    if (!P.last_ev_set) rc = hipStreamSynchronize(ds->stream) == hipSuccess ? 0 : -1;
     if (__atomic_load_n(&P.h_ctl->timed_out, __ATOMIC_RELAXED)) {
         fprintf(stderr, "[sregex-hip] the fetch of a chunk gave up waiting for the host copy\n");
         (void) hipStreamSynchronize(ds->stream);
