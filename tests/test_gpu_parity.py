@@ -797,6 +797,63 @@ def test_compat_api_large_chunks_arrive_intact(gpu):
             assert got == want, (step, len(got), len(want), [(a, b) for a, b in zip(got, want) if a != b][:4])
 
 
+def test_compat_api_contexts_on_several_host_threads(gpu):
+    """The reference has no globals: separate programs and pools may be used from different threads
+    (SURVEY.md 8b).  Four host threads each compile their own program and stream their own 24 MiB
+    subject through sre_vm_pike_exec in chunks that travel through the ONE process-wide pinned ring
+    (1 MiB and 5 MiB + 1: ring_begin serialises the chunks and waits for the fetch of another
+    context's chunk), plus byte-sized calls on the exact VM in between.  Every thread must see its
+    own stream's answer."""
+    import threading
+    total = 24 << 20
+    errors, results = [], {}
+
+    def work(k):
+        try:
+            tail = b" a%d@abc.cc " % k
+            data = S.gen_data_host(total, tail)
+            L = len(data)
+            buf = ctypes.create_string_buffer(data, L)
+            with S.Pool() as pool:
+                re = S.parse(pool, [rb"[a-z]+[0-9]@[a-z]+\.[a-z]+" if k % 2 else rb"([a-z]+)%d@([a-z]+)\.[a-z]+" % k])
+                prog = S.compile(pool, re)
+                for step in ((1 << 20), (5 << 20) + 1):
+                    with S.Pool() as ep:
+                        ctx = S.PikeCtx(ep, prog, re.ncaps)
+                        off, rc = 0, S.SRE_AGAIN
+                        while rc == S.SRE_AGAIN:
+                            n = min(step, L - off)
+                            rc = ctx.exec(None, off + n >= L, want_pending=False, base=buf, offset=off, length=n)
+                            off += n
+                        results[(k, step)] = (rc, list(ctx.ovector[:2]), L)
+                    # a short subject in byte-sized calls: the exact VM's kernels next to the others' chunks
+                    with S.Pool() as ep:
+                        ctx = S.PikeCtx(ep, prog, re.ncaps)
+                        small = b"xx" + tail
+                        rc = S.SRE_AGAIN
+                        for i in range(len(small)):
+                            rc = ctx.exec(small[i:i + 1], i + 1 == len(small), want_pending=False)
+                            if rc != S.SRE_AGAIN:
+                                break
+                        results[(k, "bytes", step)] = (rc, list(ctx.ovector[:2]))
+        except Exception as e:      # noqa: BLE001 - reported by the main thread
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(300)
+    assert not any(t.is_alive() for t in threads), "a thread is stuck"
+    assert not errors, errors
+    for k in range(4):
+        for step in ((1 << 20), (5 << 20) + 1):
+            rc, ov, L = results[(k, step)]
+            assert rc == 0 and ov == [L - 10, L - 1], (k, step, rc, ov, L)
+            rc, ov = results[(k, "bytes", step)]
+            assert rc == 0 and ov == [3, 12], (k, step, rc, ov)
+
+
 def test_compat_api_chunked_stream_rate(gpu):
     """A 256 MiB stream through sre_vm_pike_exec in 1 MiB chunks (host memory): same final
     answer as one whole-buffer call; the sustained rate is printed and written to
