@@ -733,7 +733,9 @@ sre_k_pike_exec_wave(const sre_pwave_hdr_t *__restrict__ Wg, const sre_dev_req_t
         res->pad[0] = 16 | (vm.empty_capture ? SRE_PRESET_EMPTY_CAPTURE : 0) | (vm.seen_newline ? SRE_PRESET_SEEN_NEWLINE : 0)
                       | (vm.seen_word ? SRE_PRESET_SEEN_WORD : 0) | (vm.ctx_eof ? SRE_PRESET_EOF : 0);
         res->pad[1] = vm.processed;
-        res->rc = rc;
+        /* the host watches res->rc (device_stream_exec): written last, behind a system-scope fence */
+        __threadfence_system();
+        *reinterpret_cast<volatile int64_t *>(&res->rc) = rc;
     }
 }
 

@@ -878,12 +878,15 @@ sre_k_pike_exec(const uint8_t *__restrict__ blob, const sre_dev_req_t *__restric
 
         sre_dev_result_t *res = static_cast<sre_dev_result_t *>(rq.result);
         int64_t          *ov = reinterpret_cast<int64_t *>(res + 1);
-        res->rc = vm.exec(rq.size, rq.eof, rq.want_pending != 0, res, ov, rq.ovec_slots, &rq);
+        const int64_t     rc = vm.exec(rq.size, rq.eof, rq.want_pending != 0, res, ov, rq.ovec_slots, &rq);
         /* what the context holds between two searches (the host mirrors it after a match, so the
          * next search may run on a throughput scanner again: sre_vm_api.cpp) */
         res->pad[0] = 16 | (vm.h->empty_capture ? SRE_PRESET_EMPTY_CAPTURE : 0) | (vm.h->seen_newline ? SRE_PRESET_SEEN_NEWLINE : 0)
                       | (vm.h->seen_word ? SRE_PRESET_SEEN_WORD : 0) | (vm.h->eof ? SRE_PRESET_EOF : 0);
         res->pad[1] = vm.h->processed_bytes;
+        /* the host watches res->rc (device_stream_exec): written last, behind a system-scope fence */
+        __threadfence_system();
+        *reinterpret_cast<volatile int64_t *>(&res->rc) = rc;
     }
     if (use_lds) {
         __syncthreads();
@@ -913,7 +916,8 @@ sre_k_thompson_exec(const uint8_t *__restrict__ blob, const sre_dev_req_t *__res
                 cw[1] = S;
                 res->has_pending = 0;
                 res->consumed = 0;
-                res->rc = rc;
+                __threadfence_system();
+                *reinterpret_cast<volatile int64_t *>(&res->rc) = rc;
             }
             return;
         }
@@ -942,7 +946,9 @@ sre_k_thompson_exec(const uint8_t *__restrict__ blob, const sre_dev_req_t *__res
         sre_dev_result_t *res = static_cast<sre_dev_result_t *>(rq.result);
         res->has_pending = 0;
         res->consumed = 0;
-        res->rc = vm.exec(rq.size, rq.eof, res);
+        const int64_t rc = vm.exec(rq.size, rq.eof, res);
+        __threadfence_system();
+        *reinterpret_cast<volatile int64_t *>(&res->rc) = rc;
     }
     if (use_lds) {
         __syncthreads();

@@ -57,6 +57,8 @@ extern "C" uint32_t sre_hip_scanner_chunk_entry(sre_hip_scanner_t *sc, uint32_t 
 
 namespace {
 
+#define SRE_EXEC_PENDING INT64_MIN    /* res.rc until the kernel has published its result */
+
 /* pinned host block: request, result header, ovector */
 struct HostBlock {
     sre_dev_req_t    req;
@@ -235,7 +237,7 @@ device_stream_exec(DeviceStream *ds, const sre_char *input, size_t len, unsigned
         SRE_HIP_TRY(hipMemcpyAsync(ds->d_in, input, len, hipMemcpyHostToDevice, ds->stream));
         rq->input = static_cast<const uint8_t *>(ds->d_in);
     }
-    ds->h_blk->res.rc = SRE_ERROR;
+    *const_cast<volatile int64_t *>(&ds->h_blk->res.rc) = SRE_EXEC_PENDING;
 
     if (launch == sre_launch_pike_exec && ds->dp->d_pwave != NULL) {
         /* the exact step by a wavefront (sre_hip_pwave.hip) */
@@ -243,7 +245,28 @@ device_stream_exec(DeviceStream *ds, const sre_char *input, size_t len, unsigned
     } else {
         SRE_HIP_TRY(launch(ds->dp->d_blob, ds->dp->blob_bytes, &ds->d_blk->req, 1, ds->ctx_bytes, ds->stream));
     }
-    SRE_HIP_TRY(hipStreamSynchronize(ds->stream));
+    {
+        /* the kernel writes res->rc last, behind a system-scope fence: watching that word costs
+         * a few us less than the runtime's wait (an interrupt and a wake-up: 63-byte calls took
+         * 59 us, profiles/r02_crossover.json) — for as long as a short call can take, then the
+         * ordinary wait.  (What the kernel still does behind that store — the context's way back
+         * from LDS — is in front of the next call's work on the same queue.) */
+        const volatile int64_t *prc = &ds->h_blk->res.rc;
+        const auto              t0 = std::chrono::steady_clock::now();
+        uint32_t                polls = 0;
+        while (*prc == SRE_EXEC_PENDING) {
+            if ((++polls & 63u) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(500)) {
+                SRE_HIP_TRY(hipStreamSynchronize(ds->stream));
+                break;
+            }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        if (*prc == SRE_EXEC_PENDING) {
+            /* the kernel never published: a device fault */
+            ds->h_blk->res.rc = SRE_ERROR;
+            goto hip_failed;
+        }
+    }
     return 0;
 
 hip_failed:
