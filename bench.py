@@ -519,7 +519,7 @@ def main():
             # ranks sharing a GPU: a plumbing rehearsal, not a scaling record
             line["config"]["rehearsal"] = True
             line["value_comparable"] = False
-        prof = os.path.join(ROOT, "profiles", "r02_pmc_hbm.json")
+        prof = os.path.join(ROOT, "profiles", "r03_pmc_hbm.json")
         if world == 1 and head["name"] == "cfg2" and m["total"] == 4 * GIB - 3 and os.path.exists(prof):
             # HBM bytes per launch of the dominant kernel from separate rocprofv3 --pmc passes
             # of this same command (profiles/README.md): 2 x FETCH_SIZE (gfx950 correction,
@@ -529,7 +529,7 @@ def main():
             pm = {(r["counter"], "sre_k_scan<1, 2" in r["kernel"]): r["mean_value_KB"] for r in pj["counters"]}
             if ("FETCH_SIZE", True) in pm:
                 line["roofline"]["traffic"] = (2 * pm[("FETCH_SIZE", True)] + pm[("WRITE_SIZE", True)]) * 1024
-                line["roofline"]["traffic_source"] = "profiles/r02_pmc_hbm.json (commit %s, %s)" % (
+                line["roofline"]["traffic_source"] = "profiles/r03_pmc_hbm.json (commit %s, %s)" % (
                     pj.get("commit"), pj.get("date"))
         if world == 1 and not many:
             # measured streaming-read ceiling of this box, same buffer
