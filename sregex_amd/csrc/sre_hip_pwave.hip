@@ -55,22 +55,31 @@ pw_readlane(uint32_t v, uint32_t lane)
     return (uint32_t) __builtin_amdgcn_readlane((int) v, (int) lane);
 }
 
+template <bool ENTS_LDS>
 struct PikeWave {
     /* tables (LDS copies, entries possibly global) */
     const sre_pwave_hdr_t   *W;
     const uint32_t          *accw;      /* [64][8] */
     const sre_pwave_list_t  *lists;     /* [nlists][3] */
-    const sre_pwave_entry_t *ents;
+    const sre_pwave_entry_t *ents;      /* the entries in global memory */
+    uint32_t                 ents_lds;  /* ... and their LDS copy's address when there is one (else ~0): a generic
+                                         * pointer makes every entry load a flat_load */
     const uint16_t          *tid_list, *tid_match;
     /* state (LDS) */
-    int64_t  *caps[2];      /* [nslots][64] each */
+    int64_t  *capsb;        /* two lists x [nslots][64]: list l at capsb + l * nslots * 64 (no member ARRAYS indexed at run time:
+                             * they would send the whole struct to scratch memory — 240 bytes per lane and a memory round trip
+                             * per member access, which is what the first build did: 1.5-2 us per byte) */
     int64_t  *matched;      /* [nslots] */
-    uint16_t *tidv[2];      /* [64] */
+    uint16_t *tidvb;        /* two lists x [64] */
     uint32_t *stamp;        /* [64] */
     uint16_t *initial;      /* [64] */
     uint8_t  *inl;          /* [16] */
     /* uniform state */
     const uint8_t *in;
+    uint32_t nleading, nregexes;    /* (of the header: read once — a load per byte from global memory was the step's largest cost) */
+    const uint32_t *lead;           /* [8] the leading-byte map, LDS copy */
+    uint32_t win;           /* this lane's byte of the 64-byte input window [win_base, win_base + 64) */
+    int64_t  win_base;
     uint32_t nslots, lane;
     uint32_t n, cur, stamp_cur;
     int64_t  processed;
@@ -79,39 +88,55 @@ struct PikeWave {
     uint32_t first_buf, seen_word;      /* a context fed in chunks (exec_chunk) */
     int64_t  matched_id;
 
-    __device__ inline uint32_t ctx_at(int64_t pos) const
+    __device__ __forceinline__ sre_pwave_entry_t entry(uint32_t idx) const
+    {
+        if (ENTS_LDS) {
+            typedef const __attribute__((address_space(3))) uint16_t *lds_u16_t;
+            typedef const __attribute__((address_space(3))) uint64_t *lds_u64_t;
+            const uint32_t    a = ents_lds + idx * (uint32_t) sizeof(sre_pwave_entry_t);
+            sre_pwave_entry_t e;
+            e.tid = *reinterpret_cast<lds_u16_t>((uintptr_t) a);
+            e.saves = *reinterpret_cast<lds_u64_t>((uintptr_t) (a + 8u));
+            return e;
+        }
+        return ents[idx];
+    }
+
+    __device__ __forceinline__ size_t nslots_x64() const { return (size_t) nslots * 64u; }
+
+    __device__ __forceinline__ uint32_t ctx_at(int64_t pos) const
     {
         if (pos == 0) return processed == 0 ? 2u : (seen_newline ? 1u : 0u);    /* :841-860 */
         return pw_uniform(in[pos - 1] == '\n' ? 1u : 0u);
     }
 
     /* the list of a search that (re)starts at `pos`: closure of instruction 0 with an all -1 vector */
-    __device__ inline void seed(int64_t pos)
+    __device__ __forceinline__ void seed(int64_t pos)
     {
         const sre_pwave_list_t L = lists[0 * SRE_PWAVE_NCTX + ctx_at(pos)];
         const bool             valid = lane < L.len;
         sre_pwave_entry_t      e;
         e.tid = 0;
         e.saves = 0;
-        if (valid) e = ents[L.off + lane];
-        if (valid) tidv[cur][lane] = e.tid;
+        if (valid) e = entry(L.off + lane);
+        if (valid) tidvb[(cur) * 64u + lane] = e.tid;
         const int64_t at = processed + pos;
         for (uint32_t s = 0; s < nslots; s++) {
-            if (valid) caps[cur][s * 64 + lane] = ((e.saves >> s) & 1) ? at : (int64_t) -1;
+            if (valid) capsb[(size_t) (cur) * nslots_x64() + s * 64 + lane] = ((e.saves >> s) & 1) ? at : (int64_t) -1;
         }
         n = pw_uniform(L.len);          /* (every lane read the same entry: tell the compiler) */
         if (pw_uniform(L.sss)) sss = 1;
     }
 
     /* sre_vm_pike.c:992-1061, 64 bytes at a time */
-    __device__ inline int64_t find_first_byte(int64_t pos, int64_t last) const
+    __device__ __forceinline__ int64_t find_first_byte(int64_t pos, int64_t last) const
     {
         while (pos < last) {
             const int64_t  p = pos + lane;
             bool           hit = false;
             if (p < last) {
                 const uint32_t c = in[p];
-                hit = (W->lead[c >> 5] >> (c & 31)) & 1;
+                hit = (lead[c >> 5] >> (c & 31)) & 1;
             }
             const uint64_t m = __builtin_amdgcn_ballot_w64(hit);
             if (m) return pos + __builtin_ctzll(m);
@@ -120,8 +145,21 @@ struct PikeWave {
         return last;
     }
 
+    /* the input byte at `pos` (< last): the wave loads 64 bytes at a time, lane l byte l, and a
+     * step reads its byte out of a lane — a load per byte was a third of a thin list's step */
+    __device__ __forceinline__ uint32_t byte_at(int64_t pos, int64_t last)
+    {
+        if (pos < win_base || pos >= win_base + 64) {
+            win_base = pos;
+            const int64_t p = pos + lane;
+            win = p < last ? (uint32_t) in[p] : 0u;
+        }
+        return pw_readlane(win, (uint32_t) (pos - win_base));
+    }
+    __device__ inline void window_reset() { win_base = -((int64_t) 1 << 62); }
+
     /* slot 1 of the match just recorded (last_matched_pos, :530-532, :895) */
-    __device__ inline int64_t matched_end() const
+    __device__ __forceinline__ int64_t matched_end() const
     {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         const int64_t m1 = matched[1];
@@ -129,16 +167,16 @@ struct PikeWave {
     }
 
     /* one byte step at `sp` (:312-581); returns whether a MATCH was reached */
-    __device__ inline bool step(int64_t sp, int64_t last)
+    __device__ __forceinline__ bool step(int64_t sp, int64_t last)
     {
         const bool     at_end = sp == last;
-        const uint32_t c = at_end ? 0u : pw_uniform((uint32_t) in[sp]);
+        const uint32_t c = at_end ? 0u : byte_at(sp, last);
         const uint32_t nxt = cur ^ 1u;
         const int64_t  pos1 = processed + sp + 1;
         uint32_t       t = 0, is_m = 0, acc = 0;
         uint32_t       l_off = 0, l_len = 0, l_done = 0, l_sss = 0;
         if (lane < n) {
-            t = tidv[cur][lane];
+            t = tidvb[(cur) * 64u + lane];
             is_m = tid_match[t];
             if (!at_end && !is_m) {
                 acc = (accw[t * 8 + (c >> 5)] >> (c & 31)) & 1u;
@@ -159,42 +197,73 @@ struct PikeWave {
         const uint64_t dm = __builtin_amdgcn_ballot_w64(l_done != 0) & src;
         const uint32_t d = dm ? (uint32_t) __builtin_ctzll(dm) : 64u;
         if (d < 63) src &= (2ull << d) - 1;                 /* SRE_DONE ends the step behind its source (:895-898) */
+        /* ---- the closures of all consuming threads at once.  Candidate c = (source, position in the
+         * source's static list), numbered in the reference's order (sources by priority, then closure
+         * order); lane c takes candidate c.  The scalar loop below hands the lanes to the sources with
+         * two selects per source and no memory access; then ONE round for all candidates: load the
+         * entry, claim the target thread with an LDS max of (step stamp, 63 - c) — the FIRST candidate
+         * of a thread wins, which is what the generation tags do (:770, :792) —, read the claim back,
+         * rank the winners by a prefix count, hand the owner's capture column over.  More than 64
+         * candidates: batches of whole sources; a later batch first drops what the step has listed. */
+        if (stamp_cur >= (1u << 26) - 2u) {
+            stamp[lane] = 0;
+            stamp_cur = 0;
+        }
         stamp_cur++;
         uint32_t nn = 0;
-        bool     done = false;
-        for (uint64_t rem = src; rem; rem &= rem - 1) {
-            const uint32_t i = (uint32_t) __builtin_ctzll(rem);
-            const uint32_t off = pw_readlane(l_off, i), len = pw_readlane(l_len, i);
-            if (pw_readlane(l_sss, i)) sss = 1;
-            const bool        valid = lane < len;
+        bool     done = false, first_batch = true;
+        uint32_t d_off = 0, d_len = 0;
+        for (uint64_t rem = src; rem;) {
+            uint32_t owner = 0, kbase = 0, loff = 0, total = 0;
+            while (rem) {
+                const uint32_t i = (uint32_t) __builtin_ctzll(rem);
+                const uint32_t len = pw_readlane(l_len, i);
+                if (total + len > 64u) break;
+                const uint32_t off = pw_readlane(l_off, i);
+                const bool     ge = lane >= total;
+                owner = ge ? i : owner;
+                kbase = ge ? total : kbase;
+                loff = ge ? off : loff;
+                total += len;
+                if (pw_readlane(l_sss, i)) sss = 1;
+                if (i == d) {
+                    d_off = off;
+                    d_len = len;
+                }
+                rem &= rem - 1;
+            }
+            const bool        valid = lane < total;
             sre_pwave_entry_t e;
             e.tid = 0;
             e.saves = 0;
-            if (valid) e = ents[off + lane];
-            const bool     keep = valid && stamp[e.tid] != stamp_cur;       /* first arrival wins (:770) */
+            if (valid) e = entry(loff + (lane - kbase));
+            bool keep = valid;
+            if (!first_batch) keep = keep && (stamp[e.tid] >> 6) != stamp_cur;
+            const uint32_t key = (stamp_cur << 6) | (63u - lane);
+            if (keep) __hip_atomic_fetch_max(&stamp[e.tid], key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            keep = keep && stamp[e.tid] == key;
             const uint64_t km = __builtin_amdgcn_ballot_w64(keep);
             const uint32_t rank = nn + pw_lane_rank(km);
-            if (keep) {
-                stamp[e.tid] = stamp_cur;
-                tidv[nxt][rank] = e.tid;
-            }
-            /* the source's capture vector, broadcast slot by slot */
+            if (keep) tidvb[(nxt) * 64u + rank] = e.tid;
+            /* the owner's capture vector, slot by slot */
             for (uint32_t s = 0; s < nslots; s++) {
-                const int64_t v = caps[cur][s * 64 + i];
-                if (keep) caps[nxt][s * 64 + rank] = ((e.saves >> s) & 1) ? pos1 : v;
+                const int64_t v = capsb[(size_t) (cur) * nslots_x64() + s * 64 + owner];
+                if (keep) capsb[(size_t) (nxt) * nslots_x64() + s * 64 + rank] = ((e.saves >> s) & 1) ? pos1 : v;
             }
             nn += (uint32_t) __builtin_popcountll(km);
-            if (i == d) {
-                /* the closure reached MATCH behind its listed targets: the match (:895-898) */
-                const sre_pwave_entry_t me = ents[off + len];
-                if (lane < nslots) matched[lane] = ((me.saves >> lane) & 1) ? pos1 : caps[cur][lane * 64 + i];
-                matched_id = (int64_t) pw_uniform(tid_match[me.tid]) - 1;
-                done = true;
-            }
+            first_batch = false;
+        }
+        if (d < 64) {
+            /* the closure of source d reached MATCH behind its listed targets: the match (:895-898) */
+            const sre_pwave_entry_t me = entry(d_off + d_len);
+            if (lane < nslots) matched[lane] = ((me.saves >> lane) & 1) ? pos1 : capsb[(size_t) (cur) * nslots_x64() + lane * 64 + d];
+            matched_id = (int64_t) pw_uniform(tid_match[me.tid]) - 1;
+            done = true;
         }
         if (!done && m < 64) {
             /* the listed MATCH thread is reached (:530-553) */
-            if (lane < nslots) matched[lane] = caps[cur][lane * 64 + m];
+            if (lane < nslots) matched[lane] = capsb[(size_t) (cur) * nslots_x64() + lane * 64 + m];
             matched_id = (int64_t) pw_readlane(is_m, m) - 1;
             done = true;
         }
@@ -206,12 +275,13 @@ struct PikeWave {
 
     /* one whole-buffer exec() of a fresh (possibly re-armed) context with eof, picked up at `start`
      * (sre_hip_vm.hip Pike::exec) */
-    __device__ int64_t exec(int64_t size, int64_t start, bool start_is_skip_target, int64_t *ov, uint32_t ovec_slots)
+    __device__ __forceinline__ int64_t exec(int64_t size, int64_t start, bool start_is_skip_target, int64_t *ov, uint32_t ovec_slots)
     {
         const int64_t last = size;
         int64_t       sp = 0;
         bool          no_check_once = false, skip_ran_out = false;
         int64_t       last_matched_pos = -1;
+        window_reset();
         if (ctx_eof) return -1;                                 /* :165-168 */
         if (empty_capture) {                                    /* :179-196 */
             empty_capture = 0;
@@ -231,10 +301,10 @@ struct PikeWave {
         /* :202-233 */
         seed(sp);
         initial_count = n;
-        if (lane + 1 < n) initial[lane] = tidv[cur][lane];      /* all but its last thread (:218-229) */
+        if (lane + 1 < n) initial[lane] = tidvb[(cur) * 64u + lane];      /* all but its last thread (:218-229) */
         if (start > sp) {
             sp = start;
-            if (W->nleading && start_is_skip_target) {
+            if (nleading && start_is_skip_target) {
                 sp = find_first_byte(sp, last);
                 no_check_once = true;
                 if (sp == last) skip_ran_out = true;            /* :304-306 */
@@ -246,11 +316,11 @@ struct PikeWave {
             if (n == 0) break;
             if (no_check_once) {
                 no_check_once = false;
-            } else if (W->nleading && sss) {                    /* :256-309 */
+            } else if (nleading && sss) {                    /* :256-309 */
                 sss = 0;
                 bool same = (sp != last) && (n == initial_count);
                 if (same) {
-                    const bool diff = lane + 1 < n && tidv[cur][lane] != initial[lane];
+                    const bool diff = lane + 1 < n && tidvb[(cur) * 64u + lane] != initial[lane];
                     same = __builtin_amdgcn_ballot_w64(diff) == 0;
                 }
                 if (same) {
@@ -271,7 +341,7 @@ struct PikeWave {
             if (p > 0) seen_newline = pw_uniform(in[p - 1] == '\n' ? 1u : 0u);
         }
         if (has_matched) {                                      /* :607-636, eof */
-            if (matched_id >= (int64_t) W->nregexes) return -1;
+            if (matched_id >= (int64_t) nregexes) return -1;
             const uint32_t *ncaps = reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(W) + W->multi_ncaps_off);
             uint32_t        ofs = 0;
             for (int64_t r = 0; r < matched_id; r++) ofs += ncaps[r] + 1;
@@ -299,11 +369,12 @@ struct PikeWave {
      * context between calls; without a decision the call answers SRE_AGAIN with the range a match
      * could still span (:692-735) and the pending match (:640-658).
      */
-    __device__ int64_t exec_chunk(int64_t size, bool eof, bool want_pending, int64_t *ov, uint32_t ovec_slots,
+    __device__ __forceinline__ int64_t exec_chunk(int64_t size, bool eof, bool want_pending, int64_t *ov, uint32_t ovec_slots,
                                   int64_t *has_pending, int64_t *pending, int64_t *consumed)
     {
         const int64_t last = size;
         int64_t       sp = 0, last_matched_pos = -1;
+        window_reset();
         *has_pending = 0;
         *consumed = 0;
         if (ctx_eof) return -1;                                 /* :165-168 */
@@ -325,15 +396,15 @@ struct PikeWave {
             sss = 0;
             seed(sp);
             initial_count = n;
-            if (lane + 1 < n) initial[lane] = tidv[cur][lane];
+            if (lane + 1 < n) initial[lane] = tidvb[(cur) * 64u + lane];
         }
         for (; sp < last || (eof && sp == last); sp++) {        /* :235 */
             if (n == 0) break;
-            if (W->nleading && sss) {                           /* :256-309 */
+            if (nleading && sss) {                           /* :256-309 */
                 sss = 0;
                 bool same = (sp != last) && (n == initial_count);
                 if (same) {
-                    const bool diff = lane + 1 < n && tidv[cur][lane] != initial[lane];
+                    const bool diff = lane + 1 < n && tidvb[(cur) * 64u + lane] != initial[lane];
                     same = __builtin_amdgcn_ballot_w64(diff) == 0;
                 }
                 if (same) {
@@ -360,7 +431,7 @@ struct PikeWave {
         }
         const uint32_t *ncaps = reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(W) + W->multi_ncaps_off);
         if (has_matched) {                                      /* :607-658 */
-            if (matched_id >= (int64_t) W->nregexes) return -1;
+            if (matched_id >= (int64_t) nregexes) return -1;
             uint32_t ofs = 0;
             for (int64_t r = 0; r < matched_id; r++) ofs += ncaps[r] + 1;
             ofs *= 2;
@@ -396,12 +467,12 @@ struct PikeWave {
             int64_t a0 = INT64_MAX, a1 = -1;
             if (lane < n) {
                 uint32_t ofs = 0;
-                for (uint32_t r = 0; r < W->nregexes; r++) {
-                    const int64_t b = caps[cur][ofs * 64 + lane];
+                for (uint32_t r = 0; r < nregexes; r++) {
+                    const int64_t b = capsb[(size_t) (cur) * nslots_x64() + ofs * 64 + lane];
                     if (b != -1 && b < a0) a0 = b;
                     ofs += 2 * (ncaps[r] + 1);
                 }
-                a1 = caps[cur][1 * 64 + lane];
+                a1 = capsb[(size_t) (cur) * nslots_x64() + 1 * 64 + lane];
             }
             for (int d = 32; d > 0; d >>= 1) {
                 const int64_t o0 = __shfl_xor(a0, d), o1 = __shfl_xor(a1, d);
@@ -427,6 +498,7 @@ pwave_lds_bytes(const sre_pwave_hdr_t *h, bool *ents_in_lds)
     b += 2 * (size_t) h->nslots * 64 * 8;       /* caps */
     b += 64 * 8;                                /* matched */
     b += 16;                                    /* a chunk that travels in the request (sre_k_pike_exec_wave) */
+    b += 32;                                    /* leading-byte map */
     b += 2 * 64 * 2 + 64 * 4 + 64 * 2;          /* tidv, stamp, initial */
     b += 64 * 8 * 4 + 64 * 2 * 2;               /* accept words, tid_list, tid_match */
     b += (size_t) h->nlists * SRE_PWAVE_NCTX * sizeof(sre_pwave_list_t);
@@ -437,19 +509,21 @@ pwave_lds_bytes(const sre_pwave_hdr_t *h, bool *ents_in_lds)
 }
 
 /* carve the wave's LDS and copy the program's tables into it */
-__device__ inline void
-pwave_setup(PikeWave &vm, const sre_pwave_hdr_t *Wg, uint8_t *lds, uint32_t lane, uint32_t ents_in_lds)
+template <bool ENTS_LDS>
+__device__ __forceinline__ void
+pwave_setup(PikeWave<ENTS_LDS> &vm, const sre_pwave_hdr_t *Wg, uint8_t *lds, uint32_t lane)
 {
     const uint32_t nslots = Wg->nslots;
     uint8_t       *p = lds;
-    vm.caps[0] = reinterpret_cast<int64_t *>(p);    p += (size_t) nslots * 64 * 8;
-    vm.caps[1] = reinterpret_cast<int64_t *>(p);    p += (size_t) nslots * 64 * 8;
+    vm.capsb = reinterpret_cast<int64_t *>(p);      p += 2 * (size_t) nslots * 64 * 8;
     vm.matched = reinterpret_cast<int64_t *>(p);    p += 64 * 8;
     vm.inl = p;                                     p += 16;
+    uint32_t *lead = reinterpret_cast<uint32_t *>(p);   p += 32;
+    if (lane < 8) lead[lane] = Wg->lead[lane];
+    vm.lead = lead;
     uint32_t *accw = reinterpret_cast<uint32_t *>(p);   p += 64 * 8 * 4;
     vm.stamp = reinterpret_cast<uint32_t *>(p);     p += 64 * 4;
-    vm.tidv[0] = reinterpret_cast<uint16_t *>(p);   p += 64 * 2;
-    vm.tidv[1] = reinterpret_cast<uint16_t *>(p);   p += 64 * 2;
+    vm.tidvb = reinterpret_cast<uint16_t *>(p);     p += 2 * 64 * 2;
     vm.initial = reinterpret_cast<uint16_t *>(p);   p += 64 * 2;
     uint16_t *tid_list = reinterpret_cast<uint16_t *>(p);   p += 64 * 2;
     uint16_t *tid_match = reinterpret_cast<uint16_t *>(p);  p += 64 * 2;
@@ -465,13 +539,16 @@ pwave_setup(PikeWave &vm, const sre_pwave_hdr_t *Wg, uint8_t *lds, uint32_t lane
         for (uint32_t k = lane; k < Wg->nlists * SRE_PWAVE_NCTX; k += 64) lists[k] = gl[k];
     }
     const sre_pwave_entry_t *ents = reinterpret_cast<const sre_pwave_entry_t *>(wb + Wg->off_entries);
-    if (ents_in_lds) {
+    vm.ents_lds = ~0u;
+    if (ENTS_LDS) {
         sre_pwave_entry_t *le = reinterpret_cast<sre_pwave_entry_t *>(p);
         for (uint32_t k = lane; k < Wg->nentries + 1; k += 64) le[k] = ents[k];
-        ents = le;
+        vm.ents_lds = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) uint8_t *) p;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     vm.W = Wg;
+    vm.nleading = pw_uniform(Wg->nleading);
+    vm.nregexes = pw_uniform(Wg->nregexes);
     vm.accw = accw;
     vm.lists = lists;
     vm.ents = ents;
@@ -492,17 +569,18 @@ pwave_setup(PikeWave &vm, const sre_pwave_hdr_t *Wg, uint8_t *lds, uint32_t lane
  * reference's caller on one re-armed context (exec from the previous match's end until SRE_DECLINED,
  * sre_vm_pike.c:179-196, :586-636), as sre_hip_vm.hip sre_k_pike_scan does with one lane per stream.
  */
-extern "C" __global__ __launch_bounds__(64) void
+template <bool ENTS_LDS>
+__global__ __launch_bounds__(64) void
 sre_k_pike_scan_wave(const sre_pwave_hdr_t *__restrict__ Wg, const uint8_t *const *__restrict__ streams,
                      const uint64_t *__restrict__ lens, uint32_t nstreams, int64_t *__restrict__ records,
-                     uint32_t ovec_slots, int mode, uint32_t ents_in_lds)
+                     uint32_t ovec_slots, int mode)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const uint32_t i = blockIdx.x;
     if (i >= nstreams) return;
     const uint32_t lane = threadIdx.x;
-    PikeWave vm;
-    pwave_setup(vm, Wg, lds, lane, ents_in_lds);
+    PikeWave<ENTS_LDS> vm;
+    pwave_setup(vm, Wg, lds, lane);
     int64_t       *rec = records + (size_t) i * (2 + ovec_slots);
     const uint8_t *s = streams[i];
     const uint64_t n = lens[i];
@@ -525,11 +603,12 @@ sre_k_pike_scan_wave(const sre_pwave_hdr_t *__restrict__ Wg, const uint8_t *cons
     }
 }
 
-extern "C" __global__ __launch_bounds__(64) void
+template <bool ENTS_LDS>
+__global__ __launch_bounds__(64) void
 sre_k_pike_window_wave(const sre_pwave_hdr_t *__restrict__ Wg, const uint8_t *const *__restrict__ streams,
                        const uint64_t *__restrict__ lens, uint32_t nstreams, int64_t *__restrict__ records,
                        uint32_t ovec_slots, sre_nfa_window_t *__restrict__ win, const int64_t *__restrict__ lo,
-                       const sre_nfa_count_req_t *__restrict__ creq, uint32_t ents_in_lds)
+                       const sre_nfa_count_req_t *__restrict__ creq)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const uint32_t i = blockIdx.x;
@@ -538,8 +617,8 @@ sre_k_pike_window_wave(const sre_pwave_hdr_t *__restrict__ Wg, const uint8_t *co
     if (!win[i].done || win[i].ev_pos < 0) return;
     const uint32_t lane = threadIdx.x;
 
-    PikeWave vm;
-    pwave_setup(vm, Wg, lds, lane, ents_in_lds);
+    PikeWave<ENTS_LDS> vm;
+    pwave_setup(vm, Wg, lds, lane);
     vm.in = streams[i];
     vm.processed = 0;
     vm.seen_newline = 0;
@@ -588,13 +667,19 @@ sre_launch_pike_window_wave(const void *d_wave_v, const void *h_wave_v, const vo
     bool         in_lds = false;
     const size_t bytes = pwave_lds_bytes(h_wave, &in_lds);
     if (bytes > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sre_k_pike_window_wave),
+        hipError_t e = hipFuncSetAttribute(in_lds ? reinterpret_cast<const void *>(sre_k_pike_window_wave<true>) : reinterpret_cast<const void *>(sre_k_pike_window_wave<false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(sre_k_pike_window_wave, dim3(nstreams), dim3(64), bytes, stream, d_wave,
-                       reinterpret_cast<const uint8_t *const *>(d_streams), d_lens, nstreams, d_records, ovec_slots,
-                       d_win, d_lo, d_creq, in_lds ? 1u : 0u);
+    if (in_lds) {
+        hipLaunchKernelGGL(sre_k_pike_window_wave<true>, dim3(nstreams), dim3(64), bytes, stream, d_wave,
+                           reinterpret_cast<const uint8_t *const *>(d_streams), d_lens, nstreams, d_records, ovec_slots,
+                           d_win, d_lo, d_creq);
+    } else {
+        hipLaunchKernelGGL(sre_k_pike_window_wave<false>, dim3(nstreams), dim3(64), bytes, stream, d_wave,
+                           reinterpret_cast<const uint8_t *const *>(d_streams), d_lens, nstreams, d_records, ovec_slots,
+                           d_win, d_lo, d_creq);
+    }
     return hipGetLastError();
 }
 
@@ -608,13 +693,17 @@ sre_launch_pike_scan_wave(const void *d_wave_v, const void *h_wave_v, int mode, 
     bool         in_lds = false;
     const size_t bytes = pwave_lds_bytes(h_wave, &in_lds);
     if (bytes > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sre_k_pike_scan_wave),
+        hipError_t e = hipFuncSetAttribute(in_lds ? reinterpret_cast<const void *>(sre_k_pike_scan_wave<true>) : reinterpret_cast<const void *>(sre_k_pike_scan_wave<false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(sre_k_pike_scan_wave, dim3(nstreams), dim3(64), bytes, stream, d_wave,
-                       reinterpret_cast<const uint8_t *const *>(d_streams), d_lens, nstreams, d_records, ovec_slots, mode,
-                       in_lds ? 1u : 0u);
+    if (in_lds) {
+        hipLaunchKernelGGL(sre_k_pike_scan_wave<true>, dim3(nstreams), dim3(64), bytes, stream, d_wave,
+                           reinterpret_cast<const uint8_t *const *>(d_streams), d_lens, nstreams, d_records, ovec_slots, mode);
+    } else {
+        hipLaunchKernelGGL(sre_k_pike_scan_wave<false>, dim3(nstreams), dim3(64), bytes, stream, d_wave,
+                           reinterpret_cast<const uint8_t *const *>(d_streams), d_lens, nstreams, d_records, ovec_slots, mode);
+    }
     return hipGetLastError();
 }
 
@@ -641,17 +730,17 @@ sre_pwave_ctx_bytes(const void *h_wave)
     return sizeof(sre_pwave_ctx_t) + (size_t) static_cast<const sre_pwave_hdr_t *>(h_wave)->nslots * 64 * 8;
 }
 
-extern "C" __global__ __launch_bounds__(64) void
-sre_k_pike_exec_wave(const sre_pwave_hdr_t *__restrict__ Wg, const sre_dev_req_t *__restrict__ reqs, uint32_t nreqs,
-                     uint32_t ents_in_lds)
+template <bool ENTS_LDS>
+__global__ __launch_bounds__(64) void
+sre_k_pike_exec_wave(const sre_pwave_hdr_t *__restrict__ Wg, const sre_dev_req_t *__restrict__ reqs, uint32_t nreqs)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const uint32_t i = blockIdx.x;
     if (i >= nreqs) return;
     const sre_dev_req_t rq = reqs[i];
     const uint32_t      lane = threadIdx.x;
-    PikeWave            vm;
-    pwave_setup(vm, Wg, lds, lane, ents_in_lds);
+    PikeWave<ENTS_LDS>  vm;
+    pwave_setup(vm, Wg, lds, lane);
     const uint32_t   nslots = vm.nslots;
     sre_pwave_ctx_t *cx = static_cast<sre_pwave_ctx_t *>(rq.ctx);
     int64_t         *ccaps = reinterpret_cast<int64_t *>(cx + 1);
@@ -683,11 +772,11 @@ sre_k_pike_exec_wave(const sre_pwave_hdr_t *__restrict__ Wg, const sre_dev_req_t
         vm.seen_word = pw_uniform(cx->seen_word);
         vm.processed = cx->processed;
         vm.matched_id = cx->matched_id;
-        vm.tidv[0][lane] = cx->tidv[lane];
+        vm.tidvb[(0) * 64u + lane] = cx->tidv[lane];
         vm.initial[lane] = cx->initial[lane];
         vm.matched[lane] = cx->matched[lane];
         if (lane < vm.n) {
-            for (uint32_t s = 0; s < nslots; s++) vm.caps[0][s * 64 + lane] = ccaps[s * 64 + lane];
+            for (uint32_t s = 0; s < nslots; s++) vm.capsb[(size_t) (0) * vm.nslots_x64() + s * 64 + lane] = ccaps[s * 64 + lane];
         }
     }
     /* a chunk of up to 8 bytes travels in the request */
@@ -706,11 +795,11 @@ sre_k_pike_exec_wave(const sre_pwave_hdr_t *__restrict__ Wg, const sre_dev_req_t
                                          &has_pending, pending, &consumed);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     /* the context for the next call */
-    cx->tidv[lane] = vm.tidv[vm.cur][lane];
+    cx->tidv[lane] = vm.tidvb[(vm.cur) * 64u + lane];
     cx->initial[lane] = vm.initial[lane];
     cx->matched[lane] = vm.matched[lane];
     if (lane < vm.n) {
-        for (uint32_t s = 0; s < nslots; s++) ccaps[s * 64 + lane] = vm.caps[vm.cur][s * 64 + lane];
+        for (uint32_t s = 0; s < nslots; s++) ccaps[s * 64 + lane] = vm.capsb[(size_t) (vm.cur) * vm.nslots_x64() + s * 64 + lane];
     }
     if (lane == 0) {
         cx->magic = SRE_PWAVE_CTX_MAGIC;
@@ -748,11 +837,15 @@ sre_launch_pike_exec_wave(const void *d_wave_v, const void *h_wave_v, const sre_
     bool         in_lds = false;
     const size_t bytes = pwave_lds_bytes(h_wave, &in_lds);
     if (bytes > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(sre_k_pike_exec_wave),
+        hipError_t e = hipFuncSetAttribute(in_lds ? reinterpret_cast<const void *>(sre_k_pike_exec_wave<true>) : reinterpret_cast<const void *>(sre_k_pike_exec_wave<false>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(sre_k_pike_exec_wave, dim3(nreqs), dim3(64), bytes, stream, d_wave, d_reqs, nreqs, in_lds ? 1u : 0u);
+    if (in_lds) {
+        hipLaunchKernelGGL(sre_k_pike_exec_wave<true>, dim3(nreqs), dim3(64), bytes, stream, d_wave, d_reqs, nreqs);
+    } else {
+        hipLaunchKernelGGL(sre_k_pike_exec_wave<false>, dim3(nreqs), dim3(64), bytes, stream, d_wave, d_reqs, nreqs);
+    }
     return hipGetLastError();
 }
 

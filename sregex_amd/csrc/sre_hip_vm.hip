@@ -163,7 +163,9 @@ struct Pike {
     Prog               P;
     PikeHdr           *h;
     uint32_t          *tags, *initial;
-    uint8_t           *nodes[2];
+    uint8_t           *nodes0;           /* list l's nodes at nodes0 + l * nodes_step (a member ARRAY indexed at run time would
+                                          * send the whole struct to scratch memory) */
+    size_t             nodes_step;
     int64_t           *matched, *work;
     StackRec          *stack;
     uint32_t           node_bytes, nslots;
@@ -171,7 +173,7 @@ struct Pike {
 
     __device__ inline Node *node(int l, int32_t i) const
     {
-        return reinterpret_cast<Node *>(nodes[l] + (size_t) i * node_bytes);
+        return reinterpret_cast<Node *>(nodes0 + (size_t) l * nodes_step + (size_t) i * node_bytes);
     }
     __device__ inline int64_t *cap(Node *n) const { return reinterpret_cast<int64_t *>(n + 1); }
 
@@ -686,7 +688,8 @@ struct Thompson {
     Prog         P;
     ThompsonHdr *h;
     uint32_t    *tags;
-    uint32_t    *list[2];      /* entries: pc | seen_word << 31 */
+    uint32_t    *list0;        /* entries: pc | seen_word << 31; list l at list0 + l * list_step (see Pike::nodes0) */
+    size_t       list_step;
     uint32_t    *stack;
     Chunk        in;
 
@@ -741,7 +744,7 @@ struct Thompson {
                     h->overflow = 1;            /* see Pike::node_new */
                     break;
                 }
-                list[l][h->count[l]++] = pc | (seen_word << 31);
+                list0[(size_t) l * list_step + h->count[l]++] = pc | (seen_word << 31);
                 break;
             }
         }
@@ -771,7 +774,7 @@ struct Thompson {
             const unsigned c = at_end ? 0u : in.at(sp);
 
             for (uint32_t i = 0; i < h->count[cl]; i++) {
-                const uint32_t       e = list[cl][i];
+                const uint32_t       e = list0[(size_t) cl * list_step + i];
                 const uint32_t       pc = e & 0x7fffffffu;
                 const sre_dev_insn_t ins = P.insns[pc];
 
@@ -866,8 +869,8 @@ sre_k_pike_exec(const uint8_t *__restrict__ blob, const sre_dev_req_t *__restric
         vm.h = reinterpret_cast<PikeHdr *>(base);
         vm.tags = reinterpret_cast<uint32_t *>(base + L.tags);
         vm.initial = reinterpret_cast<uint32_t *>(base + L.initial);
-        vm.nodes[0] = base + L.nodes[0];
-        vm.nodes[1] = base + L.nodes[1];
+        vm.nodes0 = base + L.nodes[0];
+        vm.nodes_step = L.nodes[1] - L.nodes[0];
         vm.matched = reinterpret_cast<int64_t *>(base + L.matched);
         vm.work = reinterpret_cast<int64_t *>(base + L.work);
         vm.stack = reinterpret_cast<StackRec *>(base + L.stack);
@@ -937,8 +940,8 @@ sre_k_thompson_exec(const uint8_t *__restrict__ blob, const sre_dev_req_t *__res
     if (threadIdx.x == 0) {
         vm.h = reinterpret_cast<ThompsonHdr *>(base);
         vm.tags = reinterpret_cast<uint32_t *>(base + L.tags);
-        vm.list[0] = reinterpret_cast<uint32_t *>(base + L.list[0]);
-        vm.list[1] = reinterpret_cast<uint32_t *>(base + L.list[1]);
+        vm.list0 = reinterpret_cast<uint32_t *>(base + L.list[0]);
+        vm.list_step = (L.list[1] - L.list[0]) / 4;
         vm.stack = reinterpret_cast<uint32_t *>(base + L.stack);
         vm.in.p = rq.input;
         vm.in.inl = rq.inline_bytes;
@@ -979,8 +982,8 @@ sre_k_pike_scan(const uint8_t *__restrict__ blob, const uint8_t *const *__restri
     vm.h = reinterpret_cast<PikeHdr *>(base);
     vm.tags = reinterpret_cast<uint32_t *>(base + L.tags);
     vm.initial = reinterpret_cast<uint32_t *>(base + L.initial);
-    vm.nodes[0] = base + L.nodes[0];
-    vm.nodes[1] = base + L.nodes[1];
+    vm.nodes0 = base + L.nodes[0];
+    vm.nodes_step = L.nodes[1] - L.nodes[0];
     vm.matched = reinterpret_cast<int64_t *>(base + L.matched);
     vm.work = reinterpret_cast<int64_t *>(base + L.work);
     vm.stack = reinterpret_cast<StackRec *>(base + L.stack);
@@ -1047,8 +1050,8 @@ sre_k_pike_window(const uint8_t *__restrict__ blob, const uint8_t *const *__rest
     vm.h = reinterpret_cast<PikeHdr *>(base);
     vm.tags = reinterpret_cast<uint32_t *>(base + L.tags);
     vm.initial = reinterpret_cast<uint32_t *>(base + L.initial);
-    vm.nodes[0] = base + L.nodes[0];
-    vm.nodes[1] = base + L.nodes[1];
+    vm.nodes0 = base + L.nodes[0];
+    vm.nodes_step = L.nodes[1] - L.nodes[0];
     vm.matched = reinterpret_cast<int64_t *>(base + L.matched);
     vm.work = reinterpret_cast<int64_t *>(base + L.work);
     vm.stack = reinterpret_cast<StackRec *>(base + L.stack);
@@ -1134,8 +1137,8 @@ sre_k_thompson_scan(const uint8_t *__restrict__ blob, const uint8_t *const *__re
     uint8_t *base = ctx_base + (size_t) i * ctx_stride;
     vm.h = reinterpret_cast<ThompsonHdr *>(base);
     vm.tags = reinterpret_cast<uint32_t *>(base + L.tags);
-    vm.list[0] = reinterpret_cast<uint32_t *>(base + L.list[0]);
-    vm.list[1] = reinterpret_cast<uint32_t *>(base + L.list[1]);
+    vm.list0 = reinterpret_cast<uint32_t *>(base + L.list[0]);
+    vm.list_step = (L.list[1] - L.list[0]) / 4;
     vm.stack = reinterpret_cast<uint32_t *>(base + L.stack);
     vm.in.p = streams[i];
     vm.in.inl = 0;

@@ -85,3 +85,41 @@ def test_small_input_crossover_vs_reference(lib):
     slow = [r for r in rows if r["pike_us"] > r["ref_pike_us"] + LATENCY_BUDGET_US
             or r["thompson_us"] > r["ref_thompson_us"] + LATENCY_BUDGET_US]
     assert not slow, slow
+
+
+def test_exact_vm_per_stream_rate(lib):
+    """Row * of the round-2 verdict: the exact VM's rate on ONE stream (a 1 MiB device buffer, one
+    wavefront) — the wave-cooperative Pike step and the wave Thompson kernel, for a thin list (the
+    headline program, 2-3 threads listed) and a wide one (configs[2]'s 12 regexes).  The records must
+    equal the table-driven scanner's; the rates go to gpurun_out/vm_rate.json (profiles/)."""
+    n = 1 << 20
+    rows = []
+    cfg3 = [b"a", b"ab", b"c", b"a(bc)", b"e(f)", b"gh", b"A", b"b", b"BLAH", rb"\s+", b"abcd", b"bc"]
+    cases = [("headline program, no match", [rb"[a-z]+@[a-z]+\.[a-z]+"], b"aaabbccb"),
+             ("headline program, match at the end", [rb"[a-z]+@[a-z]+\.[a-z]+"], b" a@abc.cc "),
+             ("x(.*)y(.*)z, lists of 3-5", [rb"x(.*)y(.*)z"], b"aaabbccb")]
+    buf = S.DeviceBuffer(n)
+    for name, pats, tail in cases:
+        with S.Pool() as pool:
+            re = S.parse(pool, pats)
+            prog = S.compile(pool, re)
+            L = S.gen_data_length(n, len(tail))
+            assert lib.sre_hip_gen_data(buf.ptr, L, tail, len(tail), None) == 0
+            want = S.Scanner(pool, prog, S.HIP_PIKE_FIRST, S.ENGINE_SCAN).scan([buf.ptr], [L])[0]
+            row = {"case": name, "bytes": L}
+            for mode, key in ((S.HIP_PIKE_FIRST, "pike"), (S.HIP_THOMPSON, "thompson")):
+                sc = S.Scanner(pool, prog, mode, S.ENGINE_VM)
+                got = sc.scan([buf.ptr], [L])[0]
+                if mode == S.HIP_PIKE_FIRST:
+                    assert got == want, (name, got, want)
+                else:
+                    assert (got[0] >= 0) == (want[0] >= 0), (name, got, want)
+                t = _time(lambda: sc.scan([buf.ptr], [L]), 3)
+                row[key + "_ms"] = t * 1e3
+                row[key + "_MBps"] = L / t / 1e6
+            rows.append(row)
+            print(row)
+    out = os.path.join(harness.ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "vm_rate.json"), "w") as f:
+        json.dump(rows, f, indent=1)
