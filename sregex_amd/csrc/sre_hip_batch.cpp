@@ -52,6 +52,7 @@ struct sre_hip_scanner_s {
     sre_scan_geom_t           geom;
     uint64_t                 *d_seg_first, *h_seg_first;
     sre_seg_summary_t        *d_sum;
+    sre_seg_digest_t         *d_digest;                 /* SRE_VERIFY_ONE_SEGS entries, see sre_scan_geom_t.digest */
     size_t                    sum_cap;
     sre_stream_status_t      *d_status, *h_status;
     void                     *d_acc;
@@ -138,6 +139,7 @@ scanner_release(void *data)
     if (sc->h_out) (void) hipHostFree(sc->h_out);
     if (sc->d_ctx) (void) hipFree(sc->d_ctx);
     if (sc->d_sum) (void) hipFree(sc->d_sum);
+    if (sc->d_digest) (void) hipFree(sc->d_digest);
     if (sc->d_acc) (void) hipFree(sc->d_acc);
     if (sc->d_lo) (void) hipFree(sc->d_lo);
     if (sc->h_lo) (void) hipHostFree(sc->h_lo);
@@ -666,6 +668,16 @@ scan_geometry(sre_hip_scanner_t *sc, size_t nstreams)
         sc->sum_cap = 0;
         SRE_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&sc->d_sum), nsegs * sizeof(sre_seg_summary_t)));
         sc->sum_cap = nsegs;
+    }
+    /* the digest for the one-workgroup chain check: small batches only */
+    sc->geom.digest = NULL;
+    if (nsegs <= SRE_VERIFY_ONE_SEGS && sc->mode != SRE_HIP_PIKE_COUNT) {
+        if (sc->d_digest == NULL
+            && hipMalloc(reinterpret_cast<void **>(&sc->d_digest), SRE_VERIFY_ONE_SEGS * sizeof(sre_seg_digest_t)) != hipSuccess)
+        {
+            sc->d_digest = NULL;
+        }
+        sc->geom.digest = sc->d_digest;
     }
     {
         size_t need = nstreams * ((size_t) seg + 16);

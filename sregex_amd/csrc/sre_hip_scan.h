@@ -141,6 +141,11 @@ typedef struct {
     uint32_t stable_until, stable_from;
 } sre_seg_summary_t;
 
+/* bits: [1] SRE_SUM_TERM [2] SRE_SUM_LASTEV [3] cur_sp >= 0 [4] not SRE_SUM_STABLE (as verify_one_stream keeps them) */
+typedef struct sre_seg_digest_s {
+    uint32_t s_in, s_out, bits, count;
+} sre_seg_digest_t;
+
 #define SRE_SUM_PENDING   1u
 #define SRE_SUM_TERM      2u   /* the scan of this stream ended inside this segment */
 #define SRE_SUM_LASTEV    4u
@@ -244,6 +249,10 @@ typedef struct {
      * the reference arrives at offset 0 (bit 0 of sre_nfa_summary_t.last_clean's mode), whether
      * the buffer ends before the stream does.  NULL: init_variant / flags hold for every stream. */
     const uint8_t *sflags;
+    /* FIRST / Thompson: what the chain check of a small batch reads of every summary, 16 bytes a segment
+     * (sre_seg_digest_t; NULL: none is written).  One workgroup checks up to 8192 segments: out of the
+     * 144-byte summaries that was 14 us for the 4096 segments of a 1 MiB chunk. */
+    struct sre_seg_digest_s *digest;
 } sre_scan_geom_t;
 #define SRE_SFLAG_INIT(f)    ((f) & 3u)
 #define SRE_SFLAG_SNAP(f)    (((f) >> 2) & 3u)

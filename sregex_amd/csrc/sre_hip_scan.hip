@@ -994,6 +994,15 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
     out.pe_apos = w.ev_apos;
     out.pe_astate = w.ev_astate;
     sum[g] = out;
+    if (MODE != SRE_HIP_PIKE_COUNT && G.digest != nullptr) {
+        sre_seg_digest_t dg;
+        dg.s_in = out.s_in;
+        dg.s_out = out.s_out;
+        dg.bits = ((out.flags & SRE_SUM_TERM) ? 2u : 0u) | ((out.flags & SRE_SUM_LASTEV) ? 4u : 0u) | (out.cur_sp >= 0 ? 8u : 0u)
+                  | ((out.flags & SRE_SUM_STABLE) ? 0u : 16u);
+        dg.count = (uint32_t) out.count;
+        G.digest[g] = dg;
+    }
 }
 
 /* ============================================================ exact entry states */
@@ -1395,7 +1404,8 @@ sre_k_verify_c(sre_scan_tables_t T, sre_scan_geom_t G, const sre_seg_summary_t *
 template <int NT>
 __device__ void
 verify_one_stream(const sre_scan_tables_t &T, const sre_seg_summary_t *__restrict__ sum, uint64_t nseg,
-                  sre_stream_status_t *__restrict__ status, VerifyAcc *sh_acc, sre_stream_status_t *out)
+                  sre_stream_status_t *__restrict__ status, VerifyAcc *sh_acc, sre_stream_status_t *out,
+                  const sre_seg_digest_t *__restrict__ dig = nullptr)
 {
     constexpr int  PER = SRE_VERIFY_ONE_MAX / NT;
     const uint32_t tid = threadIdx.x;
@@ -1412,7 +1422,13 @@ verify_one_stream(const sre_scan_tables_t &T, const sre_seg_summary_t *__restric
         const uint64_t k = (uint64_t) i * NT + tid;
         bits[i] = 0;
         cnt[i] = 0;
-        if (k < nseg) {
+        if (k < nseg && dig != nullptr) {
+            /* (the scan kernel's digest: 16 bytes a segment, coalesced) */
+            const sre_seg_digest_t c = dig[k];
+            const uint32_t         prev_out = k > 0 ? dig[k - 1].s_out : c.s_in;
+            bits[i] = ((c.s_in == 0xffffffffu || c.s_in != prev_out) ? 1u : 0u) | c.bits;
+            cnt[i] = c.count;
+        } else if (k < nseg) {
             const sre_seg_summary_t &c = sum[k];
             const uint32_t s_in = c.s_in, fl = c.flags;
             const uint32_t prev_out = k > 0 ? sum[k - 1].s_out : s_in;
@@ -2190,7 +2206,7 @@ sre_k_captures(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
     if (NT != 64) {
         __shared__ VerifyAcc sh_acc;
         __shared__ sre_stream_status_t sh_st;
-        verify_one_stream<NT>(Ts, sum, geom_first(G, 1), status, &sh_acc, &sh_st);
+        verify_one_stream<NT>(Ts, sum, geom_first(G, 1), status, &sh_acc, &sh_st, G.digest);
     }
     /* one WORKGROUP per stream, lane 0 walks: the walks of a batch run side by side on
      * different CUs instead of as 64 divergent lanes of one wave (128 streams: 51 us -> see
@@ -2343,9 +2359,18 @@ sre_k_stream_tail(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
     __shared__ uint8_t  sh_syms[72];
     __shared__ VerifyAcc sh_acc;
     __shared__ sre_stream_status_t sh_st;
+#ifdef SRE_DEBUG_TAIL
+    const unsigned long long dbg_t0 = wall_clock64();
+#endif
     stage_walk_tables(tabp, lds, &Ts);
+#ifdef SRE_DEBUG_TAIL
+    const unsigned long long dbg_t1 = wall_clock64();
+#endif
     const uint64_t             nseg = geom_first(G, 1) - geom_first(G, 0);
-    if (verify) verify_one_stream<SRE_TAIL_THREADS>(Ts, sum, nseg, status, &sh_acc, &sh_st);
+    if (verify) verify_one_stream<SRE_TAIL_THREADS>(Ts, sum, nseg, status, &sh_acc, &sh_st, G.digest);
+#ifdef SRE_DEBUG_TAIL
+    const unsigned long long dbg_t2 = wall_clock64();
+#endif
     if (threadIdx.x != 0) return;
     /* the host may be spinning on res->rc (host-visible memory): it is written last, behind
      * a system-scope fence, once everything else of the result is in place */
@@ -2541,6 +2566,12 @@ sre_k_stream_tail(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
     }
     };
     body();
+#ifdef SRE_DEBUG_TAIL
+    /* (10 ns ticks) table staging, chain check, the lane's work */
+    res->ov[SRE_STREAM_MAX_SLOTS - 3] = (int64_t) (dbg_t1 - dbg_t0);
+    res->ov[SRE_STREAM_MAX_SLOTS - 2] = (int64_t) (dbg_t2 - dbg_t1);
+    res->ov[SRE_STREAM_MAX_SLOTS - 1] = (int64_t) (wall_clock64() - dbg_t2);
+#endif
     __threadfence_system();
     *reinterpret_cast<volatile int64_t *>(&res->rc) = rc_out;
 }

@@ -1003,6 +1003,12 @@ pike_stream_route(sre_vm_pike_ctx_t *ctx, sre_char *input, size_t len, unsigned 
     }
     const sre_stream_result_t *res = ds->h_sres;
     const sre_int_t            rc = (sre_int_t) res->rc;
+#ifdef SRE_DEBUG_TAIL
+    if (dbg_t) {
+        fprintf(stderr, "  tail: staging %.1f us, chain check %.1f us, lane 0 %.1f us\n", res->ov[SRE_STREAM_MAX_SLOTS - 3] / 100.0,
+                res->ov[SRE_STREAM_MAX_SLOTS - 2] / 100.0, res->ov[SRE_STREAM_MAX_SLOTS - 1] / 100.0);
+    }
+#endif
     if (rc == SRE_STREAM_PENDING || rc == SRE_STREAM_UNSETTLED) {
         /* the tail kernel never published: a device fault.  The stream is not parked for re-use */
         ds->failed = 1;
