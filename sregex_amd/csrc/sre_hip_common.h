@@ -95,7 +95,15 @@ typedef struct {
     int64_t        preset_processed;
     uint32_t       preset_valid;
     uint32_t       preset_flags;    /* SRE_PRESET_* */
+    /* the context has not been used since it was opened / handed back: whatever its memory holds
+     * is ignored (a flag instead of a fill in front of every first call) */
+    uint32_t       fresh;
+    /* `input` lies in pinned host memory (chunks up to SRE_SMALL_INPUT bytes: written next to the
+     * request instead of a copy of their own): the kernel stages it into LDS before it runs */
+    uint32_t       input_pinned;
 } sre_dev_req_t;
+
+#define SRE_SMALL_INPUT 1024u
 
 #define SRE_PRESET_EMPTY_CAPTURE 1u
 #define SRE_PRESET_SEEN_NEWLINE  2u

@@ -751,7 +751,7 @@ sre_k_pike_exec_wave(const sre_pwave_hdr_t *__restrict__ Wg, const sre_dev_req_t
     vm.has_matched = 0;
     vm.poisoned = 0;
     vm.matched_id = 0;
-    if (pw_uniform(cx->magic) != SRE_PWAVE_CTX_MAGIC) {
+    if (rq.fresh || pw_uniform(cx->magic) != SRE_PWAVE_CTX_MAGIC) {
         /* fresh context (sre_vm_pike.c:94-145); earlier searches may have run on the scanner */
         if (rq.preset_valid) {
             vm.processed = rq.preset_processed;
@@ -779,10 +779,17 @@ sre_k_pike_exec_wave(const sre_pwave_hdr_t *__restrict__ Wg, const sre_dev_req_t
             for (uint32_t s = 0; s < nslots; s++) vm.capsb[(size_t) (0) * vm.nslots_x64() + s * 64 + lane] = ccaps[s * 64 + lane];
         }
     }
-    /* a chunk of up to 8 bytes travels in the request */
+    /* a chunk of up to 8 bytes travels in the request, one of up to SRE_SMALL_INPUT in pinned host
+     * memory next to it (staged into LDS, all loads in flight at once) */
+    __shared__ __attribute__((aligned(16))) uint8_t sh_small_in[SRE_SMALL_INPUT];
     if (rq.input == nullptr) {
         if (lane < 8) vm.inl[lane] = (uint8_t) (rq.inline_bytes >> (8 * lane));
         vm.in = vm.inl;
+    } else if (rq.input_pinned) {
+        for (uint32_t k = lane * 16; k < rq.size; k += 64 * 16) {
+            *reinterpret_cast<uint4 *>(sh_small_in + k) = *reinterpret_cast<const uint4 *>(rq.input + k);
+        }
+        vm.in = sh_small_in;
     } else {
         vm.in = rq.input;
     }

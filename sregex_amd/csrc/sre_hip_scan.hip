@@ -2387,6 +2387,7 @@ sre_k_stream_tail(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
     res->ev_slot1 = -1;
     res->poisoned = 0;
     res->next_state = 0;
+    if (!continues) ctx->has_pending = 0;       /* a search starts with this chunk: nothing is carried in */
     if (!st.done) {
         rc_out = SRE_STREAM_UNSETTLED;
         return;

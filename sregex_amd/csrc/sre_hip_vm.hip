@@ -837,6 +837,26 @@ stage_blob(const uint8_t *blob, uint8_t *lds, uint32_t blob_lds_bytes)
     return lds;
 }
 
+/* a chunk that came in pinned host memory (sre_dev_req_t.input_pinned): into LDS, every load in flight at once */
+__device__ inline const uint8_t *
+stage_small_input(const sre_dev_req_t &rq, uint8_t *sh)
+{
+    if (!rq.input_pinned || rq.input == nullptr) return rq.input;
+    for (uint32_t i = threadIdx.x * 16; i < rq.size; i += blockDim.x * 16) {
+        *reinterpret_cast<uint4 *>(sh + i) = *reinterpret_cast<const uint4 *>(rq.input + i);
+    }
+    __syncthreads();
+    return sh;
+}
+
+__device__ inline void
+ctx_fill_zero(uint8_t *dst, size_t bytes)
+{
+    for (size_t i = (size_t) threadIdx.x * 16; i < bytes; i += (size_t) blockDim.x * 16) {
+        *reinterpret_cast<uint4 *>(dst + i) = make_uint4(0, 0, 0, 0);
+    }
+}
+
 __device__ inline void
 ctx_copy(uint8_t *dst, const uint8_t *src, size_t bytes)
 {
@@ -850,18 +870,23 @@ sre_k_pike_exec(const uint8_t *__restrict__ blob, const sre_dev_req_t *__restric
                 uint32_t nreqs, uint32_t use_lds, uint32_t blob_lds_bytes)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t ctx_lds[];
+    __shared__ __attribute__((aligned(16))) uint8_t sh_small_in[SRE_SMALL_INPUT];
     const uint32_t i = blockIdx.x;
     if (i >= nreqs) return;
     const sre_dev_req_t rq = reqs[i];
     /* the program image too: the VM fetches an instruction per thread and step */
     blob = stage_blob(blob, ctx_lds, blob_lds_bytes);
+    const uint8_t *input = stage_small_input(rq, sh_small_in);
 
     Pike vm;
     vm.P = prog_view(blob);
     const sre_pike_layout_t L = sre_pike_layout(vm.P.h->len, vm.P.h->nthreads, vm.P.h->nslots);
     uint8_t *home = static_cast<uint8_t *>(rq.ctx);
     uint8_t *base = use_lds ? ctx_lds + blob_lds_bytes : home;
-    if (use_lds) {
+    if (rq.fresh) {
+        ctx_fill_zero(base, L.total);       /* zero-filled == fresh (tags, lists, the magic word) */
+        __syncthreads();
+    } else if (use_lds) {
         ctx_copy(base, home, L.total);
         __syncthreads();
     }
@@ -876,7 +901,7 @@ sre_k_pike_exec(const uint8_t *__restrict__ blob, const sre_dev_req_t *__restric
         vm.stack = reinterpret_cast<StackRec *>(base + L.stack);
         vm.node_bytes = L.node_bytes;
         vm.nslots = vm.P.h->nslots;
-        vm.in.p = rq.input;
+        vm.in.p = input;
         vm.in.inl = rq.inline_bytes;
 
         sre_dev_result_t *res = static_cast<sre_dev_result_t *>(rq.result);
@@ -902,17 +927,19 @@ sre_k_thompson_exec(const uint8_t *__restrict__ blob, const sre_dev_req_t *__res
                     uint32_t nreqs, uint32_t use_lds, uint32_t blob_lds_bytes)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t ctx_lds[];
+    __shared__ __attribute__((aligned(16))) uint8_t sh_small_in[SRE_SMALL_INPUT];
     const uint32_t i = blockIdx.x;
     if (i >= nreqs) return;
     const sre_dev_req_t rq = reqs[i];
+    const uint8_t *input = stage_small_input(rq, sh_small_in);
     {
         const uint32_t wave_off = reinterpret_cast<const sre_dev_prog_hdr_t *>(blob)->wave_off;
         if (wave_off != 0) {
-            /* the wave form: the context is the live set (zero-filled == fresh) */
+            /* the wave form: the context is the live set (zero-filled or flagged == fresh) */
             const sre_dev_wave_t *W = reinterpret_cast<const sre_dev_wave_t *>(blob + wave_off);
             uint64_t             *cw = static_cast<uint64_t *>(rq.ctx);
-            uint64_t              S = wave_uniform64((uint32_t) cw[0] == THOMPSON_WAVE_MAGIC ? cw[1] : W->init0);
-            const int64_t         rc = thompson_wave_run(W, S, rq.input, rq.inline_bytes, rq.size, rq.eof != 0);
+            uint64_t              S = wave_uniform64(!rq.fresh && (uint32_t) cw[0] == THOMPSON_WAVE_MAGIC ? cw[1] : W->init0);
+            const int64_t         rc = thompson_wave_run(W, S, input, rq.inline_bytes, rq.size, rq.eof != 0);
             if (threadIdx.x == 0) {
                 sre_dev_result_t *res = static_cast<sre_dev_result_t *>(rq.result);
                 cw[0] = THOMPSON_WAVE_MAGIC;
@@ -933,7 +960,10 @@ sre_k_thompson_exec(const uint8_t *__restrict__ blob, const sre_dev_req_t *__res
     const sre_thompson_layout_t L = sre_thompson_layout(vm.P.h->len);
     uint8_t *home = static_cast<uint8_t *>(rq.ctx);
     uint8_t *base = use_lds ? ctx_lds + blob_lds_bytes : home;
-    if (use_lds) {
+    if (rq.fresh) {
+        ctx_fill_zero(base, L.total);
+        __syncthreads();
+    } else if (use_lds) {
         ctx_copy(base, home, L.total);
         __syncthreads();
     }
@@ -943,7 +973,7 @@ sre_k_thompson_exec(const uint8_t *__restrict__ blob, const sre_dev_req_t *__res
         vm.list0 = reinterpret_cast<uint32_t *>(base + L.list[0]);
         vm.list_step = (L.list[1] - L.list[0]) / 4;
         vm.stack = reinterpret_cast<uint32_t *>(base + L.stack);
-        vm.in.p = rq.input;
+        vm.in.p = input;
         vm.in.inl = rq.inline_bytes;
 
         sre_dev_result_t *res = static_cast<sre_dev_result_t *>(rq.result);

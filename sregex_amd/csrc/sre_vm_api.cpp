@@ -49,6 +49,8 @@ extern "C" uint32_t sre_hip_scanner_chunk_entry(sre_hip_scanner_t *sc, uint32_t 
  * the exact VM's ~1 us per byte is cheaper than the scanners' fixed launch cost
  * (profiles/r02_crossover.json) */
 #define SRE_COMPAT_SCAN_MIN_BYTES  16u
+/* ... and up to this size as ONE chunk of a stream (the chain check by the tail's own workgroup) */
+#define SRE_COMPAT_ONE_CHUNK_MAX   (1u << 20)
 /* a chunked stream starts on the scanner when its first chunk is at least this long: a chunk
  * costs the scanner ~60-110 us whatever its size, the exact VM kernel ~1 us per byte — and a
  * stream that starts on the VM stays there.  (Byte-at-a-time feeding stays on the VM; the
@@ -77,6 +79,9 @@ struct DeviceStream {
     HostBlock         *d_blk;       /* device alias of h_blk */
     hipStream_t        stream;
     int                failed;
+    int                ctx_fresh;   /* nothing has run on d_ctx since it was opened / handed back: the next request says so
+                                     * (sre_dev_req_t.fresh) instead of a fill of the context in front of it */
+    size_t             small_off;   /* offset of the small-input area (SRE_SMALL_INPUT bytes) inside the pinned block */
     /* context state accumulated while its searches ran on the scanner */
     uint32_t           preset_valid, preset_flags;
     int64_t            preset_processed;
@@ -155,7 +160,9 @@ device_stream_open(sre_pool_t *pool, sre_program_t *prog, size_t ctx_bytes, size
 {
     sre_hip_program_s *dp = sre_hip_program_get(prog);
     if (dp == NULL) return NULL;
-    const size_t blk = sizeof(HostBlock) + ovec_slots * sizeof(int64_t);
+    /* [request][result][ovector][a chunk of up to SRE_SMALL_INPUT bytes] */
+    const size_t small_off = (sizeof(HostBlock) + ovec_slots * sizeof(int64_t) + 15) & ~(size_t) 15;
+    const size_t blk = small_off + SRE_SMALL_INPUT;
 
     DeviceStream *ds = NULL;
     {
@@ -175,8 +182,9 @@ device_stream_open(sre_pool_t *pool, sre_program_t *prog, size_t ctx_bytes, size
         ds->failed = 0;
         ds->preset_valid = ds->preset_flags = 0;
         ds->preset_processed = 0;
-        memset(ds->h_blk, 0, blk);
-        SRE_HIP_TRY(hipMemsetAsync(ds->d_ctx, 0, ctx_bytes, ds->stream));
+        ds->ctx_fresh = 1;
+        ds->small_off = small_off;
+        memset(ds->h_blk, 0, small_off);
         if (sre_pool_add_cleanup(pool, device_stream_release, ds) != SRE_OK) goto hip_failed;
         return ds;
     }
@@ -188,11 +196,12 @@ device_stream_open(sre_pool_t *pool, sre_program_t *prog, size_t ctx_bytes, size
     ds->ctx_bytes = ctx_bytes;
     /* room to be reused by the next program too */
     ds->ctx_cap = ctx_bytes < 64 * 1024 ? 64 * 1024 : ctx_bytes;
-    ds->blk_cap = blk < 1024 ? 1024 : blk;
+    ds->blk_cap = blk < 4096 ? 4096 : blk;
+    ds->ctx_fresh = 1;
+    ds->small_off = small_off;
 
     SRE_HIP_TRY(hipStreamCreateWithFlags(&ds->stream, hipStreamNonBlocking));
     SRE_HIP_TRY(hipMalloc(&ds->d_ctx, ds->ctx_cap));
-    SRE_HIP_TRY(hipMemsetAsync(ds->d_ctx, 0, ctx_bytes, ds->stream));
     SRE_HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&ds->h_blk), ds->blk_cap, hipHostMallocMapped));
     SRE_HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void **>(&ds->d_blk), ds->h_blk, 0));
     memset(ds->h_blk, 0, ds->blk_cap);
@@ -223,8 +232,17 @@ device_stream_exec(DeviceStream *ds, const sre_char *input, size_t len, unsigned
     rq->preset_valid = ds->preset_valid;
     rq->preset_processed = ds->preset_processed;
     rq->preset_flags = ds->preset_flags;
+    rq->fresh = ds->ctx_fresh ? 1u : 0u;
+    rq->input_pinned = 0;
+    ds->ctx_fresh = 0;
     if (len > 0 && len <= 8) {
         memcpy(&rq->inline_bytes, input, len);
+    } else if (len <= SRE_SMALL_INPUT && len > 8) {
+        /* next to the request, in the pinned block: the kernel stages it into LDS itself (a copy
+         * of its own costs more than the whole call should) */
+        memcpy(reinterpret_cast<uint8_t *>(ds->h_blk) + ds->small_off, input, len);
+        rq->input = reinterpret_cast<const uint8_t *>(ds->d_blk) + ds->small_off;
+        rq->input_pinned = 1;
     } else if (len > 8) {
         if (len > ds->in_cap) {
             if (ds->d_in) (void) hipFree(ds->d_in);
@@ -747,7 +765,7 @@ stage_input(DeviceStream *ds, const sre_char *input, size_t len, RingTicket *tic
         const int r = ticket && helpers ? ring_begin(ds, input, len, *ticket) : ring_upload(ds, input, len);
         if (r <= 0) return r;
     }
-    if (len < SRE_STAGE_MIN || len > SRE_STAGE_PIECE) {
+    if (len > SRE_STAGE_PIECE) {
         return hipMemcpyAsync(ds->d_in, input, len, hipMemcpyHostToDevice, ds->stream) == hipSuccess ? 0 : -1;
     }
     /* one pinned buffer: exec() is synchronous, the copy out of it has finished (its
@@ -968,11 +986,7 @@ pike_stream_route(sre_vm_pike_ctx_t *ctx, sre_char *input, size_t len, unsigned 
             return 0;
         }
     }
-    if (!ctx->stream_mode
-        && hipMemsetAsync(ds->d_sctx, 0, offsetof(sre_stream_ctx_t, pending_vec), ds->stream) != hipSuccess)
-    {
-        return 0;
-    }
+    /* (a search that starts with this chunk: the tail kernel ignores what the context holds) */
     static const bool dbg_t = getenv("SRE_HIP_DEBUG_TIMING") != NULL;
     const auto t_a = std::chrono::steady_clock::now();
     /* (a chunk that travels through the ring is still being copied when the scan is queued) */
@@ -1100,6 +1114,15 @@ sre_vm_pike_exec(sre_vm_pike_ctx_t *ctx, sre_char *input, size_t len, unsigned e
         && ctx->ovec_slots >= 2)
     {
         sre_int_t rc;
+        /* a small buffer: as the one chunk of a stream — scan + tail, the result in pinned memory
+         * the host watches; the batch path below ends with two copies back and a wait on the
+         * queue (a 63-byte call: 53 us) */
+        if (len <= SRE_COMPAT_ONE_CHUNK_MAX && !ctx->prog->lookahead_asserts
+            && pike_stream_route(ctx, input, len, 1, pending_matched, &rc))
+        {
+            g_route_counts[0]++;
+            return rc;
+        }
         if (pike_scan_route(ctx, input, len, &rc)) {
             g_route_counts[0]++;
             return rc;
@@ -1148,18 +1171,17 @@ sre_vm_pike_exec(sre_vm_pike_ctx_t *ctx, sre_char *input, size_t len, unsigned e
              * came back with the result: the host takes the state over and the next call is routed
              * afresh — a stream whose first chunk was a short header line no longer keeps every
              * later search on the exact VM (round-2 advisor finding).  The device context is
-             * zero-filled so that the VM kernel, if it is needed again, starts from the preset. */
+             * flagged fresh so that the VM kernel, if it is needed again, starts from the preset. */
             ctx->processed_bytes = (sre_int_t) res->pad[1];
             ctx->empty_capture = (res->pad[0] & SRE_PRESET_EMPTY_CAPTURE) != 0;
             ctx->seen_newline = (res->pad[0] & SRE_PRESET_SEEN_NEWLINE) != 0;
             ctx->seen_word = (res->pad[0] & SRE_PRESET_SEEN_WORD) != 0;
             ctx->eof = (res->pad[0] & SRE_PRESET_EOF) != 0;
-            if (hipMemsetAsync(ds->d_ctx, 0, ds->ctx_bytes, ds->stream) == hipSuccess) {
-                ds->preset_valid = ds->preset_flags = 0;
-                ds->preset_processed = 0;
-                ctx->vm_touched = 0;
-                ctx->at_boundary = 1;
-            }
+            ds->ctx_fresh = 1;
+            ds->preset_valid = ds->preset_flags = 0;
+            ds->preset_processed = 0;
+            ctx->vm_touched = 0;
+            ctx->at_boundary = 1;
         }
     } else if (rc == SRE_AGAIN) {
         /* temporary $& range only (reference sre_vm_pike.c:700-701) */
@@ -1281,6 +1303,14 @@ sre_vm_thompson_exec(sre_vm_thompson_ctx_t *ctx, sre_char *input, size_t len, un
             return rc;
         }
         if (ctx->stream_mode) return SRE_ERROR;
+    }
+    if (!ctx->started && eof && len >= SRE_COMPAT_SCAN_MIN_BYTES && len <= SRE_COMPAT_ONE_CHUNK_MAX) {
+        /* a small buffer: as the one chunk of a stream (see sre_vm_pike_exec) */
+        sre_int_t rc;
+        if (thompson_stream_route(ctx, input, len, 1, &rc)) {
+            g_route_counts[0]++;
+            return rc;
+        }
     }
     if (!ctx->started && eof && len >= SRE_COMPAT_SCAN_MIN_BYTES) {
         /* first and only chunk of a large stream: match / no match from the scanner */
