@@ -841,6 +841,33 @@ sre_hip_compat_trim(void)
         g_nparked = 0;
     }
     for (int i = 0; i < n; i++) device_stream_destroy(gone[i]);
+    /* ... and the pinned ring with its helper threads (started again by the next large chunk) */
+    {
+        std::lock_guard<std::mutex> job_lock(g_copy_mutex);
+        CopyPool *P = g_copy_pool;
+        if (P != NULL) {
+            /* the last chunk's fetch may still read the ring */
+            if (P->last_epoch != 0) {
+                const auto t0 = std::chrono::steady_clock::now();
+                while ((uint32_t) __atomic_load_n(&P->h_ctl->chunk_done, __ATOMIC_ACQUIRE) != P->last_epoch
+                       && std::chrono::steady_clock::now() - t0 < std::chrono::seconds(5))
+                {
+                }
+            }
+            {
+                std::lock_guard<std::mutex> lk(P->m);
+                P->stop = true;
+                P->generation.fetch_add(1, std::memory_order_release);
+            }
+            P->cv_work.notify_all();
+            for (auto &t : P->threads) t.join();
+            (void) hipHostFree(P->h_ring);
+            (void) hipHostFree(P->h_ctl);
+            (void) hipFree(P->d_counters);
+            delete P;
+            g_copy_pool = NULL;
+        }
+    }
     return n;
 }
 
