@@ -19,6 +19,13 @@
  *      match, lower-priority threads are dropped.
  * Between steps the leading-byte skip (:256-309) compares the list with the snapshot by one
  * ballot and looks for the next byte that can start a match 64 bytes at a time.
+ * STABLE RUNS.  Captures never steer the VM, so a byte step is a function of (ordered list, seen_start_state,
+ * byte).  A step that hands every thread its own place back — parent == itself, nothing saved on the
+ * way, no MATCH — with seen_start_state as it was has changed NOTHING the later steps or the result can
+ * see; its byte joins a 256-bit set that is valid while the list stands, and the bytes of that set that
+ * follow are skipped 512 at a time (the reference's leading-byte skip, :256-309, for ANY list that loops
+ * in place: [a-z]+ inside a word, .* behind its x, the idle .*? list of a program with too many leading
+ * bytes for :992-1061).  Any other step drops the set.  tests/pwave_sim.cpp models it (on and off).
  * Everything the reference's quirks need is kept: seen_start_state, the snapshot without its last
  * thread, a skip target stepped without a check, the poisoned context.  Control flow is uniform;
  * the list (thread id per lane) and the capture vectors (one column per lane, slot-major) live in
@@ -74,6 +81,8 @@ struct PikeWave {
     uint32_t *stamp;        /* [64] */
     uint16_t *initial;      /* [64] */
     uint8_t  *inl;          /* [16] */
+    uint32_t *stab;         /* [8] the stable-run byte set of the current list */
+    uint32_t *lab;          /* two lists x [64]: equal labels => equal capture columns (copies of one column) */
     /* uniform state */
     const uint8_t *in;
     uint32_t nleading, nregexes;    /* (of the header: read once — a load per byte from global memory was the step's largest cost) */
@@ -86,6 +95,7 @@ struct PikeWave {
     uint32_t seen_newline, sss, initial_count, has_matched, poisoned;
     uint32_t empty_capture, ctx_eof;    /* the re-armed context of a find-all iteration (:179-196, :616-628) */
     uint32_t first_buf, seen_word;      /* a context fed in chunks (exec_chunk) */
+    uint32_t stab_on, stab_x, step_stable;
     int64_t  matched_id;
 
     __device__ __forceinline__ sre_pwave_entry_t entry(uint32_t idx) const
@@ -120,6 +130,7 @@ struct PikeWave {
         e.saves = 0;
         if (valid) e = entry(L.off + lane);
         if (valid) tidvb[(cur) * 64u + lane] = e.tid;
+        lab[(cur) * 64u + lane] = lane;
         const int64_t at = processed + pos;
         for (uint32_t s = 0; s < nslots; s++) {
             if (valid) capsb[(size_t) (cur) * nslots_x64() + s * 64 + lane] = ((e.saves >> s) & 1) ? at : (int64_t) -1;
@@ -143,6 +154,44 @@ struct PikeWave {
             pos += 64;
         }
         return last;
+    }
+
+    /* first position >= pos whose byte is not in the stable set (or `last`): eight 64-byte loads in flight */
+    __device__ __forceinline__ int64_t skip_stable(int64_t pos, int64_t last) const
+    {
+        while (pos < last) {
+            uint32_t c[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const int64_t p = pos + k * 64 + lane;
+                c[k] = p < last ? (uint32_t) in[p] : 256u;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const bool     stop = c[k] > 255u || !((stab[(c[k] >> 5) & 7u] >> (c[k] & 31)) & 1u);
+                const uint64_t m = __builtin_amdgcn_ballot_w64(stop);
+                if (m) return pos + k * 64 + __builtin_ctzll(m);
+            }
+            pos += 512;
+        }
+        return last;
+    }
+
+    /* after the step of an iteration: its byte joins the set, or the set is dropped */
+    __device__ __forceinline__ void learn(bool plain, uint32_t c, uint32_t x_in)
+    {
+        if (plain && step_stable && sss == x_in) {
+            if (!stab_on || stab_x != x_in) {
+                if (lane < 8) stab[lane] = 0;
+                stab_x = x_in;
+                stab_on = 1;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            if (lane == 0) stab[c >> 5] |= 1u << (c & 31);
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        } else {
+            stab_on = 0;
+        }
     }
 
     /* the input byte at `pos` (< last): the wave loads 64 bytes at a time, lane l byte l, and a
@@ -208,10 +257,11 @@ struct PikeWave {
         if (stamp_cur >= (1u << 26) - 2u) {
             stamp[lane] = 0;
             stamp_cur = 0;
+            lab[(cur) * 64u + lane] = lane;         /* (fresh labels are (stamp << 6) | rank: start over, all distinct) */
         }
         stamp_cur++;
         uint32_t nn = 0;
-        bool     done = false, first_batch = true;
+        bool     done = false, first_batch = true, moved = false;
         uint32_t d_off = 0, d_len = 0;
         for (uint64_t rem = src; rem;) {
             uint32_t owner = 0, kbase = 0, loff = 0, total = 0;
@@ -246,6 +296,11 @@ struct PikeWave {
             const uint64_t km = __builtin_amdgcn_ballot_w64(keep);
             const uint32_t rank = nn + pw_lane_rank(km);
             if (keep) tidvb[(nxt) * 64u + rank] = e.tid;
+            /* stable runs: does every place keep its thread and its column — nothing saved on the way, and the
+             * parent's column known to equal the one the place held (labels)? */
+            const uint32_t lo = lab[(cur) * 64u + owner];
+            if (keep) lab[(nxt) * 64u + rank] = e.saves ? ((stamp_cur << 6) | rank) : lo;
+            moved = moved || __builtin_amdgcn_ballot_w64(keep && (e.saves != 0 || tidvb[(cur) * 64u + rank] != e.tid || lab[(cur) * 64u + rank] != lo)) != 0;
             /* the owner's capture vector, slot by slot */
             for (uint32_t s = 0; s < nslots; s++) {
                 const int64_t v = capsb[(size_t) (cur) * nslots_x64() + s * 64 + owner];
@@ -268,6 +323,7 @@ struct PikeWave {
             done = true;
         }
         if (done) has_matched = 1;
+        step_stable = !at_end && !done && !moved && nn == n;
         cur = nxt;
         n = nn;
         return done;
@@ -312,27 +368,38 @@ struct PikeWave {
             seed(sp);
         }
 
+        stab_on = 0;
         for (; !skip_ran_out && sp <= last; sp++) {             /* :235 (eof) */
             if (n == 0) break;
+            bool     plain = true;
+            uint32_t x_in = sss;
             if (no_check_once) {
                 no_check_once = false;
-            } else if (nleading && sss) {                    /* :256-309 */
-                sss = 0;
-                bool same = (sp != last) && (n == initial_count);
-                if (same) {
-                    const bool diff = lane + 1 < n && tidvb[(cur) * 64u + lane] != initial[lane];
-                    same = __builtin_amdgcn_ballot_w64(diff) == 0;
-                }
-                if (same) {
-                    const int64_t p = find_first_byte(sp, last);
-                    if (p > sp) {
-                        sp = p;
-                        seed(sp);
-                        if (sp == last) break;
+                plain = false;
+            } else {
+                if (stab_on && sss == stab_x && sp < last) sp = skip_stable(sp, last);     /* a stable run */
+                x_in = sss;
+                if (nleading && sss) {                       /* :256-309 */
+                    sss = 0;
+                    bool same = (sp != last) && (n == initial_count);
+                    if (same) {
+                        const bool diff = lane + 1 < n && tidvb[(cur) * 64u + lane] != initial[lane];
+                        same = __builtin_amdgcn_ballot_w64(diff) == 0;
+                    }
+                    if (same) {
+                        const int64_t p = find_first_byte(sp, last);
+                        if (p > sp) {
+                            sp = p;
+                            seed(sp);
+                            plain = false;
+                            if (sp == last) break;
+                        }
                     }
                 }
             }
+            const uint32_t c = sp < last ? byte_at(sp, last) : 0u;
             if (step(sp, last)) last_matched_pos = matched_end();
+            learn(plain && sp < last, c, x_in);
             if (sp == last) break;
         }
 
@@ -398,8 +465,15 @@ struct PikeWave {
             initial_count = n;
             if (lane + 1 < n) initial[lane] = tidvb[(cur) * 64u + lane];
         }
+        stab_on = 0;
         for (; sp < last || (eof && sp == last); sp++) {        /* :235 */
             if (n == 0) break;
+            bool plain = true;
+            if (stab_on && sss == stab_x && sp < last) {        /* a stable run */
+                sp = skip_stable(sp, last);
+                if (sp == last && !eof) break;
+            }
+            const uint32_t x_in = sss;
             if (nleading && sss) {                           /* :256-309 */
                 sss = 0;
                 bool same = (sp != last) && (n == initial_count);
@@ -412,11 +486,14 @@ struct PikeWave {
                     if (p > sp) {
                         sp = p;
                         seed(sp);
+                        plain = false;
                         if (sp == last) break;
                     }
                 }
             }
+            const uint32_t c = sp < last ? byte_at(sp, last) : 0u;
             if (step(sp, last)) last_matched_pos = matched_end();
+            learn(plain && sp < last, c, x_in);
             if (sp == last) break;
         }
         *consumed = sp;
@@ -499,6 +576,7 @@ pwave_lds_bytes(const sre_pwave_hdr_t *h, bool *ents_in_lds)
     b += 64 * 8;                                /* matched */
     b += 16;                                    /* a chunk that travels in the request (sre_k_pike_exec_wave) */
     b += 32;                                    /* leading-byte map */
+    b += 32 + 2 * 64 * 4;                       /* stable-run byte set, column labels */
     b += 2 * 64 * 2 + 64 * 4 + 64 * 2;          /* tidv, stamp, initial */
     b += 64 * 8 * 4 + 64 * 2 * 2;               /* accept words, tid_list, tid_match */
     b += (size_t) h->nlists * SRE_PWAVE_NCTX * sizeof(sre_pwave_list_t);
@@ -521,6 +599,11 @@ pwave_setup(PikeWave<ENTS_LDS> &vm, const sre_pwave_hdr_t *Wg, uint8_t *lds, uin
     uint32_t *lead = reinterpret_cast<uint32_t *>(p);   p += 32;
     if (lane < 8) lead[lane] = Wg->lead[lane];
     vm.lead = lead;
+    vm.stab = reinterpret_cast<uint32_t *>(p);      p += 32;
+    vm.lab = reinterpret_cast<uint32_t *>(p);       p += 2 * 64 * 4;
+    vm.stab_on = 0;
+    vm.stab_x = 0;
+    vm.step_stable = 0;
     uint32_t *accw = reinterpret_cast<uint32_t *>(p);   p += 64 * 8 * 4;
     vm.stamp = reinterpret_cast<uint32_t *>(p);     p += 64 * 4;
     vm.tidvb = reinterpret_cast<uint16_t *>(p);     p += 2 * 64 * 2;
@@ -773,6 +856,7 @@ sre_k_pike_exec_wave(const sre_pwave_hdr_t *__restrict__ Wg, const sre_dev_req_t
         vm.processed = cx->processed;
         vm.matched_id = cx->matched_id;
         vm.tidvb[(0) * 64u + lane] = cx->tidv[lane];
+        vm.lab[(0) * 64u + lane] = lane;
         vm.initial[lane] = cx->initial[lane];
         vm.matched[lane] = cx->matched[lane];
         if (lane < vm.n) {

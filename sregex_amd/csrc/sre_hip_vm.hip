@@ -648,26 +648,83 @@ wave_uniform64(uint64_t v)
     return ((uint64_t) hi << 32) | lo;
 }
 
-/* one exec() of sre_vm_thompson_exec on the set S; input == nullptr: the (<= 8) bytes travel in `inl` */
+/* one exec() of sre_vm_thompson_exec on the set S; input == nullptr: the (<= 8) bytes travel in `inl`.
+ * STABLE RUNS: the step is a function of (S, byte), so a byte that maps S to itself joins a 256-bit set
+ * kept for that S, and from the second such step in a row on the bytes of the set that follow are
+ * skipped — inside the block by one ballot, across blocks 512 bytes at a time (`[a-z]+` inside a word,
+ * the idle set of a program between candidates). */
 __device__ inline int64_t
 thompson_wave_run(const sre_dev_wave_t *W, uint64_t &S, const uint8_t *input, uint64_t inl, uint64_t size, bool eof)
 {
+    __shared__ uint32_t stab[8];
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t pred = W->pred[lane];
     const uint32_t pred_lo = (uint32_t) pred, pred_hi = (uint32_t) (pred >> 32);
     const uint64_t match = wave_uniform64(W->match);
-    for (uint64_t base = 0; base < size; base += 64) {
+    uint64_t       stabS = 0;
+    bool           stab_valid = false, streak = false;
+    uint64_t       base = 0;
+    while (base < size) {
+        if (streak && stab_valid && stabS == S && input != nullptr) {
+            /* across blocks: the first byte at or behind `base` that is not in the set */
+            bool found = false;
+            while (!found && base < size) {
+                uint32_t c[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const uint64_t p = base + (uint64_t) k * 64 + lane;
+                    c[k] = p < size ? (uint32_t) input[p] : 256u;
+                }
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const bool     stop = c[k] > 255u || !((stab[(c[k] >> 5) & 7u] >> (c[k] & 31)) & 1u);
+                    const uint64_t m = __builtin_amdgcn_ballot_w64(stop);
+                    if (!found && m) {
+                        base += (uint64_t) k * 64 + (uint64_t) __builtin_ctzll(m);
+                        found = true;
+                    }
+                }
+                if (!found) base += 512;
+            }
+            if (base >= size) break;
+        }
         const uint64_t idx = base + lane;
         uint32_t       byte = 0;
         if (idx < size) byte = input != nullptr ? input[idx] : (uint32_t) ((inl >> (8 * idx)) & 0xffu);
         const uint64_t acc = W->accept[byte];
         const uint32_t nb = size - base < 64 ? (uint32_t) (size - base) : 64u;
-        for (uint32_t i = 0; i < nb; i++) {
+        uint32_t       i = 0;
+        while (i < nb) {
             if (S == 0) return eof ? RC_DECLINED : RC_AGAIN;            /* :89 the list is empty */
             if (S & match) return RC_OK;                                /* :233-235 */
             const uint64_t T = S & wave_readlane64(acc, i);
-            S = __builtin_amdgcn_ballot_w64(((pred_lo & (uint32_t) T) | (pred_hi & (uint32_t) (T >> 32))) != 0);
+            const uint64_t S1 = __builtin_amdgcn_ballot_w64(((pred_lo & (uint32_t) T) | (pred_hi & (uint32_t) (T >> 32))) != 0);
+            i++;
+            if (S1 != S) {
+                S = S1;
+                streak = false;
+                continue;
+            }
+            if (streak) {
+                const uint32_t b = (uint32_t) __builtin_amdgcn_readlane((int) byte, (int) (i - 1));
+                if (!stab_valid || stabS != S) {
+                    if (lane < 8) stab[lane] = 0;
+                    stabS = S;
+                    stab_valid = true;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                if (lane == 0) stab[b >> 5] |= 1u << (b & 31);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                if (i < nb) {
+                    /* inside the block: the run of set bytes from lane i on */
+                    const bool     mem = lane < nb && ((stab[byte >> 5] >> (byte & 31)) & 1u);
+                    const uint64_t stopm = ~__builtin_amdgcn_ballot_w64(mem) >> i;     /* (lanes >= nb stop it) */
+                    i += stopm ? (uint32_t) __builtin_ctzll(stopm) : 64u - i;
+                }
+            }
+            streak = true;
         }
+        base += nb;
     }
     /* the extra iteration at end of input (:88): a listed MATCH is met, nothing consumes */
     if (eof && (S & match)) return RC_OK;

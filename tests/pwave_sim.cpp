@@ -19,6 +19,9 @@
 
 namespace {
 
+int     g_ff_enabled = 1;
+int64_t g_ff_bytes = 0;
+
 struct Sim {
     const sre_pwave_hdr_t   *W;
     const sre_pwave_list_t  *lists;
@@ -32,6 +35,28 @@ struct Sim {
     std::vector<int64_t>     caps[2], matched;
     uint16_t                 tidv[2][64], initial[64];
     uint32_t                 stamp[64];
+    uint32_t                 lab[2][64];     /* equal labels => equal capture columns */
+    /* stable runs (sre_hip_pwave.hip "stable runs"): bytes whose step left list, columns and sss as they were */
+    uint32_t                 stab[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stab_on = 0, stab_x = 0, step_stable = 0;
+
+    int64_t skip_stable(int64_t pos, int64_t last)
+    {
+        while (pos < last && ((stab[in[pos] >> 5] >> (in[pos] & 31)) & 1)) pos++;
+        return pos;
+    }
+    void learn(bool plain, uint32_t c, uint32_t x_in)
+    {
+        if (plain && step_stable && sss == x_in && g_ff_enabled) {
+            if (!stab_on || stab_x != x_in) {
+                memset(stab, 0, sizeof(stab));
+                stab_x = x_in;
+                stab_on = 1;
+            }
+            stab[c >> 5] |= 1u << (c & 31);
+        } else {
+            stab_on = 0;
+        }
+    }
 
     uint32_t ctx_at(int64_t pos) const
     {
@@ -44,6 +69,7 @@ struct Sim {
         for (uint32_t k = 0; k < L.len; k++) {
             const sre_pwave_entry_t e = ents[L.off + k];
             tidv[cur][k] = e.tid;
+            lab[cur][k] = k;
             for (uint32_t s = 0; s < nslots; s++) caps[cur][s * 64 + k] = ((e.saves >> s) & 1) ? processed + pos : -1;
         }
         n = L.len;
@@ -90,84 +116,40 @@ struct Sim {
             }
             seed(sp);
         }
+        stab_on = 0;
         for (; !skip_ran_out && sp <= last; sp++) {
             if (n == 0) break;
+            bool     plain = true;
+            uint32_t x_in = sss;
             if (no_check_once) {
                 no_check_once = false;
-            } else if (W->nleading && sss) {
-                sss = 0;
-                bool same = (sp != last) && (n == initial_count);
-                for (uint32_t k = 0; same && k + 1 < n; k++) same = tidv[cur][k] == initial[k];
-                if (same) {
-                    const int64_t p = find_first_byte(sp, last);
-                    if (p > sp) {
-                        sp = p;
-                        seed(sp);
-                        if (sp == last) break;
+                plain = false;
+            } else {
+                if (stab_on && sss == stab_x && sp < last) {
+                    const int64_t p = skip_stable(sp, last);
+                    g_ff_bytes += p - sp;
+                    sp = p;
+                }
+                x_in = sss;
+                if (W->nleading && sss) {
+                    sss = 0;
+                    bool same = (sp != last) && (n == initial_count);
+                    for (uint32_t k = 0; same && k + 1 < n; k++) same = tidv[cur][k] == initial[k];
+                    if (same) {
+                        const int64_t p = find_first_byte(sp, last);
+                        if (p > sp) {
+                            sp = p;
+                            seed(sp);
+                            plain = false;
+                            if (sp == last) break;
+                        }
                     }
                 }
             }
-            const bool     at_end = sp == last;
-            const uint32_t c = at_end ? 0u : in[sp];
-            const uint32_t nxt = cur ^ 1u;
-            const int64_t  pos1 = processed + sp + 1;
-            uint32_t       m = 64, d = 64;
-            uint64_t       src = 0;
-            sre_pwave_list_t Ls[64];
-            for (uint32_t i = 0; i < n; i++) {
-                const uint32_t t = tidv[cur][i];
-                if (W->tid_match[t]) {
-                    if (m == 64) m = i;
-                    continue;
-                }
-                if (at_end || !((W->accept[t][c >> 5] >> (c & 31)) & 1)) continue;
-                src |= 1ull << i;
-                Ls[i] = lists[(uint32_t) W->tid_list[t] * SRE_PWAVE_NCTX + (c == '\n' ? 1u : 0u)];
-            }
-            if (m < 64) src &= (1ull << m) - 1;
-            for (uint32_t i = 0; i < 64; i++) {
-                if (((src >> i) & 1) && Ls[i].done) {
-                    d = i;
-                    break;
-                }
-            }
-            if (d < 63) src &= (2ull << d) - 1;
-            stamp_cur++;
-            uint32_t nn = 0;
-            bool     done = false;
-            for (uint32_t i = 0; i < 64; i++) {
-                if (!((src >> i) & 1)) continue;
-                const sre_pwave_list_t L = Ls[i];
-                if (L.sss) sss = 1;
-                for (uint32_t k = 0; k < L.len; k++) {
-                    const sre_pwave_entry_t e = ents[L.off + k];
-                    if (stamp[e.tid] == stamp_cur) continue;
-                    stamp[e.tid] = stamp_cur;
-                    tidv[nxt][nn] = e.tid;
-                    for (uint32_t s = 0; s < nslots; s++) {
-                        caps[nxt][s * 64 + nn] = ((e.saves >> s) & 1) ? pos1 : caps[cur][s * 64 + i];
-                    }
-                    nn++;
-                }
-                if (i == d) {
-                    const sre_pwave_entry_t me = ents[L.off + L.len];
-                    for (uint32_t s = 0; s < nslots; s++) matched[s] = ((me.saves >> s) & 1) ? pos1 : caps[cur][s * 64 + i];
-                    matched_id = (int64_t) W->tid_match[me.tid] - 1;
-                    done = true;
-                }
-            }
-            if (!done && m < 64) {
-                for (uint32_t s = 0; s < nslots; s++) matched[s] = caps[cur][s * 64 + m];
-                matched_id = (int64_t) W->tid_match[tidv[cur][m]] - 1;
-                done = true;
-            }
-            if (done) {
-                has_matched = 1;
-                last_matched_pos = matched[1];
-            }
-            cur = nxt;
-            n = nn;
-            if (at_end) break;
+            const uint32_t c = sp < last ? in[sp] : 0u;
+            if (step(sp, last)) last_matched_pos = matched[1];
+            learn(plain && sp < last, c, x_in);
+            if (sp == last) break;
         }
         if (last_matched_pos >= 0) {
             const int64_t p = last_matched_pos - processed;
@@ -221,8 +203,17 @@ struct Sim {
             initial_count = n;
             for (uint32_t k = 0; k + 1 < n; k++) initial[k] = tidv[cur][k];
         }
+        stab_on = 0;
         for (; sp < last || (eof && sp == last); sp++) {
             if (n == 0) break;
+            bool plain = true;
+            if (stab_on && sss == stab_x && sp < last) {
+                const int64_t p = skip_stable(sp, last);
+                g_ff_bytes += p - sp;
+                sp = p;
+                if (sp == last && !eof) break;
+            }
+            const uint32_t x_in = sss;
             if (W->nleading && sss) {
                 sss = 0;
                 bool same = (sp != last) && (n == initial_count);
@@ -232,11 +223,14 @@ struct Sim {
                     if (p > sp) {
                         sp = p;
                         seed(sp);
+                        plain = false;
                         if (sp == last) break;
                     }
                 }
             }
+            const uint32_t c = sp < last ? in[sp] : 0u;
             if (step(sp, last)) last_matched_pos = matched[1];
+            learn(plain && sp < last, c, x_in);
             if (sp == last) break;
         }
         if (last_matched_pos >= 0) {
@@ -320,7 +314,7 @@ struct Sim {
         if (d < 63) src &= (2ull << d) - 1;
         stamp_cur++;
         uint32_t nn = 0;
-        bool     done = false;
+        bool     done = false, moved = false;
         for (uint32_t i = 0; i < 64; i++) {
             if (!((src >> i) & 1)) continue;
             const sre_pwave_list_t L = Ls[i];
@@ -331,6 +325,10 @@ struct Sim {
                 stamp[e.tid] = stamp_cur;
                 tidv[nxt][nn] = e.tid;
                 for (uint32_t s = 0; s < nslots; s++) caps[nxt][s * 64 + nn] = ((e.saves >> s) & 1) ? pos1 : caps[cur][s * 64 + i];
+                /* a thread that keeps its place and its column: nothing saved on the way, and the parent's
+                 * column is known to equal the one the place held (labels: copies of one column) */
+                lab[nxt][nn] = e.saves ? ((stamp_cur << 6) | nn) : lab[cur][i];
+                if (e.saves != 0 || nn >= n || tidv[cur][nn] != e.tid || lab[cur][nn] != lab[cur][i]) moved = true;
                 nn++;
             }
             if (i == d) {
@@ -346,6 +344,7 @@ struct Sim {
             done = true;
         }
         if (done) has_matched = 1;
+        step_stable = !at_end && !done && !moved && nn == n;
         cur = nxt;
         n = nn;
         return done;
@@ -355,6 +354,10 @@ struct Sim {
 }  // namespace
 
 extern "C" {
+
+/* the stable-run fast-forward on / off (the tests compare both with the oracle), and how many bytes it skipped */
+void pwave_sim_set_ff(int on) { g_ff_enabled = on; }
+int64_t pwave_sim_ff_bytes(void) { return g_ff_bytes; }
 
 void *pwave_sim_build(const sre_program_t *prog) { return sre_pwave_build(prog); }
 void pwave_sim_free(void *h) { free(h); }

@@ -119,6 +119,27 @@ def test_exact_vm_per_stream_rate(lib):
                 row[key + "_MBps"] = L / t / 1e6
             rows.append(row)
             print(row)
+    # the other end: a subject whose list changes with nearly every byte (no stable runs to skip) —
+    # the rate of the bare wave step
+    import random
+    rng = random.Random(7)
+    noise = bytes(rng.choice(b"ab@. c") for _ in range(1 << 18))
+    nbuf = S.DeviceBuffer.from_bytes(noise)
+    with S.Pool() as pool:
+        re = S.parse(pool, [rb"([a-z]+)@([a-z]+)\.[a-z]+x"])
+        prog = S.compile(pool, re)
+        want = S.Scanner(pool, prog, S.HIP_PIKE_FIRST, S.ENGINE_SCAN).scan([nbuf.ptr], [len(noise)])[0]
+        row = {"case": "([a-z]+)@([a-z]+)\\.[a-z]+x over random 'ab@. c' (the list changes with nearly every byte)", "bytes": len(noise)}
+        for mode, key in ((S.HIP_PIKE_FIRST, "pike"), (S.HIP_THOMPSON, "thompson")):
+            sc = S.Scanner(pool, prog, mode, S.ENGINE_VM)
+            got = sc.scan([nbuf.ptr], [len(noise)])[0]
+            assert got == want if mode == S.HIP_PIKE_FIRST else (got[0] >= 0) == (want[0] >= 0), (got, want)
+            t = _time(lambda: sc.scan([nbuf.ptr], [len(noise)]), 2)
+            row[key + "_ms"] = t * 1e3
+            row[key + "_MBps"] = len(noise) / t / 1e6
+        rows.append(row)
+        print(row)
+    nbuf.free()
     out = os.path.join(harness.ROOT, "gpurun_out")
     os.makedirs(out, exist_ok=True)
     with open(os.path.join(out, "vm_rate.json"), "w") as f:

@@ -1317,6 +1317,81 @@ def test_scanner_random_patterns_vs_oracle(gpu, seg):
                                for b in bad[:6]])
 
 
+def test_exact_vm_stable_runs_vs_oracle(gpu):
+    """Stable runs on the exact VM (sre_hip_pwave.hip / thompson_wave_run): subjects made of long runs,
+    over which most lists loop in place and the wave skips 512 bytes at a time — ENGINE_VM scans in all
+    three modes, and sre_vm_pike_exec / sre_vm_thompson_exec fed in chunks that stay on the VM (a short
+    first chunk), against the oracle.  tests/test_pwave_model.py checks the same on the CPU model."""
+    import random
+    ora = harness.OracleEngine()
+    eng = harness.ProductEngine()
+    rng = random.Random(int(os.environ.get("SRE_FUZZ_SEED", "20261004")) + 77)
+    alphabet = b"abcx \n_."
+
+    def runs(total):
+        out = bytearray()
+        while len(out) < total:
+            out += bytes([rng.choice(alphabet)]) * rng.choice([1, 1, 2, 3, 9, 30, 70, 150, 700])
+        return bytes(out[:total])
+
+    zoo = [[rb"[a-z]+@[a-z]+\.[a-z]+"], [rb"([a-z]+)@([a-z]+)\.[a-z]+"], [rb"a+b"], [rb"(a+)(b+)?"], [rb"x(.*)y(.*)z"],
+           [rb"^a+c"], [rb"(?:a|b)*c"], [rb"a.*b"], [rb"(a*)*x"], [rb"\n+a"], [rb"[^x]+x", rb"a+_"], [rb"(?:aa)+b"],
+           [rb"(a|ab)(c|bcd)(d*)"], [rb"a{3,}b"], [rb"(?:.|\n)*x"], [rb"\s+\S"], [rb"(?:a|b)*a(?:a|b){7}_"]]
+    progs = zoo + [[harness.random_regex(rng) for _ in range(1 if rng.random() < 0.8 else 2)] for _ in range(220)]
+    modes = (S.HIP_THOMPSON, S.HIP_PIKE_FIRST, S.HIP_PIKE_COUNT)
+    bad, n, fed = [], 0, 0
+    for k, pats in enumerate(progs):
+        if prog_has_lookahead(pats):
+            continue            # the one-lane kernels (no stable runs there)
+        with S.Pool() as pool:
+            try:
+                re = S.parse(pool, pats)
+            except Exception:
+                continue
+            prog = S.compile(pool, re)
+            nov = 2 * (re.ncaps + 1)
+            datas = [runs(rng.choice([300, 2000, 6000])) for _ in range(4)]
+            bufs = [S.DeviceBuffer.from_bytes(d) for d in datas]
+            got = {m: S.Scanner(pool, prog, m, S.ENGINE_VM).scan([b.ptr for b in bufs], [len(d) for d in datas]) for m in modes}
+            for i, d in enumerate(datas):
+                first, cnt = _expect(ora, prog, re.ncaps, d)
+                t = ora.thompson(prog)
+                th = t.exec(d, True)
+                t.close()
+                n += 1
+                if got[S.HIP_PIKE_FIRST][i] != first or got[S.HIP_PIKE_COUNT][i] != cnt or \
+                        (th != S.SRE_ERROR and got[S.HIP_THOMPSON][i][0] != th):
+                    bad.append((pats, d[:80], got[S.HIP_PIKE_FIRST][i][:4], first[:4], got[S.HIP_PIKE_COUNT][i][:4], cnt[:4],
+                                got[S.HIP_THOMPSON][i][0], th))
+            for b in bufs:
+                b.free()
+            if k < 60:
+                # chunks on the VM: the first one is short, so the stream starts (and stays) there
+                d = datas[1]
+                sizes = [rng.choice([60, 100, 200]), 700, 64, 1500, 1, 900]
+                want = _feed(ora.pike(prog, re.ncaps), d, sizes, nov)
+                gotf = _feed(eng.pike(prog, re.ncaps), d, sizes, nov)
+                fed += 1
+                if gotf != want:
+                    bad.append((pats, "pike chunks", sizes, gotf[-2:], want[-2:]))
+                to, tp = ora.thompson(prog), eng.thompson(prog)
+                off, rcs = 0, []
+                for sz in sizes + [len(d)]:
+                    chunk = d[off:off + sz]
+                    off += len(chunk)
+                    eof = off >= len(d)
+                    rcs.append((to.exec(chunk, eof), tp.exec(chunk, eof)))
+                    if rcs[-1][0] != S.SRE_AGAIN or eof:
+                        break
+                to.close()
+                if any(a != b for a, b in rcs if a != S.SRE_ERROR):
+                    bad.append((pats, "thompson chunks", sizes, rcs))
+                eng.recycle()
+    eng.pool.destroy()
+    assert not bad, (len(bad), bad[:3])
+    assert n > 400 and fed > 30, (n, fed)
+
+
 def test_recorded_fuzz_regressions(gpu):
     """Cases the randomised tests once failed on (tests/golden/fuzz_regressions.jsonl:
     engine, mode, segment size, patterns and subject in hex) stay fixed."""

@@ -39,6 +39,8 @@ def sim(lib):
     L.pwave_sim_ctx_exec.restype = _i64
     L.pwave_sim_ctx_exec.argtypes = [_vp, ctypes.c_char_p, _i64, ctypes.c_int, ctypes.POINTER(_i64), ctypes.c_uint32,
                                      ctypes.POINTER(ctypes.c_int), ctypes.POINTER(_i64)]
+    L.pwave_sim_set_ff.argtypes = [ctypes.c_int]
+    L.pwave_sim_ff_bytes.restype = _i64
     return L
 
 
@@ -250,3 +252,72 @@ def test_wave_step_chunked_feeding_vs_oracle(sim, blocks):
             sim.pwave_sim_free(h)
     assert not bad, (len(bad), bad[:3])
     assert n > 1500, n
+
+
+def _runs(rng, alphabet, total):
+    """a subject made of runs: the lists of most programs loop in place over them"""
+    out = bytearray()
+    while len(out) < total:
+        out += bytes([rng.choice(alphabet)]) * rng.choice([1, 1, 2, 3, 9, 30, 70, 150])
+    return bytes(out[:total])
+
+
+def test_wave_stable_runs_vs_oracle(sim):
+    """Stable runs (sre_hip_pwave.hip): a byte whose step left the list, every capture column and
+    seen_start_state as they were joins a per-list byte set, and the following bytes of that set are
+    skipped 64 at a time.  The model with and without the fast-forward, whole buffers, the find-all
+    iteration and chunked feeding, against the oracle over subjects made of runs; the headline
+    program over a gen-data stream must skip nearly everything."""
+    ora = harness.OracleEngine()
+    rng = random.Random(int(os.environ.get("SRE_FUZZ_SEED", "20261004")) + 24)
+    alphabet = b"abcx \n_."
+    zoo = [[rb"[a-z]+@[a-z]+\.[a-z]+"], [rb"([a-z]+)@([a-z]+)\.[a-z]+"], [rb"a+b"], [rb"(a+)(b+)?"], [rb"x(.*)y(.*)z"],
+           [rb"^a+c"], [rb"(?:a|b)*c"], [rb"a.*b"], [rb"(a*)*x"], [rb"\n+a"], [rb"[^x]+x", rb"a+_"], [rb"(?:aa)+b"],
+           [rb"(a|ab)(c|bcd)(d*)"], [rb"a{3,}b"], [rb"(?:.|\n)*x"], [rb"\s+\S"]]
+    cases = [(p, _runs(rng, alphabet, rng.choice([40, 300, 900]))) for p in zoo for _ in range(6)]
+    for _ in range(2500):
+        nre = 1 if rng.random() < 0.8 else 2
+        cases.append(([harness.random_regex(rng) for _ in range(nre)], _runs(rng, alphabet, rng.choice([40, 300, 900]))))
+    n, bad = 0, []
+    skipped0 = sim.pwave_sim_ff_bytes()
+    for pats, data in cases:
+        with S.Pool() as pool:
+            try:
+                re = S.parse(pool, pats)
+            except Exception:
+                continue
+            prog = S.compile(pool, re)
+            h = sim.pwave_sim_build(prog.h)
+            if not h:
+                continue
+            nov = 2 * (re.ncaps + 1)
+            want = _oracle(ora, prog, re.ncaps, data)
+            want_count = _count_want(ora, prog, re.ncaps, data)
+            sizes = [rng.choice([0, 1, 5, 64, 65, 200]) for _ in range(rng.randrange(1, 8))]
+            want_feed = _feed_oracle(ora.pike(prog, re.ncaps), data, sizes, nov)
+            for ff in (1, 0):
+                sim.pwave_sim_set_ff(ff)
+                got = _exec(sim, h, data, re.ncaps)
+                rec = (_i64 * (2 + nov))()
+                sim.pwave_sim_count(h, bytes(data), len(data), rec, nov)
+                got_feed = _feed_sim(sim, h, data, sizes, nov)
+                n += 1
+                if got != want or list(rec) != want_count or got_feed != want_feed:
+                    bad.append((pats, data[:60], ff, got, want, list(rec)[:4], want_count[:4], got_feed[-1:], want_feed[-1:]))
+            sim.pwave_sim_set_ff(1)
+            sim.pwave_sim_free(h)
+    assert not bad, (len(bad), bad[:3])
+    assert n > 2500, n
+    skipped = sim.pwave_sim_ff_bytes() - skipped0
+    assert skipped > 50000, skipped
+    # the headline program over gen-data: everything but a few learning steps is skipped
+    data = S.gen_data_host(1 << 16, b" x@abc.cc ")
+    with S.Pool() as pool:
+        re = S.parse(pool, [rb"[a-z]+@[a-z]+\.[a-z]+"])
+        prog = S.compile(pool, re)
+        h = sim.pwave_sim_build(prog.h)
+        before = sim.pwave_sim_ff_bytes()
+        got = _exec(sim, h, data, re.ncaps)
+        assert got == _oracle(ora, prog, re.ncaps, data), got
+        assert sim.pwave_sim_ff_bytes() - before > len(data) - 64, sim.pwave_sim_ff_bytes() - before
+        sim.pwave_sim_free(h)
