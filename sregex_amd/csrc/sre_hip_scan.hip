@@ -235,6 +235,7 @@ struct Walk {
     int64_t  ev_apos;                   /* anchor of that event: known state shortly before it */
     uint32_t ev_astate;
     int64_t  cur_sp;                    /* start of the search in flight, -1 unknown */
+    int64_t  warm_lo;                   /* first byte of the lane's warm-up (COUNT: restarts in front of it are not followed) */
     int64_t  anchor_pos;                /* start of the tile round being processed and the */
     uint32_t anchor_state;              /* state there (set by the kernel), -1 none */
     /* F_LM_VALID: FIRST: last event seen; COUNT: last completed match */
@@ -359,7 +360,34 @@ __device__ void slow_run(Walk &w, int64_t p, int64_t p_to, bool warm, uint32_t w
 
         /* the thread list died: this search is over */
         if (warm) {
-            w.st = warm_seed;
+            if (MODE == SRE_HIP_PIKE_COUNT) {
+                /* COUNT: the warm-up follows the caller's restarts like the exact path below (nothing is
+                 * counted): where the next search starts — at the match end, a byte further after an
+                 * empty match, possibly beyond this span (F_SKIP_NEXT: part of what the lane believes about
+                 * its entry) — and from which initial list (the byte in front) is what the lane must get
+                 * right.  With a fixed seed every restart of `\b` or `^x` resumed from the wrong list, the
+                 * chain check failed at nearly every segment and the fix-up rounds (one verified segment
+                 * each) were linear in the stream: 64 MiB of "ab cd " took 131 086 rounds = 151 s. */
+                if (w.f(F_HAS_EV)) {
+                    const bool    pop = (w.ev_kind == EV_POP || w.ev_kind == SRE_DEV_EV_POP_FULL);
+                    const bool    empty = w.ev_kind == EV_POP || w.ev_kind == SRE_DEV_EV_DONE_EMPTY;
+                    const int64_t e = pop ? w.ev_pos : w.ev_pos + 1;
+                    const int64_t sp = empty ? e + 1 : e;
+                    if (e >= w.warm_lo && sp >= 1 && !(empty && e >= w.n)) {
+                        w.fl &= ~F_HAS_EV;
+                        w.cur_sp = sp;
+                        w.st = T.init[restart_variant_of(T, byte_at(sp - 1))];
+                        p = sp;
+                        if (p > p_to && p_to <= w.n) w.fl |= F_SKIP_NEXT;
+                        continue;
+                    }
+                }
+                /* the lane's guess was off (a search only ends with a match or the input): the list a
+                 * search behind this byte would start from */
+                w.st = p < w.n ? T.init[restart_variant_of(T, byte_at(p))] : warm_seed;
+            } else {
+                w.st = warm_seed;
+            }
             w.fl &= ~F_HAS_EV;
             w.cur_sp = -1;
             p++;
@@ -433,12 +461,16 @@ resolve_fast_span(const sre_scan_tables_t *Tp, const uint16_t *tr2, const uint8_
         const uint32_t t2 = tr2[st * (T.ncls + 1) + sym];
         struct { uint32_t next; uint8_t kind; } tr = {t2 & 0xffu, (uint8_t) (t2 >> 8)};
         if (tr.kind && tr.next == 0) {
+            /* a folded match: behind this byte, or (a look-ahead assertion completed it) in front of it —
+             * then the next search reads the byte again, without an event (sre_scan_host.cpp) */
+            const bool pop = tr.kind == SRE_DEV_EV_POP_FULL && gpos + b > 0;
             r.last_pos = gpos + b;
             r.last_state = st;
             r.last_sym = sym;
             r.last_sp = r.sp;
-            r.sp = gpos + b + 1;
+            r.sp = pop ? gpos + b : gpos + b + 1;
             st = T.init[restart_variant(T, data, r.sp)];
+            if (pop) st = tr2[st * (T.ncls + 1) + sym] & 0xffu;
         } else {
             st = tr.next;
         }
@@ -621,6 +653,7 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
     w.ev_apos = -1;
     w.ev_astate = 0;
     w.cur_sp = -1;
+    w.warm_lo = 0;
     w.anchor_pos = -1;
     w.anchor_state = 0;
     w.lm_state = w.lm_sym = 0;
@@ -714,6 +747,7 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
             }
             w.st = seed;
         }
+        w.warm_lo = seg_a >= (int64_t) WARM ? seg_a - (int64_t) WARM : 0;
         s_in = w.st | (MODE == SRE_HIP_PIKE_COUNT && w.f(F_SKIP_NEXT) ? SRE_STATE_SKIP : 0u);   /* what the chain check compares */
         /* row = [seg_a - WARM, seg_b): the warm-up rounds, then the segment */
         mine.addr = (uint64_t) reinterpret_cast<uintptr_t>(w.data) + (uint64_t) (seg_a - WARM);
@@ -868,7 +902,7 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
                     if (su == SU_UNSET) su = (uint32_t) (base - seg_a);
                 }
                 if (r + 1 == WARM / TILE) {
-                    s_in = w.st;
+                    s_in = w.st | (MODE == SRE_HIP_PIKE_COUNT && w.f(F_SKIP_NEXT) ? SRE_STATE_SKIP : 0u);
                     w.cur_sp = -1;
                     if (w.st == 0) w.fl |= F_FINISHED;
                     if (MODE == SRE_HIP_PIKE_COUNT) {
@@ -921,7 +955,7 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
         }
         if (r + 1 == WARM / TILE) {
             /* end of the warm-up: what this lane assumes about its entry */
-            s_in = w.st;
+            s_in = w.st | (MODE == SRE_HIP_PIKE_COUNT && w.f(F_SKIP_NEXT) ? SRE_STATE_SKIP : 0u);
             w.cur_sp = -1;                  /* search starts seen in the warm-up are not verified */
             if (w.st == 0) w.fl |= F_FINISHED;
             if (MODE == SRE_HIP_PIKE_COUNT) {
@@ -1168,25 +1202,43 @@ sre_k_verify_a(sre_scan_geom_t G, const sre_seg_summary_t *__restrict__ sum, Ver
 {
     SRE_TAIL_PRIO();
     const uint64_t g = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= G.nsegs) return;
-    const uint32_t s = stream_of(G, g);
-    const uint64_t k = g - geom_first(G, s);
-    const uint32_t s_in = sum[g].s_in;
-    bool           bad = s_in == 0xffffffffu;
-    if (k > 0) {
-        const sre_seg_summary_t &p = sum[g - 1], &c = sum[g];
-        if (s_in != p.s_out) bad = true;
-        if (mode == SRE_HIP_PIKE_COUNT) {
-            /* the same entry state can hold different pending matches */
-            const bool pp = (p.flags & SRE_SUM_PENDING) != 0, cp = (c.flags & SRE_SUM_IN_PENDING) != 0;
-            if (pp != cp) bad = true;
-            if (pp && cp && (p.pe_pos != c.in_pe_pos || p.pe_state != c.in_pe_state || p.pe_sym != c.in_pe_sym)) {
-                bad = true;
+    const bool     valid = g < G.nsegs;
+    const uint32_t s = stream_of(G, valid ? g : G.nsegs - 1);
+    unsigned long long kb = ~0ull, ke = ~0ull;      /* this lane's candidates for acc[s].bad / .end */
+    if (valid) {
+        const uint64_t k = g - geom_first(G, s);
+        const uint32_t s_in = sum[g].s_in;
+        bool           bad = s_in == 0xffffffffu;
+        if (k > 0) {
+            const sre_seg_summary_t &p = sum[g - 1], &c = sum[g];
+            if (s_in != p.s_out) bad = true;
+            if (mode == SRE_HIP_PIKE_COUNT) {
+                /* the same entry state can hold different pending matches */
+                const bool pp = (p.flags & SRE_SUM_PENDING) != 0, cp = (c.flags & SRE_SUM_IN_PENDING) != 0;
+                if (pp != cp) bad = true;
+                if (pp && cp && (p.pe_pos != c.in_pe_pos || p.pe_state != c.in_pe_state || p.pe_sym != c.in_pe_sym)) {
+                    bad = true;
+                }
             }
         }
+        if (bad) kb = k;
+        if (sum[g].flags & SRE_SUM_TERM) ke = k;
     }
-    if (bad) atomicMin(&acc[s].bad, (unsigned long long) k);
-    if (sum[g].flags & SRE_SUM_TERM) atomicMin(&acc[s].end, (unsigned long long) k);
+    /* One atomic per wave at most, and none when the word already holds less: with a match in reach of
+     * every segment (`foo` over "foo foo ..", first match) each of the 262 144 lanes of a 64 MiB stream
+     * reported TERM with an atomicMin on ONE address — 3 ms for a scan of 0.13 (profiles/r03_floor_probe.json).
+     * (A stale read is only ever larger than the word: the test errs towards the atomic.) */
+    const uint32_t s0 = (uint32_t) __builtin_amdgcn_readfirstlane((int) s);
+    if (__builtin_amdgcn_ballot_w64(s != s0) == 0) {
+        for (int d = 32; d >= 1; d >>= 1) {
+            const unsigned long long ob = __shfl_xor(kb, d, 64), oe = __shfl_xor(ke, d, 64);
+            kb = ob < kb ? ob : kb;
+            ke = oe < ke ? oe : ke;
+        }
+        if ((threadIdx.x & 63u) != 0) kb = ke = ~0ull;
+    }
+    if (kb != ~0ull && kb < __hip_atomic_load(&acc[s].bad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&acc[s].bad, kb);
+    if (ke != ~0ull && ke < __hip_atomic_load(&acc[s].end, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&acc[s].end, ke);
 }
 
 /* (256 threads cover SRE_VERIFY_SPAN = 1024 segments: one global atomic per 1024 segments
@@ -1314,8 +1366,10 @@ sre_k_verify_b2(sre_scan_geom_t G, const sre_seg_summary_t *__restrict__ sum, Ve
 
 /* the status word of one stream from its accumulated chain-check results; `sum` = the
  * stream's first summary */
+#define SRE_EV_SP_SEARCH ((int64_t) -2)
 __device__ inline sre_stream_status_t
-assemble_status(const sre_scan_tables_t &T, const sre_seg_summary_t *__restrict__ sum, uint64_t nseg, const VerifyAcc &acc)
+assemble_status(const sre_scan_tables_t &T, const sre_seg_summary_t *__restrict__ sum, uint64_t nseg, const VerifyAcc &acc,
+                bool defer_search = false)
 {
     uint64_t       bad = acc.bad, end = acc.end;
     if (bad > nseg) bad = nseg;
@@ -1362,6 +1416,8 @@ assemble_status(const sre_scan_tables_t &T, const sre_seg_summary_t *__restrict_
                 sp = 0;                     /* one search per stream, from its start */
             } else if (spseg < evseg) {
                 sp = sum[spseg - 1].cur_sp;
+            } else if (defer_search) {
+                sp = SRE_EV_SP_SEARCH;      /* the caller looks for it with the whole wave (sre_k_verify_c) */
             } else {
                 for (int64_t q = (int64_t) evseg - 2; q >= 0; q--) {
                     if (sum[q].cur_sp >= 0) {
@@ -1377,19 +1433,58 @@ assemble_status(const sre_scan_tables_t &T, const sre_seg_summary_t *__restrict_
     return st;
 }
 
-__global__ void
+__global__ __launch_bounds__(64) void
 sre_k_verify_c(sre_scan_tables_t T, sre_scan_geom_t G, const sre_seg_summary_t *__restrict__ sum,
                VerifyAcc *__restrict__ accs, sre_stream_status_t *__restrict__ status)
 {
     SRE_TAIL_PRIO();
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= G.nstreams) return;
-    /* take this stream's accumulator and leave it reset for the next pass */
-    const VerifyAcc acc = accs[s];
-    accs[s].bad = accs[s].end = ~0ull;
-    accs[s].count = accs[s].evseg = accs[s].spseg = accs[s].unst = accs[s].unst_end = 0;
-    const uint64_t first = geom_first(G, s), nseg = geom_first(G, s + 1) - first;
-    status[s] = assemble_status(T, sum + first, nseg, acc);
+    const bool     valid = s < G.nstreams;
+    const uint32_t lane = threadIdx.x & 63u;
+    sre_stream_status_t st;
+    uint64_t            first = 0;
+    st.ev_sp = -1;
+    st.ev_seg = -1;
+    if (valid) {
+        /* take this stream's accumulator and leave it reset for the next pass */
+        const VerifyAcc acc = accs[s];
+        accs[s].bad = accs[s].end = ~0ull;
+        accs[s].count = accs[s].evseg = accs[s].spseg = accs[s].unst = accs[s].unst_end = 0;
+        first = geom_first(G, s);
+        const uint64_t nseg = geom_first(G, s + 1) - first;
+        st = assemble_status(T, sum + first, nseg, acc, true);
+    }
+    /* COUNT: the search of the last match began in an earlier segment and a later one knows a start too
+     * (`a+` over a stream of a: the match spans it, the search behind it starts at its end): the latest
+     * start known in front of the match's segment, looked for by the whole wave, 256 segments per trip —
+     * one lane walking the summaries backwards took 36 ms over the 131 072 segments of 64 MiB. */
+    uint64_t need = __builtin_amdgcn_ballot_w64(valid && st.ev_sp == SRE_EV_SP_SEARCH);
+    while (need) {
+        const int      l = __builtin_ctzll(need);
+        need &= need - 1;
+        const uint64_t f = __shfl(first, l, 64);
+        const int64_t  top = __shfl(st.ev_seg, l, 64) - 1;     /* segments [0, top] are in front of the match's */
+        int64_t        sp = 0;
+        bool           found = false;
+        for (int64_t hi = top; hi >= 0 && !found; hi -= 256) {
+            int64_t v[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int64_t q = hi - (int64_t) lane - 64 * j;
+                v[j] = q >= 0 ? sum[f + (uint64_t) q].cur_sp : (int64_t) -1;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint64_t b = __builtin_amdgcn_ballot_w64(v[j] >= 0);
+                if (!found && b) {
+                    sp = __shfl(v[j], __builtin_ctzll(b), 64);      /* the lowest lane holds the highest segment */
+                    found = true;
+                }
+            }
+        }
+        if ((int) lane == l) st.ev_sp = sp;
+    }
+    if (valid) status[s] = st;
 }
 
 /*

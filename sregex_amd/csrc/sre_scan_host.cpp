@@ -100,6 +100,29 @@ sre_scan_tables_build(const sre_program_t *prog, const sre_dfa_t *d, int mode, c
             if (sre_isword(c)) rep_is_word[d->cls_map[c]] = 1;
         }
     }
+    /* COUNT: a match that a look-ahead assertion completes (`foo$`, `\bfoo\b`) ends IN FRONT of the byte that
+     * decided it; when nothing outlives it the next search starts AT that byte, from the initial list the byte
+     * in front of it selects (sre_vm_pike.c:586-601, :624-628).  Inside an index that byte is the previous
+     * sub-step's; at its first sub-step it is whatever byte led into the row's state — known when every way
+     * into the state (transitions, its role as an initial list) agrees on the initial list it selects. */
+    auto restart_of = [&](uint32_t k) {
+        return d->init[rep_is_nl[k] ? SRE_DFA_INIT_RESTART_NL : rep_is_word[k] ? SRE_DFA_INIT_RESTART_WORD : SRE_DFA_INIT_RESTART];
+    };
+    const uint32_t RESTART_NONE = 0xfffffffeu, RESTART_MIXED = 0xffffffffu;
+    std::vector<uint32_t> restart_in(d->nstates, RESTART_NONE);
+    {
+        auto merge = [&](uint32_t s, uint32_t r) {
+            if (s == SRE_DFA_DEAD || s >= d->nstates) return;
+            restart_in[s] = restart_in[s] == RESTART_NONE || restart_in[s] == r ? r : RESTART_MIXED;
+        };
+        for (uint32_t s = 1; s < d->nstates; s++) {
+            for (uint32_t k = 0; k < d->ncls; k++) merge(d->t(s, k).next, restart_of(k));
+        }
+        merge(d->init[SRE_DFA_INIT_RESTART], d->init[SRE_DFA_INIT_RESTART]);
+        merge(d->init[SRE_DFA_INIT_RESTART_NL], d->init[SRE_DFA_INIT_RESTART_NL]);
+        merge(d->init[SRE_DFA_INIT_RESTART_WORD], d->init[SRE_DFA_INIT_RESTART_WORD]);
+    }
+    const bool fold_pop = getenv("SRE_HIP_NO_POP_FOLD") == NULL;     /* (experiment knob) */
     auto build_fast = [&](int fmode) {
     std::vector<uint32_t> fast((size_t) d->nstates * 256);
     for (uint32_t s = 0; s < d->nstates; s++) {
@@ -119,9 +142,28 @@ sre_scan_tables_build(const sre_program_t *prog, const sre_dfa_t *d, int mode, c
                     /* a non-empty match completes and nothing outlives it: the
                      * next search starts at the next byte (sre_vm_pike.c:624-628) */
                     /* the byte in front of that search is the one just consumed */
-                    st = d->init[rep_is_nl[k] ? SRE_DFA_INIT_RESTART_NL : rep_is_word[k] ? SRE_DFA_INIT_RESTART_WORD
-                                              : SRE_DFA_INIT_RESTART];
+                    st = restart_of(k);
                     cnt++;
+                } else if (fold_pop && fmode == SRE_HIP_PIKE_COUNT && tr.ev_kind == SRE_DFA_EV_POP
+                           && tr.next == SRE_DFA_DEAD && !tr.ev_empty)
+                {
+                    /* ... or in front of this byte, which the next search reads again */
+                    uint32_t r = RESTART_MIXED;
+                    if (sub > 0) {
+                        r = restart_of((idx >> ((sub - 1) * bits)) & ((1u << bits) - 1));
+                    } else if (restart_in[s] != RESTART_NONE) {
+                        r = restart_in[s];
+                    }
+                    bool ok = r != RESTART_MIXED && r != SRE_DFA_DEAD;
+                    if (ok) {
+                        const sre_dfa_trans_t &tr2 = d->t(r, k);
+                        ok = tr2.ev_kind == SRE_DFA_EV_NONE && tr2.next != SRE_DFA_DEAD;
+                        if (ok) {
+                            st = tr2.next;
+                            cnt++;
+                        }
+                    }
+                    if (!ok) flags |= SRE_FAST_SLOW;
                 } else if (tr.ev_kind != SRE_DFA_EV_NONE || tr.next == SRE_DFA_DEAD) {
                     flags |= SRE_FAST_SLOW;
                 } else {

@@ -1142,23 +1142,62 @@ def test_nfa_tier_large_stream_closed_form(gpu):
 
 
 def test_bench_floor_variant_closed_form_vs_oracle(gpu):
-    """bench.py's `floor` variant (a look-ahead match every 4 bytes: every round of every lane leaves the
-    scan kernel's fast path): the closed form it asserts at 4 GiB, against the oracle at small sizes."""
+    """bench.py's `floor` (every byte of a run extends a pending match: every round of every lane runs the
+    scan kernel's exact path) and `floorla` (a look-ahead match every 4 bytes, folded into the COUNT table
+    since round 3) variants: the closed forms they assert at 4 GiB, against the oracle at small sizes."""
     ora = harness.OracleEngine()
-    with S.Pool() as pool:
-        re = S.parse(pool, [rb"\bfoo\b"])
-        prog = S.compile(pool, re)
-        sc = S.Scanner(pool, prog, S.HIP_PIKE_COUNT, S.ENGINE_AUTO)
-        assert sc.engine == S.ENGINE_SCAN
-        for k in (1, 17, 5000):
-            data = b"foo " * k
-            _, cnt = _expect(ora, prog, re.ncaps, data)
-            n = len(data)
-            assert cnt == [0, n // 4, n - 4, n - 1], (k, cnt)
-            buf = S.DeviceBuffer.from_bytes(data)
-            rec = sc.scan([buf.ptr], [n])[0]
+    for pat, body in ((rb"\bfoo\b", b"foo "), (rb"a+", b"aaab")):
+        with S.Pool() as pool:
+            re = S.parse(pool, [pat])
+            prog = S.compile(pool, re)
+            sc = S.Scanner(pool, prog, S.HIP_PIKE_COUNT, S.ENGINE_AUTO)
+            assert sc.engine == S.ENGINE_SCAN
+            for k in (1, 17, 5000):
+                data = body * k
+                _, cnt = _expect(ora, prog, re.ncaps, data)
+                n = len(data)
+                assert cnt == [0, n // 4, n - 4, n - 1], (k, cnt)
+                buf = S.DeviceBuffer.from_bytes(data)
+                rec = sc.scan([buf.ptr], [n])[0]
+                buf.free()
+                assert rec == cnt, (pat, k, rec, cnt)
+
+
+def test_count_restarts_that_depend_on_the_byte_in_front_settle_at_once(gpu):
+    """Find-all counts whose every search ends at once and restarts from the list the byte in front selects
+    (`\\b` over words, `$` over lines, empty matches at every byte): the lanes' warm-up follows the caller's
+    restarts, so the chain check holds on the first pass — with a fixed warm-up seed 64 MiB of "ab cd " took
+    131 086 fix-up rounds (151 s; tools/floor_probe.py).  Counts against the oracle at small sizes, closed
+    forms and the number of rounds at 16 MiB."""
+    ora = harness.OracleEngine()
+    cases = [(rb"\b", b"ab cd "), (rb"$", b"ab\n"), (rb"x*", b"abc"), (rb"a*", b"ab"), (rb"^a", b"ab\nab\n"),
+             (rb"\bfoo\b", b"foo "), (rb"a+", b"aaab")]
+    for pat, body in cases:
+        with S.Pool() as pool:
+            re = S.parse(pool, [pat])
+            prog = S.compile(pool, re)
+            sc = S.Scanner(pool, prog, S.HIP_PIKE_COUNT, S.ENGINE_AUTO)
+            assert sc.engine == S.ENGINE_SCAN
+            for seg in (0, 256):
+                if seg:
+                    sc.set_segment_bytes(seg)
+                for k in (1, 50, 3000):
+                    data = body * k
+                    _, cnt = _expect(ora, prog, re.ncaps, data)
+                    buf = S.DeviceBuffer.from_bytes(data)
+                    rec = sc.scan([buf.ptr], [len(data)])[0]
+                    buf.free()
+                    assert rec == cnt, (pat, seg, k, rec, cnt)
+            # 16 MiB: the count scales linearly from the 3000-period sample, and the rounds stay few
+            small = body * 3000
+            _, c_small = _expect(ora, prog, re.ncaps, small)
+            big_k = (16 << 20) // len(body)
+            buf = S.DeviceBuffer.from_bytes(body * big_k)
+            rec = sc.scan([buf.ptr], [big_k * len(body)])[0]
             buf.free()
-            assert rec == cnt, (k, rec, cnt)
+            per = (c_small[1] - _expect(ora, prog, re.ncaps, body * 2999)[1][1])
+            assert rec[1] == c_small[1] + per * (big_k - 3000), (pat, rec[:4], c_small[:4], per)
+            assert sc.last_fixups <= 4, (pat, sc.last_fixups)
 
 
 def test_newline_flag_exec_vs_reference_goldens(gpu):
