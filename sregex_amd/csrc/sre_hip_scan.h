@@ -31,6 +31,11 @@
  *                capture slot — a thread list "looping in place" (x+ over a run of x).
  *                The capture walker jumps over stretches made of such steps only. */
 #define SRE_FAST_STABLE     32u
+/*   bit  5       EVT (COUNT tables, which have no STABLE entries): a sub-step recorded a match that is still
+ *                pending at its end — the list lives on in a FRESH state (sre_scan_host.cpp) */
+#define SRE_FAST_EVT        32u
+#define SRE_STATE_FRESH     8u      /* sre_scan_tables_t.state_flags: every way into the state records a match that ends
+                                       with the byte just consumed */
 #define SRE_FAST_ROW_BYTES  1024u
 
 /* In LDS the fast table has extra rows behind the automaton's own: one TRAP row (every
@@ -100,6 +105,7 @@ typedef struct {
     const uint32_t        *list_pcs;
     const uint32_t        *multi_ncaps; /* [nregexes] */
     uint32_t nregexes;
+    uint32_t any_fresh;                 /* COUNT tables: some state is SRE_STATE_FRESH (entries may carry SRE_FAST_EVT) */
     uint32_t nshadow;                   /* shadow rows in the LDS fast table (FIRST / Thompson tables) */
     uint32_t fast_rows;                 /* rows of the scan kernel's LDS copy: nstates + 1 (trap) + nshadow */
     uint32_t wide;                      /* the staging tile holds 16-bit pre-scaled indices (sre_hip_tile.h): always with

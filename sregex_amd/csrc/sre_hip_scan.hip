@@ -213,7 +213,10 @@ restart_variant(const sre_scan_tables_t &T, const uint8_t *data, int64_t sp)
 enum : uint32_t {
     F_HAS_EV = 1u, F_LM_VALID = 2u, F_FINISHED = 4u, F_ERROR = 8u, F_UNRESOLVED = 16u, F_SKIP_NEXT = 32u,
     F_IN_PENDING = 64u, F_SP_DIRTY = 128u,
-    F_SHADOW = 256u     /* FIRST: the lane is inside a stable stretch (in a shadow row of the fast table) */
+    F_SHADOW = 256u,    /* FIRST: the lane is inside a stable stretch (in a shadow row of the fast table) */
+    F_PEND_LAZY = 512u, /* COUNT: the last fast span ended in a FRESH state: a match is pending whose event was not
+                           recorded — it ends with that span's last byte (settle() replays the span) */
+    F_LZ_GROUP = 1024u  /* ... and that span was a 16-byte group, not a 64-byte round */
 };
 
 /* the search a lane is currently following */
@@ -331,8 +334,11 @@ __device__ void slow_run(Walk &w, int64_t p, int64_t p_to, bool warm, uint32_t w
             w.ev_sp = w.cur_sp;
             /* the round's entry state is a usable anchor if it belongs to this
              * same search and lies at most one round in front of the event */
+            /* (strictly behind the search start: a search that a folded match started AT the round's first byte
+             * — the byte is read again, sre_scan_host.cpp — does not begin in the round's entry state; found by
+             * the random campaign, `\ba+` seed 403) */
             if (w.anchor_pos >= 0 && w.anchor_pos <= p && p - w.anchor_pos <= 256
-                && (w.cur_sp < 0 || w.anchor_pos >= w.cur_sp))
+                && (w.cur_sp < 0 || w.anchor_pos > w.cur_sp))
             {
                 w.ev_apos = w.anchor_pos;
                 w.ev_astate = w.anchor_state;
@@ -442,13 +448,16 @@ __device__ void slow_run(Walk &w, int64_t p, int64_t p_to, bool warm, uint32_t w
  * segment and must not add to the scan loop's register pressure. */
 struct SpanResult {
     int64_t  sp;                /* start of the search in flight after the span */
-    int64_t  last_pos, last_sp; /* last completed match: its final byte (-1 none), its search start */
+    int64_t  last_pos, last_sp; /* last completed match: its event's byte (-1 none), its search start */
     uint32_t last_state, last_sym;
+    int64_t  pend_pos;          /* the match pending at the end of the span, recorded inside it (-1 none) */
+    uint32_t pend_state, pend_sym;
 };
 
+/* pend0_*: the match pending in front of the span (its event; pend0_pos < 0: none, or unknown and superseded) */
 __device__ __attribute__((noinline)) SpanResult
 resolve_fast_span(const sre_scan_tables_t *Tp, const uint16_t *tr2, const uint8_t *data, int64_t gpos,
-                  uint32_t len, uint32_t s0, int64_t sp0)
+                  uint32_t len, uint32_t s0, int64_t sp0, int64_t pend0_pos, uint32_t pend0_state, uint32_t pend0_sym)
 {
     const sre_scan_tables_t &T = *Tp;
     SpanResult r;
@@ -456,6 +465,9 @@ resolve_fast_span(const sre_scan_tables_t *Tp, const uint16_t *tr2, const uint8_
     r.sp = sp0;
     r.last_pos = r.last_sp = -1;
     r.last_state = r.last_sym = 0;
+    r.pend_pos = pend0_pos;
+    r.pend_state = pend0_state;
+    r.pend_sym = pend0_sym;
     for (uint32_t b = 0; b < len; b++) {
         const uint32_t         sym = T.cls[data[gpos + b]];
         const uint32_t t2 = tr2[st * (T.ncls + 1) + sym];
@@ -469,8 +481,32 @@ resolve_fast_span(const sre_scan_tables_t *Tp, const uint16_t *tr2, const uint8_
             r.last_sym = sym;
             r.last_sp = r.sp;
             r.sp = pop ? gpos + b : gpos + b + 1;
+            r.pend_pos = -1;
             st = T.init[restart_variant(T, data, r.sp)];
             if (pop) st = tr2[st * (T.ncls + 1) + sym] & 0xffu;
+        } else if (tr.kind) {
+            /* the pending match grows (a FRESH state follows) */
+            r.pend_pos = gpos + b;
+            r.pend_state = st;
+            r.pend_sym = sym;
+            st = tr.next;
+        } else if (tr.next == 0 && gpos + b > 0) {
+            /* the list dies in a FRESH state: the pending match, which ends in front of this byte, completes;
+             * the next search reads the byte again — and may record a match with it */
+            r.last_pos = r.pend_pos;            /* (unknown only for a completion that a later one supersedes) */
+            r.last_state = r.pend_state;
+            r.last_sym = r.pend_sym;
+            r.last_sp = r.sp;
+            r.sp = gpos + b;
+            st = T.init[restart_variant(T, data, r.sp)];
+            const uint32_t t3 = tr2[st * (T.ncls + 1) + sym];
+            r.pend_pos = -1;
+            if (t3 >> 8) {
+                r.pend_pos = gpos + b;
+                r.pend_state = st;
+                r.pend_sym = sym;
+            }
+            st = t3 & 0xffu;
         } else {
             st = tr.next;
         }
@@ -589,8 +625,11 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
     const uint32_t shadow_lds = trap_lds + SRE_FAST_ROW_BYTES;      /* first shadow row */
     auto to_lds = [fast_lds, trap_lds](uint32_t g) -> uint32_t {
         if (g & SRE_FAST_SLOW) return trap_lds | LDS_SLOW;
+        /* COUNT: the count byte also carries the entry's EVT flag (bit 7): one SDWA add per lookup sums
+         * both — completions in the low seven bits (<= 64 a round), entries with a growing match above */
         return (fast_lds + (g & ~(SRE_FAST_ROW_BYTES - 1)))
-               | (((g >> SRE_FAST_CNT_SHIFT) & SRE_FAST_CNT_MASK) << LDS_CNT_SHIFT);
+               | (((g >> SRE_FAST_CNT_SHIFT) & SRE_FAST_CNT_MASK) << LDS_CNT_SHIFT)
+               | ((MODE == SRE_HIP_PIKE_COUNT && (g & SRE_FAST_EVT)) ? (128u << LDS_CNT_SHIFT) : 0u);
     };
     for (uint32_t i = tid; i < nst * 64; i += SRE_SCAN_BLOCK) {
         uint4 e = reinterpret_cast<const uint4 *>(tabp->fast)[i];
@@ -762,6 +801,9 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
      * completed match */
     int64_t  fcA_pos = -1, fcB_pos = -1, fc_sp0 = -1;
     uint32_t fcA_len = 0, fcA_s0 = 0, fcB_len = 0, fcB_s0 = 0;
+    /* ... and the last fast span that ended in a FRESH state (F_PEND_LAZY): where it began and in which state */
+    int64_t  lz_pos = -1;
+    uint32_t lz_s0 = 0;
     /* a pure-fast span [pos, pos + len), entered in state s0, completed cnt matches */
     auto note_span = [&](int64_t pos, uint32_t len, uint32_t s0, uint32_t cnt, bool warm_round) {
         w.fl &= ~F_HAS_EV;                       /* superseded */
@@ -777,26 +819,79 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
         fcB_pos = pos;
         fcB_len = len;
         fcB_s0 = s0;
+        if (w.f(F_PEND_LAZY)) {
+            /* the span in front ended with an unrecorded pending match, which this one may complete with its
+             * first byte: the replay starts there */
+            fcB_pos = lz_pos;
+            fcB_len = len + (w.f(F_LZ_GROUP) ? 16u : (uint32_t) TILE);
+            fcB_s0 = lz_s0;
+        }
         w.fl |= F_SP_DIRTY;
         w.count += cnt;
     };
-    /* make w.cur_sp exact again and record the last completed match (lm_*) */
-    auto settle = [&]() {
-        if (MODE != SRE_HIP_PIKE_COUNT || !w.f(F_SP_DIRTY)) return;
-        int64_t sp0 = fc_sp0;
-        if (fcA_pos >= 0) sp0 = resolve_fast_span(&T, w.tr2, w.data, fcA_pos, fcA_len, fcA_s0, -1).sp;
-        const SpanResult r = resolve_fast_span(&T, w.tr2, w.data, fcB_pos, fcB_len, fcB_s0, sp0);
-        if (r.last_pos >= 0) {
-            w.fl |= F_LM_VALID;
-            w.lm_pos = r.last_pos;
-            w.lm_state = r.last_state;
-            w.lm_sym = r.last_sym;
-            w.lm_sp = r.last_sp;
-            w.lm_apos = -1;
-            w.lm_astate = 0;
+    const bool any_fresh = __builtin_amdgcn_readfirstlane((int) tabp->any_fresh) != 0;
+    /* after a fast span of a COUNT scan: sum = what the lookups' count bytes added up to (completions in the
+     * low seven bits, entries with a growing match above), st1 = the state it ended in */
+    auto fast_span_done = [&](int64_t pos, uint32_t len, uint32_t s0, uint32_t sum, uint32_t st1, bool warm_round) {
+        if (!any_fresh) {
+            if (sum) note_span(pos, len, s0, sum, warm_round);      /* (a table without growing matches: completions only) */
+            return;
         }
-        w.cur_sp = r.sp;
-        w.fl &= ~F_SP_DIRTY;
+        if (sum == 0) {
+            w.fl &= ~F_PEND_LAZY;               /* (a FRESH state is entered by a recorded match only) */
+            return;
+        }
+        if (sum & 127u) note_span(pos, len, s0, sum & 127u, warm_round);
+        else if (sum) w.fl &= ~F_HAS_EV;        /* a later match of the same search supersedes the recorded one */
+        if (sfl[st1] & SRE_STATE_FRESH) {
+            w.fl |= F_PEND_LAZY;
+            w.set(F_LZ_GROUP, len == 16u);
+            lz_pos = pos;
+            lz_s0 = s0;
+        } else {
+            w.fl &= ~F_PEND_LAZY;
+        }
+    };
+    /* make w.cur_sp exact again, record the last completed match (lm_*) and the pending one (ev_*) */
+    auto settle = [&]() {
+        if (MODE != SRE_HIP_PIKE_COUNT || !(w.fl & (F_SP_DIRTY | F_PEND_LAZY))) return;
+        if (w.f(F_SP_DIRTY)) {
+            int64_t sp0 = fc_sp0;
+            if (fcA_pos >= 0) sp0 = resolve_fast_span(&T, w.tr2, w.data, fcA_pos, fcA_len, fcA_s0, -1, -1, 0, 0).sp;
+            /* (a span that begins in a FRESH state and was not extended begins right behind the exact path: the
+             * pending match is the one that path recorded) */
+            const SpanResult r = resolve_fast_span(&T, w.tr2, w.data, fcB_pos, fcB_len, fcB_s0, sp0, w.ev_pos, w.ev_state, w.ev_sym);
+            if (r.last_pos >= 0) {
+                w.fl |= F_LM_VALID;
+                w.lm_pos = r.last_pos;
+                w.lm_state = r.last_state;
+                w.lm_sym = r.last_sym;
+                w.lm_sp = r.last_sp;
+                /* the span's entry state is the capture walker's anchor when the match's search was under way
+                 * there (strictly: see slow_run) — without one it replays the segment up to the event */
+                const bool anchored = r.last_sp < fcB_pos && r.last_pos - fcB_pos <= 256 && fcB_pos >= seg_a;    /* (never in the warm-up) */
+                w.lm_apos = anchored ? fcB_pos : (int64_t) -1;
+                w.lm_astate = anchored ? fcB_s0 : 0u;
+            }
+            w.cur_sp = r.sp;
+            w.fl &= ~F_SP_DIRTY;
+        }
+        if (w.f(F_PEND_LAZY)) {
+            const SpanResult r = resolve_fast_span(&T, w.tr2, w.data, lz_pos, w.f(F_LZ_GROUP) ? 16u : (uint32_t) TILE, lz_s0,
+                                                   -1, -1, 0, 0);
+            w.fl &= ~F_PEND_LAZY;
+            if (r.pend_pos >= 0) {
+                w.fl |= F_HAS_EV;
+                w.ev_pos = r.pend_pos;
+                w.ev_state = r.pend_state;
+                w.ev_sym = r.pend_sym;
+                w.ev_kind = (uint8_t) (w.tr2[r.pend_state * (T.ncls + 1) + r.pend_sym] >> 8);
+                w.ev_sp = w.cur_sp;
+                const bool anchored = w.cur_sp < lz_pos && lz_pos >= seg_a;
+                w.ev_apos = anchored ? lz_pos : (int64_t) -1;
+                w.ev_astate = anchored ? lz_s0 : 0u;
+            }
+        }
     };
 
     /* FIRST: stable stretches (sre_seg_summary_t.stable_until / stable_from), as offsets
@@ -893,8 +988,8 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
             if (!(t & LDS_SLOW)) {
                 /* matches completed in the round, each followed by a restart at
                  * the next byte, are only counted here (see note_span) */
-                if (MODE == SRE_HIP_PIKE_COUNT && cnt) note_span(base, TILE, w.st, cnt, warm_round);
                 const uint32_t ridx = ((t & 0xffffu) - fast_lds) / SRE_FAST_ROW_BYTES;
+                if (MODE == SRE_HIP_PIKE_COUNT) fast_span_done(base, TILE, w.st, cnt, ridx, warm_round);
                 w.st = MODE == SRE_HIP_PIKE_COUNT ? ridx : ridx <= nst ? ridx : ridx == nst + 1 ? sh_st0 : sh_st1;
                 if (MODE != SRE_HIP_PIKE_COUNT && w.f(F_SHADOW) && ridx <= nst) {
                     /* left the shadow rows: the stable stretch ended in this round */
@@ -903,7 +998,9 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
                 }
                 if (r + 1 == WARM / TILE) {
                     s_in = w.st | (MODE == SRE_HIP_PIKE_COUNT && w.f(F_SKIP_NEXT) ? SRE_STATE_SKIP : 0u);
+                    settle();
                     w.cur_sp = -1;
+                    if (w.f(F_HAS_EV)) w.ev_sp = -1;
                     if (w.st == 0) w.fl |= F_FINISHED;
                     if (MODE == SRE_HIP_PIKE_COUNT) {
                         w.set(F_IN_PENDING, w.f(F_HAS_EV));
@@ -949,14 +1046,17 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
                 settle();
                 slow_run<MODE>(w, gp, g_end, warm_round, seed);
             } else {
-                if (MODE == SRE_HIP_PIKE_COUNT && cnt) note_span(gp, 16, w.st, cnt, warm_round);
-                w.st = ((t & 0xffffu) - fast_lds) / SRE_FAST_ROW_BYTES;     /* ordinary rows only on this path */
+                const uint32_t st1 = ((t & 0xffffu) - fast_lds) / SRE_FAST_ROW_BYTES;    /* ordinary rows only on this path */
+                if (MODE == SRE_HIP_PIKE_COUNT) fast_span_done(gp, 16, w.st, cnt, st1, warm_round);
+                w.st = st1;
             }
         }
         if (r + 1 == WARM / TILE) {
             /* end of the warm-up: what this lane assumes about its entry */
             s_in = w.st | (MODE == SRE_HIP_PIKE_COUNT && w.f(F_SKIP_NEXT) ? SRE_STATE_SKIP : 0u);
+            settle();
             w.cur_sp = -1;                  /* search starts seen in the warm-up are not verified */
+            if (w.f(F_HAS_EV)) w.ev_sp = -1;
             if (w.st == 0) w.fl |= F_FINISHED;
             if (MODE == SRE_HIP_PIKE_COUNT) {
                 w.set(F_IN_PENDING, w.f(F_HAS_EV));      /* ... nor is the pending match: the chain check compares it */

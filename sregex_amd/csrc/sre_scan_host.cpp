@@ -123,6 +123,34 @@ sre_scan_tables_build(const sre_program_t *prog, const sre_dfa_t *d, int mode, c
         merge(d->init[SRE_DFA_INIT_RESTART_WORD], d->init[SRE_DFA_INIT_RESTART_WORD]);
     }
     const bool fold_pop = getenv("SRE_HIP_NO_POP_FOLD") == NULL;     /* (experiment knob) */
+    /* COUNT: a pending match that GROWS (`[a-z]+` inside a word: every byte completes a longer match, the
+     * list lives on) used to send every such byte through the kernel's exact path — find-all of any pattern
+     * with a greedy tail ran at 0.014 of peak (tools/floor_probe.py).  A state is FRESH when every way into
+     * it is a transition that records a non-empty match ending with the byte just consumed: the pending
+     * match of a lane in a fresh state is then known without having been recorded (its end is the previous
+     * byte; state and symbol of its event come from replaying the last round, sre_hip_scan.hip settle()).
+     * Such transitions stay in the fast table (SRE_FAST_EVT), and so does the list dying in a fresh state
+     * without a new event: the pending match completes, it ends right here, and the next search reads the
+     * byte again (as above).  A step out of a fresh state that neither records a match nor kills the list
+     * would leave the pending match behind unrecorded: those take the exact path. */
+    const bool fold_grow = getenv("SRE_HIP_NO_GROW_FOLD") == NULL;   /* (experiment knob) */
+    std::vector<uint8_t> fresh(d->nstates, 0);
+    if (mode == SRE_HIP_PIKE_COUNT && fold_grow) {
+        std::vector<uint8_t> any_in(d->nstates, 0), bad_in(d->nstates, 0);
+        for (uint32_t s = 1; s < d->nstates; s++) {
+            for (uint32_t k = 0; k <= d->ncls; k++) {
+                const sre_dfa_trans_t &tr = d->t(s, k);
+                if (tr.next == SRE_DFA_DEAD || tr.next >= d->nstates) continue;
+                any_in[tr.next] = 1;
+                if (k == d->ncls || tr.ev_kind != SRE_DFA_EV_DONE || tr.ev_empty || tr.skipped) bad_in[tr.next] = 1;
+            }
+        }
+        for (int v = 0; v < SRE_DFA_NINIT; v++) bad_in[d->init[v]] = 1;
+        for (uint32_t s = 1; s < d->nstates; s++) {
+            fresh[s] = any_in[s] && !bad_in[s] && d->matched[s];
+            if (fresh[s]) h.any_fresh = 1;
+        }
+    }
     auto build_fast = [&](int fmode) {
     std::vector<uint32_t> fast((size_t) d->nstates * 256);
     for (uint32_t s = 0; s < d->nstates; s++) {
@@ -164,7 +192,37 @@ sre_scan_tables_build(const sre_program_t *prog, const sre_dfa_t *d, int mode, c
                         }
                     }
                     if (!ok) flags |= SRE_FAST_SLOW;
-                } else if (tr.ev_kind != SRE_DFA_EV_NONE || tr.next == SRE_DFA_DEAD) {
+                } else if (fmode == SRE_HIP_PIKE_COUNT && tr.ev_kind == SRE_DFA_EV_DONE && !tr.ev_empty && !tr.skipped
+                           && tr.next != SRE_DFA_DEAD && fresh[tr.next])
+                {
+                    /* the pending match grows */
+                    st = tr.next;
+                    flags |= SRE_FAST_EVT;
+                } else if (fmode == SRE_HIP_PIKE_COUNT && tr.ev_kind == SRE_DFA_EV_NONE && tr.next == SRE_DFA_DEAD && fresh[st]) {
+                    /* the list dies, the pending match ends right here: the next search reads this byte again */
+                    uint32_t r = RESTART_MIXED;
+                    if (sub > 0) {
+                        r = restart_of((idx >> ((sub - 1) * bits)) & ((1u << bits) - 1));
+                    } else if (restart_in[s] != RESTART_NONE) {
+                        r = restart_in[s];
+                    }
+                    bool ok = r != RESTART_MIXED && r != SRE_DFA_DEAD;
+                    if (ok) {
+                        const sre_dfa_trans_t &tr2 = d->t(r, k);
+                        const bool             plain = tr2.ev_kind == SRE_DFA_EV_NONE && tr2.next != SRE_DFA_DEAD;
+                        const bool             grows = tr2.ev_kind == SRE_DFA_EV_DONE && !tr2.ev_empty && !tr2.skipped
+                                                       && tr2.next != SRE_DFA_DEAD && fresh[tr2.next];
+                        ok = plain || grows;
+                        if (ok) {
+                            st = tr2.next;
+                            cnt++;
+                            if (grows) flags |= SRE_FAST_EVT;
+                        }
+                    }
+                    if (!ok) flags |= SRE_FAST_SLOW;
+                } else if (tr.ev_kind != SRE_DFA_EV_NONE || tr.next == SRE_DFA_DEAD
+                           || (fmode == SRE_HIP_PIKE_COUNT && fresh[st]))
+                {
                     flags |= SRE_FAST_SLOW;
                 } else {
                     st = tr.next;
@@ -173,6 +231,7 @@ sre_scan_tables_build(const sre_program_t *prog, const sre_dfa_t *d, int mode, c
             if (flags & SRE_FAST_SLOW) {
                 st = s;
                 cnt = 0;
+                flags = SRE_FAST_SLOW;
             }
             fast[(size_t) s * 256 + idx] = st * SRE_FAST_ROW_BYTES | flags
                                            | (cnt << SRE_FAST_CNT_SHIFT);
@@ -269,7 +328,7 @@ sre_scan_tables_build(const sre_program_t *prog, const sre_dfa_t *d, int mode, c
     std::vector<uint8_t> cls(d->cls_map, d->cls_map + 256);
     std::vector<uint8_t> flags(d->nstates);
     for (uint32_t s = 0; s < d->nstates; s++) {
-        flags[s] = (uint8_t) ((d->matched[s] ? 1 : 0) | (d->seen_start[s] << 1));
+        flags[s] = (uint8_t) ((d->matched[s] ? 1 : 0) | (d->seen_start[s] << 1) | (fresh[s] ? SRE_STATE_FRESH : 0));
     }
     std::vector<uint32_t> ncaps(prog->multi_ncaps, prog->multi_ncaps + prog->nregexes);
     std::vector<uint8_t>  unskip(d->nstates);
