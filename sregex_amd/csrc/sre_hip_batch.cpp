@@ -452,9 +452,10 @@ sre_hip_scanner_kernel_name(sre_hip_scanner_t *sc)
 {
     if (sc->kernel_name[0] == 0) {
         if (sc->engine == SRE_HIP_ENGINE_SCAN) {
-            snprintf(sc->kernel_name, sizeof(sc->kernel_name), "sre_k_scan<%d, %d, %s>",
+            snprintf(sc->kernel_name, sizeof(sc->kernel_name), "sre_k_scan<%d, %d, %s, %s>",
                      sc->mode == SRE_HIP_PIKE_COUNT ? 2 : 1, (int) sc->tab->h.class_bits,
-                     sc->tab->h.wide ? "true" : "false");
+                     sc->tab->h.wide ? "true" : "false",
+                     sc->mode == SRE_HIP_PIKE_COUNT && sc->tab->h.any_fresh ? "true" : "false");
         } else if (sc->engine == SRE_HIP_ENGINE_NFA) {
             if (sc->use_sa) sre_nfa_sa_kernel_name(&sc->satab, sc->kernel_name, sizeof(sc->kernel_name));
             else sre_nfa_kernel_name(sc->mode == SRE_HIP_THOMPSON ? 0 : 1, sc->ntab.nslices, sc->ntab.nassert != 0,

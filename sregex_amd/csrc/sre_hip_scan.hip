@@ -501,12 +501,23 @@ resolve_fast_span(const sre_scan_tables_t *Tp, const uint16_t *tr2, const uint8_
             st = T.init[restart_variant(T, data, r.sp)];
             const uint32_t t3 = tr2[st * (T.ncls + 1) + sym];
             r.pend_pos = -1;
-            if (t3 >> 8) {
-                r.pend_pos = gpos + b;
-                r.pend_state = st;
-                r.pend_sym = sym;
+            if ((t3 >> 8) && (t3 & 0xffu) == 0) {
+                /* ... and completes at once (the byte itself, or an empty match in front of it that makes the
+                 * caller skip the byte): the search behind it starts at the next byte */
+                r.last_pos = gpos + b;
+                r.last_state = st;
+                r.last_sym = sym;
+                r.last_sp = r.sp;
+                r.sp = gpos + b + 1;
+                st = T.init[restart_variant(T, data, r.sp)];
+            } else {
+                if (t3 >> 8) {
+                    r.pend_pos = gpos + b;
+                    r.pend_state = st;
+                    r.pend_sym = sym;
+                }
+                st = t3 & 0xffu;
             }
-            st = t3 & 0xffu;
         } else {
             st = tr.next;
         }
@@ -574,7 +585,10 @@ byte_x4(uint32_t v, uint32_t sh)
  * warm-up: the 128 bytes (one line) in front of the segment, walked with the
  * same fast loop, nothing recorded.
  */
-template <int MODE, int BITS, bool WIDE>
+/* GROW: COUNT tables with FRESH states (growing matches on the fast path, sre_scan_host.cpp): the lane keeps the
+ * last fast span to recover the unrecorded pending match.  A variant of its own: the bookkeeping cost the tables
+ * without such states 5 % (configs[2], same box) when it was a run-time switch. */
+template <int MODE, int BITS, bool WIDE, bool GROW>
 __global__ __launch_bounds__(SRE_SCAN_BLOCK, MODE == SRE_HIP_PIKE_COUNT ? SRE_COUNT_BLOCKS : SRE_FIRST_BLOCKS) void
 sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
            sre_seg_summary_t *__restrict__ sum, const sre_stream_status_t *__restrict__ st_lo,
@@ -829,7 +843,7 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
         w.fl |= F_SP_DIRTY;
         w.count += cnt;
     };
-    const bool any_fresh = __builtin_amdgcn_readfirstlane((int) tabp->any_fresh) != 0;
+    constexpr bool any_fresh = GROW;
     /* after a fast span of a COUNT scan: sum = what the lookups' count bytes added up to (completions in the
      * low seven bits, entries with a growing match above), st1 = the state it ended in */
     auto fast_span_done = [&](int64_t pos, uint32_t len, uint32_t s0, uint32_t sum, uint32_t st1, bool warm_round) {
@@ -2777,25 +2791,26 @@ sre_k_stream_tail(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
 typedef void (*sre_scan_kernel_t)(const sre_scan_tables_t *, sre_scan_geom_t, sre_seg_summary_t *,
                                   const sre_stream_status_t *, const uint8_t *);
 
-template <int MODE>
+template <int MODE, bool GROW>
 static sre_scan_kernel_t
 scan_kernel_bits(uint32_t bits, bool wide4)
 {
     switch (bits) {
-    case 1: return sre_k_scan<MODE, 1, true>;
-    case 2: return sre_k_scan<MODE, 2, true>;
-    case 4: return (MODE == SRE_HIP_PIKE_COUNT && wide4) ? sre_k_scan<MODE, 4, (MODE == SRE_HIP_PIKE_COUNT)>
-                                                         : sre_k_scan<MODE, 4, false>;
-    default: return sre_k_scan<MODE, 8, false>;
+    case 1: return sre_k_scan<MODE, 1, true, GROW>;
+    case 2: return sre_k_scan<MODE, 2, true, GROW>;
+    case 4: return (MODE == SRE_HIP_PIKE_COUNT && wide4) ? sre_k_scan<MODE, 4, (MODE == SRE_HIP_PIKE_COUNT), GROW>
+                                                         : sre_k_scan<MODE, 4, false, GROW>;
+    default: return sre_k_scan<MODE, 8, false, GROW>;
     }
 }
 
-/* the variant that runs for these tables: [mode][class bits][tile index width] */
+/* the variant that runs for these tables: [mode][class bits][tile index width][growing matches] */
 static sre_scan_kernel_t
 scan_kernel(const sre_scan_tables_t *h_tab)
 {
-    return h_tab->mode == SRE_HIP_PIKE_COUNT ? scan_kernel_bits<SRE_HIP_PIKE_COUNT>(h_tab->class_bits, h_tab->wide != 0)
-                                             : scan_kernel_bits<1>(h_tab->class_bits, false);
+    if (h_tab->mode != SRE_HIP_PIKE_COUNT) return scan_kernel_bits<1, false>(h_tab->class_bits, false);
+    return h_tab->any_fresh ? scan_kernel_bits<SRE_HIP_PIKE_COUNT, true>(h_tab->class_bits, h_tab->wide != 0)
+                            : scan_kernel_bits<SRE_HIP_PIKE_COUNT, false>(h_tab->class_bits, h_tab->wide != 0);
 }
 
 extern "C" size_t

@@ -173,6 +173,13 @@ sre_scan_tables_build(const sre_program_t *prog, const sre_dfa_t *d, int mode, c
                     st = restart_of(k);
                     cnt++;
                 } else if (fold_pop && fmode == SRE_HIP_PIKE_COUNT && tr.ev_kind == SRE_DFA_EV_POP
+                           && tr.next == SRE_DFA_DEAD && tr.ev_empty)
+                {
+                    /* an EMPTY match in front of this byte (`\b`, `$`, `x*` where no x is): the caller skips the
+                     * byte (sre_vm_pike.c:179-196) and the next search starts behind it */
+                    st = restart_of(k);
+                    cnt++;
+                } else if (fold_pop && fmode == SRE_HIP_PIKE_COUNT && tr.ev_kind == SRE_DFA_EV_POP
                            && tr.next == SRE_DFA_DEAD && !tr.ev_empty)
                 {
                     /* ... or in front of this byte, which the next search reads again */
@@ -212,10 +219,14 @@ sre_scan_tables_build(const sre_program_t *prog, const sre_dfa_t *d, int mode, c
                         const bool             plain = tr2.ev_kind == SRE_DFA_EV_NONE && tr2.next != SRE_DFA_DEAD;
                         const bool             grows = tr2.ev_kind == SRE_DFA_EV_DONE && !tr2.ev_empty && !tr2.skipped
                                                        && tr2.next != SRE_DFA_DEAD && fresh[tr2.next];
-                        ok = plain || grows;
+                        /* ... or completes a match of its own at once: this one byte, or an empty one in front of it */
+                        const bool             again = tr2.next == SRE_DFA_DEAD
+                                                       && ((tr2.ev_kind == SRE_DFA_EV_DONE && !tr2.ev_empty)
+                                                           || (fold_pop && tr2.ev_kind == SRE_DFA_EV_POP && tr2.ev_empty));
+                        ok = plain || grows || again;
                         if (ok) {
-                            st = tr2.next;
-                            cnt++;
+                            st = again ? restart_of(k) : tr2.next;
+                            cnt += again ? 2 : 1;
                             if (grows) flags |= SRE_FAST_EVT;
                         }
                     }

@@ -1142,11 +1142,11 @@ def test_nfa_tier_large_stream_closed_form(gpu):
 
 
 def test_bench_floor_variant_closed_form_vs_oracle(gpu):
-    """bench.py's `floor` (every byte of a run extends a pending match: every round of every lane runs the
-    scan kernel's exact path) and `floorla` (a look-ahead match every 4 bytes, folded into the COUNT table
-    since round 3) variants: the closed forms they assert at 4 GiB, against the oracle at small sizes."""
+    """bench.py's `floor` (a pending match left behind every 3 bytes: the scan kernel's exact path), `floorla`
+    (a look-ahead match every 4 bytes) and `words` (a greedy class over words) variants — the last two folded
+    into the COUNT table since round 3: the closed forms they assert at 4 GiB, against the oracle at small sizes."""
     ora = harness.OracleEngine()
-    for pat, body in ((rb"\bfoo\b", b"foo "), (rb"a+", b"aaab")):
+    for pat, body, last in ((rb"\bfoo\b", b"foo ", (4, 1)), (rb"a(?:bc)?", b"ab ", (3, 2)), (rb"[a-z]+", b"foo bar ", (4, 1))):
         with S.Pool() as pool:
             re = S.parse(pool, [pat])
             prog = S.compile(pool, re)
@@ -1156,7 +1156,8 @@ def test_bench_floor_variant_closed_form_vs_oracle(gpu):
                 data = body * k
                 _, cnt = _expect(ora, prog, re.ncaps, data)
                 n = len(data)
-                assert cnt == [0, n // 4, n - 4, n - 1], (k, cnt)
+                per = 2 if body == b"foo bar " else 1
+                assert cnt == [0, per * k, n - last[0], n - last[1]], (pat, k, cnt)
                 buf = S.DeviceBuffer.from_bytes(data)
                 rec = sc.scan([buf.ptr], [n])[0]
                 buf.free()
