@@ -101,6 +101,8 @@ struct sre_hip_scanner_s {
     size_t                    nsum_cap;
     uint64_t                 *d_belief;
     uint8_t                  *d_bvalid;
+    uint64_t                 *d_nmat;           /* the segments' singleton exit sets (exact entry sets), on demand */
+    size_t                    nmat_cap;
     void                     *d_nacc;
     sre_nfa_status_t         *d_nstatus, *h_nstatus;
 };
@@ -153,6 +155,7 @@ scanner_release(void *data)
     if (sc->d_nsum) (void) hipFree(sc->d_nsum);
     if (sc->d_belief) (void) hipFree(sc->d_belief);
     if (sc->d_bvalid) (void) hipFree(sc->d_bvalid);
+    if (sc->d_nmat) (void) hipFree(sc->d_nmat);
     if (sc->d_nacc) (void) hipFree(sc->d_nacc);
     if (sc->ntab.accept) (void) hipFree(const_cast<uint64_t *>(sc->ntab.accept));
     if (sc->ntab.follow) (void) hipFree(const_cast<uint64_t *>(sc->ntab.follow));
@@ -792,6 +795,20 @@ nfa_settle(sre_hip_scanner_t *sc, size_t n, hipStream_t stream, bool *psettled)
             return -1;
         }
         SRE_HIP_TRY(hipMemcpyAsync(sc->d_lo, sc->h_lo, n * sizeof(int64_t), hipMemcpyHostToDevice, stream));
+        if (sc->fixup_rounds > SRE_SPECULATIVE_FIXUPS && getenv("SRE_HIP_NO_NFA_EXACT") == NULL) {
+            /* speculation does not settle this batch (a program that never forgets): every remaining lane's
+             * exact entry set from the segments' singleton exit sets — the pass below is then exact */
+            if (sc->geom.nsegs > sc->nmat_cap) {
+                if (sc->d_nmat) (void) hipFree(sc->d_nmat);
+                sc->d_nmat = NULL;
+                sc->nmat_cap = 0;
+                SRE_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&sc->d_nmat), sc->geom.nsegs * 64 * sizeof(uint64_t)));
+                sc->nmat_cap = sc->geom.nsegs;
+            }
+            SRE_HIP_TRY(sre_launch_nfa_exact_entries(sc->use_sa ? 1 : 0, sc->ntab, sc->satab, sc->geom, sc->d_nsum, sc->d_lo,
+                                                     sc->d_nmat, sc->d_belief, sc->d_bvalid, stream));
+            sc->exact_passes++;
+        }
         SRE_HIP_TRY(nfa_launch_scan(sc, sc->d_lo, sc->d_belief, sc->d_bvalid, stream));
         if (nfa_finish(sc, sc->d_lo, stream) != 0) return -1;
     }

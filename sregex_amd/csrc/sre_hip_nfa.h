@@ -73,6 +73,12 @@ hipError_t sre_launch_nfa_scan(int mode, sre_nfa_tables_t tab, sre_scan_geom_t g
 hipError_t sre_launch_nfa_sa_scan(sre_nfa_sa_tables_t tab, sre_scan_geom_t geom,
     sre_nfa_summary_t *d_sum, const int64_t *d_lo, const uint64_t *d_belief,
     const uint8_t *d_bvalid, hipStream_t stream);
+/* exact entry sets for the segments [lo[s], ...) of every unsettled stream (a program that never forgets):
+ * the segments' singleton exit sets (d_mat: 64 x uint64 per segment of the batch), then the recurrence that
+ * leaves every lane's exact entry set in d_belief / d_bvalid — the next pass is exact (sre_hip_nfa.hip) */
+hipError_t sre_launch_nfa_exact_entries(int use_sa, sre_nfa_tables_t ptab, sre_nfa_sa_tables_t atab, sre_scan_geom_t geom,
+    const sre_nfa_summary_t *d_sum, const int64_t *d_lo, uint64_t *d_mat, uint64_t *d_belief, uint8_t *d_bvalid,
+    hipStream_t stream);
 int sre_nfa_sa_blocks_per_cu(const sre_nfa_sa_tables_t *tab);
 const char *sre_nfa_sa_kernel_name(const sre_nfa_sa_tables_t *tab, char *buf, size_t n);
 size_t sre_nfa_verify_acc_bytes(uint32_t nstreams);

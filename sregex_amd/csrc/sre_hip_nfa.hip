@@ -839,6 +839,198 @@ sre_k_nfa_verify_c(int mode, sre_scan_geom_t G, const sre_nfa_summary_t *__restr
     }
 }
 
+/* ===================================================================== exact entry sets */
+
+/*
+ * A program that never forgets (a thread that stays alive from an x far back: `x[^y]*y...`, `x.*y...` over a
+ * stream without newlines) defeats the speculation: a lane cannot know from 128 bytes of warm-up that the
+ * thread is alive, a fix-up round carries the knowledge ONE segment further, and every round is a pass over
+ * everything behind — 64 MiB took 262 143 rounds, 16 s (tools/nfa_never_forgets.py).  The byte step is a
+ * union-homomorphism of the thread set (sre_nfa.h), so a segment's effect on ANY entry set follows from its
+ * effect on the singletons:
+ *      F_k(B u M) = F_k(B) u U_{i in M} F_k({i})
+ * sre_k_nfa_seg_matrix walks every unsettled segment with one WAVE — lane i enters with {i} — and stores the 64
+ * exit sets (512 bytes a segment; the step written once, generically, for every table form: this is the
+ * fallback, 64 walks per segment).  sre_k_nfa_exact_entries then runs, one wave per stream, the recurrence
+ *      T_{k+1} = E_k u U_{i in T_k \ B_k} F_k({i})
+ * from the verified prefix on (B_k, E_k: what the last pass's lane believed and ended in; beliefs only ever
+ * under-estimate) up to the first segment that reports an event, and leaves T_k as every lane's belief: the next
+ * pass is exact in every lane, and the chain check proves it (a mistake here costs rounds, never an answer).
+ */
+struct NfaFnTables {
+    int                 use_sa;
+    sre_nfa_tables_t    P;
+    sre_nfa_sa_tables_t A;
+};
+
+__device__ inline uint64_t
+nfa_readlane64(uint64_t v, uint32_t i)
+{
+    const uint32_t lo = (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) v, (int) i);
+    const uint32_t hi = (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) (v >> 32), (int) i);
+    return ((uint64_t) hi << 32) | lo;
+}
+
+/* one byte step of the set S, as the scan kernels take it (sre_k_nfa / sre_k_nfa_sa); acc = the byte's accept
+ * entry, prevk / ck = the kinds of the byte in front and of this one (look-ahead forms) */
+__device__ inline uint64_t
+nfa_generic_step(const NfaFnTables &T, uint64_t S, uint64_t acc, uint32_t prevk, uint32_t ck)
+{
+    if (T.use_sa) {
+        const sre_nfa_sa_tables_t &A = T.A;
+        if (A.nassert) {
+            const uint64_t am = (1ull << A.nassert) - 1;
+            if (S & am) S |= A.expand[((size_t) (prevk * 4 + ck) << A.nassert) + (size_t) (S & am)];
+        }
+        const uint64_t t = S & acc;
+        uint64_t       e = A.seed;
+        for (uint32_t q = 0; q < A.nlut; q++) {
+            const uint32_t h = (A.perm >> (8 * q)) & 7u;            /* v_perm_b32 selector: 0-3 low word, 4-7 high (w64) */
+            const uint32_t hb = A.w64 ? h : (h & 3u);
+            e |= A.lut[(size_t) q * 256 + (size_t) ((t >> (8 * hb)) & 0xffu)];
+        }
+        const uint64_t ts = A.masked ? (t & A.shift_src) : t;
+        uint64_t       sh;
+        if (A.w64 && A.carry) sh = ts << 1;
+        else sh = (uint64_t) (uint32_t) ((uint32_t) ts << 1) | ((uint64_t) (uint32_t) ((uint32_t) (ts >> 32) << 1) << 32);
+        uint64_t S1 = sh | (t & A.self) | e;
+        if (!A.w64) S1 &= 0xffffffffull;
+        return S1;
+    }
+    const sre_nfa_tables_t &P = T.P;
+    const uint32_t          fsl = P.nassert ? P.nslices - 1 : P.nslices;
+    if (P.nassert) S |= P.expand[(size_t) (prevk * 4 + ck) * 256 + (size_t) ((S >> (8 * (P.nslices - 1))) & 0xffu)];
+    const uint64_t t = S & (acc | P.match_bits);
+    uint64_t       S1 = t & P.match_bits;                           /* sticky */
+    for (uint32_t k = 0; k < fsl; k++) S1 |= P.follow[(size_t) k * 256 + (size_t) ((t >> (8 * k)) & 0xffu)];
+    return S1;
+}
+
+__global__ __launch_bounds__(64) void
+sre_k_nfa_seg_matrix(NfaFnTables T, sre_scan_geom_t G, const int64_t *__restrict__ lo, uint64_t *__restrict__ mat)
+{
+    const uint64_t g = blockIdx.x;
+    if (g >= G.nsegs) return;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t sidx = nfa_stream_of(G, g);
+    const uint64_t k = g - geom_first(G, sidx);
+    if (lo[sidx] < 0 || (int64_t) k < lo[sidx]) return;
+    const uint8_t *data = geom_ptr(G, sidx);
+    const int64_t  n = (int64_t) geom_len(G, sidx);
+    const int64_t  seg_a = (int64_t) k * G.seg_bytes;
+    int64_t        seg_b = seg_a + G.seg_bytes;
+    if (seg_b > n) seg_b = n;
+    const uint64_t *accept = T.use_sa ? T.A.accept : T.P.accept;
+    const uint8_t  *kind = T.use_sa ? T.A.kind : T.P.kind;
+    const bool      la = (T.use_sa ? T.A.nassert : T.P.nassert) != 0;
+    const uint64_t  valid = T.use_sa ? T.A.valid : (T.P.nbits >= 64 ? ~0ull : ((1ull << T.P.nbits) - 1));
+    uint64_t        S = (1ull << lane) & valid;
+    uint32_t        prevk = 3;
+    if (la && seg_a > 0) prevk = kind[data[seg_a - 1]] & 3u;
+    for (int64_t p = seg_a; p < seg_b; p += 64) {
+        const int64_t  idx = p + lane;
+        const uint32_t byte = idx < seg_b ? data[idx] : 0u;
+        const uint64_t acc = accept[byte];
+        const uint32_t kd = la ? (kind[byte] & 3u) : 0u;
+        const uint32_t nb = seg_b - p < 64 ? (uint32_t) (seg_b - p) : 64u;
+        for (uint32_t j = 0; j < nb; j++) {
+            const uint32_t ck = (uint32_t) __builtin_amdgcn_readlane((int) kd, (int) j);
+            S = nfa_generic_step(T, S, nfa_readlane64(acc, j), prevk, ck);
+            prevk = ck;
+        }
+    }
+    mat[g * 64 + lane] = S & valid;
+}
+
+__global__ __launch_bounds__(64) void
+sre_k_nfa_exact_entries(sre_scan_geom_t G, const sre_nfa_summary_t *__restrict__ sum, const int64_t *__restrict__ lo,
+                        const uint64_t *__restrict__ mat, uint64_t *__restrict__ belief, uint8_t *__restrict__ bvalid)
+{
+    const uint32_t s = blockIdx.x;
+    if (s >= G.nstreams || lo[s] < 0) return;
+    const uint32_t lane = threadIdx.x;
+    const uint64_t first = geom_first(G, s), nseg = geom_first(G, s + 1) - first;
+    const uint64_t kstart = (uint64_t) lo[s];
+    if (kstart == 0 || kstart >= nseg) return;
+    /* T = the exact entry set of the segment at hand, uniform.  The chain is serial in the segments, so nothing
+     * on it may wait for memory: the summaries of 64 segments arrive with one load per lane, the singleton exits
+     * 16 segments ahead (one row = one coalesced 512-byte load), and the few rows of the threads that were
+     * missing from a lane's belief come out of registers by v_readlane. */
+    uint64_t T = nfa_readlane64(belief[first + kstart], 0);     /* the verified prefix's exit set (sre_k_nfa_verify_a) */
+    uint64_t stop = nseg;                                       /* first segment whose entry set is not needed */
+    for (uint64_t k0 = kstart; k0 < nseg && stop == nseg; k0 += 64) {
+        const uint64_t me = k0 + lane;
+        uint64_t       sin_l = 0, sout_l = 0, myT = 0;
+        bool           ev_l = false;
+        if (me < nseg) {
+            const sre_nfa_summary_t c = sum[first + me];
+            sin_l = c.s_in;
+            sout_l = c.s_out;
+            ev_l = c.first_ev >= 0;
+        }
+        const uint64_t evm = __builtin_amdgcn_ballot_w64(ev_l);
+        uint32_t       done_at = 64;                            /* lanes below it hold an exact entry set */
+        for (uint32_t b = 0; b < 4 && done_at == 64; b++) {
+            uint64_t rows[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) {
+                const uint64_t q = k0 + b * 16 + u;
+                rows[u] = q < nseg ? mat[(first + q) * 64 + lane] : 0ull;
+            }
+#pragma unroll
+            for (int u = 0; u < 16; u++) {
+                const uint32_t j = b * 16 + u;
+                if (done_at != 64) continue;
+                if (k0 + j >= nseg) {
+                    done_at = j;
+                    continue;
+                }
+                if (lane == j) myT = T;
+                if (((evm >> j) & 1ull) || k0 + j + 1 == nseg) {
+                    /* this segment ends the scan (or the stream): nothing behind it is needed */
+                    done_at = j + 1;
+                    stop = k0 + j + 1;
+                    continue;
+                }
+                uint64_t missing = T & ~nfa_readlane64(sin_l, j), r = 0;
+                if (__builtin_popcountll(missing) <= 6) {
+                    while (missing) {
+                        r |= nfa_readlane64(rows[u], (uint32_t) __builtin_ctzll(missing));
+                        missing &= missing - 1;
+                    }
+                } else {
+                    r = ((missing >> lane) & 1ull) ? rows[u] : 0ull;
+                    for (int d = 32; d >= 1; d >>= 1) r |= __shfl_xor(r, d, 64);
+                    r = nfa_readlane64(r, 0);
+                }
+                T = nfa_readlane64(sout_l, j) | r;
+            }
+        }
+        if (lane < done_at && me < nseg) {
+            belief[first + me] = myT;
+            bvalid[first + me] = 1;
+        }
+    }
+    /* behind the first event nothing is needed: those lanes keep their warm-up */
+    for (uint64_t q = stop + lane; q < nseg; q += 64) bvalid[first + q] = 0;
+}
+
+extern "C" hipError_t
+sre_launch_nfa_exact_entries(int use_sa, sre_nfa_tables_t ptab, sre_nfa_sa_tables_t atab, sre_scan_geom_t geom,
+                             const sre_nfa_summary_t *d_sum, const int64_t *d_lo, uint64_t *d_mat, uint64_t *d_belief,
+                             uint8_t *d_bvalid, hipStream_t stream)
+{
+    if (geom.nsegs == 0) return hipSuccess;
+    NfaFnTables T;
+    T.use_sa = use_sa;
+    T.P = ptab;
+    T.A = atab;
+    hipLaunchKernelGGL(sre_k_nfa_seg_matrix, dim3((uint32_t) geom.nsegs), dim3(64), 0, stream, T, geom, d_lo, d_mat);
+    hipLaunchKernelGGL(sre_k_nfa_exact_entries, dim3(geom.nstreams), dim3(64), 0, stream, geom, d_sum, d_lo, d_mat, d_belief,
+                       d_bvalid);
+    return hipGetLastError();
+}
+
 typedef void (*nfa_kernel_t)(sre_nfa_tables_t, sre_scan_geom_t, sre_nfa_summary_t *, const int64_t *,
                              const uint64_t *, const uint8_t *);
 

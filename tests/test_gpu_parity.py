@@ -1073,6 +1073,45 @@ def _nfa_zoo_vs_oracle(gpu, seg):
     return kernels
 
 
+@pytest.mark.parametrize("sa", [0, 128, 4 + 8, 1 + 64])
+def test_nfa_tier_program_that_never_forgets_gets_exact_entry_sets(gpu, sa, monkeypatch):
+    """A thread that stays alive from an x far back (`x[^y]*y...`, `x.*y...` over a stream without newlines): no lane
+    can know from its warm-up that the thread is alive, and a fix-up round carried the knowledge ONE segment further
+    (64 MiB: 262 143 rounds, 16 s; tools/nfa_never_forgets.py).  After two speculative rounds the tier now walks
+    every remaining segment with a wave whose lanes enter with the singleton sets, folds those exit sets into every
+    lane's exact entry set (the step is a union-homomorphism) and finishes in one exact pass — under every table
+    form (shift-and 32 / 64 bits with carry / masked, plain slices, look-ahead).  Results against the oracle,
+    rounds bounded."""
+    monkeypatch.setenv("SRE_HIP_NFA_SA", str(sa))
+    ora = harness.OracleEngine()
+    tail = b" abaabaabab@ "
+    cases = [([rb"x[^y]*y(?:a|b)*a(?:a|b){7}@"], b"ab" * 33 + b"x" + b"abccc" * 30000 + b"y" + b"abaabaabab@ zz"),
+             ([rb"x[^y]*y(?:a|b)*a(?:a|b){7}@"], b"x" + b"abccc" * 30000 + tail),                # no y: no match
+             ([rb"x.*y(?:a|b)*a(?:a|b){7}@"], b"q" * 700 + b"x" + b"abccc" * 25000 + b"yabaabaabab@ " + b"abccc" * 3000),
+             ([rb"x.*y(?:a|b)*a(?:a|b){7}@$"], b"x" + b"abccc" * 25000 + b"yabaabaabab@"),       # look-ahead form
+             ([rb"x[^y]*y(?:a|b)*a[ab]{20}c[^x]{30}@"], b"x" + b"abccc" * 20000 + b"y" + b"a" * 22 + b"c" + b"b" * 30 + b"@ ")]
+    for seg in (256, 1280):
+        for pats, data in cases:
+            with S.Pool() as pool:
+                re = S.parse(pool, pats)
+                prog = S.compile(pool, re)
+                first, cnt = _expect(ora, prog, re.ncaps, data)
+                buf = S.DeviceBuffer.from_bytes(data)
+                for mode, want in ((S.HIP_PIKE_FIRST, first), (S.HIP_THOMPSON, None)):
+                    try:
+                        sc = S.Scanner(pool, prog, mode, S.ENGINE_NFA)
+                    except RuntimeError:
+                        continue
+                    sc.set_segment_bytes(seg)
+                    rec = sc.scan([buf.ptr], [len(data)])[0]
+                    if want is None:
+                        assert rec[0] == (0 if first[0] >= 0 else S.SRE_DECLINED), (pats, seg, rec, sc.kernel_name)
+                    else:
+                        assert rec == want, (pats, seg, rec, want, sc.kernel_name)
+                    assert sc.last_fixups <= 6, (pats, seg, mode, sc.last_fixups, sc.kernel_name)
+                buf.free()
+
+
 def test_nfa_tier_takes_what_the_step_automaton_declines(gpu, blocks):
     """ENGINE_AUTO: every reference block whose ordered-list automaton is too large
     for the table-driven scanner and whose program has a bit-parallel form runs
