@@ -1098,7 +1098,8 @@ scan_settle(sre_hip_scanner_t *sc, size_t n, hipStream_t stream, bool with_captu
                 return -1;
             }
             const uint8_t *d_entry = NULL;
-            if (sc->mode != SRE_HIP_PIKE_COUNT && sc->fixup_rounds > SRE_SPECULATIVE_FIXUPS) {
+            static const bool count_exact = getenv("SRE_HIP_NO_COUNT_EXACT") == NULL;      /* (experiment knob) */
+            if ((sc->mode != SRE_HIP_PIKE_COUNT || count_exact) && sc->fixup_rounds > SRE_SPECULATIVE_FIXUPS) {
                 /* speculation does not settle this stream (an automaton that never
                  * forgets): compose the segments' transition functions instead — after
                  * this pass every lane enters with the exact state */

@@ -767,6 +767,23 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
              * (sre_k_seg_functions; FIRST / Thompson after fix-up rounds that did
              * not converge) */
             w.st = entry[g];
+            if (MODE == SRE_HIP_PIKE_COUNT && lo_s > 0 && (T.state_flags[w.st] & 1)) {
+                /* (COUNT: the match such a state holds is taken from the verified prefix, as below) */
+                const sre_seg_summary_t &c = sum[geom_first(G, sidx) + lo_s - 1];
+                if (c.flags & SRE_SUM_PENDING) {
+                    w.fl |= F_HAS_EV | F_IN_PENDING;
+                    w.ev_state = c.pe_state;
+                    w.ev_sym = c.pe_sym;
+                    w.ev_pos = c.pe_pos;
+                    w.ev_sp = c.pe_sp;
+                    w.ev_apos = -1;
+                    w.ev_astate = 0;
+                    w.ev_kind = (uint8_t) (w.tr2[c.pe_state * (T.ncls + 1) + c.pe_sym] >> 8);
+                    in_pe_pos = c.pe_pos;
+                    in_pe_state = c.pe_state;
+                    in_pe_sym = c.pe_sym;
+                }
+            }
         } else {
             /* speculative: assume the state reached by a warm-up over the WARM
              * bytes in front of the segment.  In a fix-up round the warm-up
@@ -1221,8 +1238,43 @@ sre_k_seg_functions(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t 
     int64_t        p = (int64_t) k * G.seg_bytes, seg_b = p + G.seg_bytes;
     if (seg_b > n) seg_b = n;
     uint32_t cur = lane;
+    const bool count_mode = tabp->mode == SRE_HIP_PIKE_COUNT;
     auto exact = [&](int64_t from, int64_t to) {
-        for (int64_t q = from; q < to; q++) cur = tr2[cur * nsym + clsl[data[q]]] & 0xffu;
+        if (!count_mode) {
+            for (int64_t q = from; q < to; q++) cur = tr2[cur * nsym + clsl[data[q]]] & 0xffu;
+            return;
+        }
+        /* COUNT: the caller's restarts belong to the function (slow_run): a search that ends with a match is
+         * followed by one from the match end (a byte further after an empty match), from the list the byte in
+         * front selects.  A match recorded in front of this span is taken to end right here (what a FRESH
+         * state says; elsewhere an approximation — the chain check decides, a wrong entry state costs a round). */
+        int64_t  pend = -1;
+        uint32_t pkind = 0, guard = 0;
+        for (int64_t q = from; q < to; q++) {
+            const uint32_t sym = clsl[data[q]];
+            const uint32_t t2 = tr2[cur * nsym + sym];
+            if (t2 >> 8) {
+                pend = q;
+                pkind = t2 >> 8;
+            }
+            cur = t2 & 0xffu;
+            if (cur != 0) continue;
+            int64_t sp = q + 1;
+            if (pend >= 0) {
+                const bool    pop = pkind == EV_POP || pkind == SRE_DEV_EV_POP_FULL;
+                const bool    empty = pkind == EV_POP || pkind == SRE_DEV_EV_DONE_EMPTY;
+                const int64_t e = pop ? pend : pend + 1;
+                sp = empty ? e + 1 : e;
+            } else if (++guard < 2) {
+                sp = q;                         /* the match in flight ended in front of this byte: read it again */
+            }
+            if (pend >= 0) guard = 0;
+            if (sp < 1) sp = 1;
+            if (sp > n) sp = n;
+            cur = tabp->init[restart_variant_of(*tabp, data[sp - 1])];
+            pend = -1;
+            q = sp - 1;
+        }
     };
     for (; p + 16 <= seg_b; p += 16) {
         const sre_u32x4 v = *reinterpret_cast<const __attribute__((address_space(1))) sre_u32x4_unaligned *>(
