@@ -53,6 +53,8 @@
 #define SRE_SCAN_MAX_STATES       62u     /* with 8 class bits; fewer with narrower classes */
 #define SRE_SCAN_BLOCK        256u    /* lanes = segments per workgroup */
 #define SRE_SCAN_LDS_LIMIT    (128u * 1024u)  /* dynamic LDS a scan workgroup may ask for (160 KiB per CU) */
+#define SRE_CAPTURE_MAX_GRID   16384u          /* workgroups of the capture walker: beyond that they take their streams in turn */
+#define SRE_CAPTURE_LANE_STREAMS 4096u         /* batches of that many streams are walked by lanes (64 per workgroup) */
 #define SRE_CAPTURE_LDS_LIMIT  (144u * 1024u)  /* ... and the capture walker / lineage kernels (one workgroup per CU then) */
 #define SRE_SCAN_ROUND        64u     /* bytes a lane consumes per LDS round */
 #define SRE_SCAN_LINE         128u    /* staging granule: whole lines, half a wave per stage; also the warm-up */

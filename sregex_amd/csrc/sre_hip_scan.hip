@@ -2458,8 +2458,8 @@ sre_k_captures(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
     SRE_TAIL_PRIO();
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     __shared__ sre_scan_tables_t Ts;
-    __shared__ uint16_t sh_trace[72];       /* the walker's current 64-byte block (Tracer) */
-    __shared__ uint8_t  sh_syms[72];
+    __shared__ uint16_t sh_trace[64][72];   /* the walker's current 64-byte block (Tracer), per walking lane */
+    __shared__ uint8_t  sh_syms[64][72];
 #ifdef SRE_DEBUG_WALK
     const unsigned long long dbg_t0 = wall_clock64();
 #endif
@@ -2472,8 +2472,14 @@ sre_k_captures(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
     /* one WORKGROUP per stream, lane 0 walks: the walks of a batch run side by side on
      * different CUs instead of as 64 divergent lanes of one wave (128 streams: 51 us -> see
      * profiles/r02_experiments.txt) */
-    const uint32_t s = blockIdx.x;
-    if (s >= G.nstreams || threadIdx.x != 0) return;
+    /* A batch of very many streams (a million log lines) is walked by LANES — 64 streams per wave, divergent but
+     * side by side, on a bounded grid whose workgroups take their streams in turn: a walk is ~18 us of latency
+     * on one lane, and 2048 resident workgroups of one walking lane each made 8.8 ms of 1M x 96 B with a match
+     * in every line. */
+    const bool     lane_mode = NT == 64 && G.nstreams >= SRE_CAPTURE_LANE_STREAMS;
+    if (!lane_mode && threadIdx.x != 0) return;
+    const uint32_t wl = lane_mode ? threadIdx.x : 0u;
+    auto one_stream = [&](const uint32_t s) {
     if (use_maps && !status[s].need_maps) return;   /* second pass: flagged streams only */
 #ifdef SRE_DEBUG_WALK
     const unsigned long long dbg_ts = wall_clock64();
@@ -2511,8 +2517,8 @@ sre_k_captures(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
     tr.apos = (st.ev_apos >= st.ev_sp) ? st.ev_apos : -1;
     tr.astate = st.ev_astate;
     tr.ck = scratch + (size_t) s * (G.seg_bytes + 16);
-    tr.trace = (__attribute__((address_space(3))) uint16_t *) sh_trace;
-    tr.syms = (__attribute__((address_space(3))) uint8_t *) sh_syms;
+    tr.trace = (__attribute__((address_space(3))) uint16_t *) sh_trace[wl];
+    tr.syms = (__attribute__((address_space(3))) uint8_t *) sh_syms[wl];
     tr.bind();
     tr.seg_lo = tr.seg_hi = -1;
     tr.blk_lo = 1;
@@ -2586,6 +2592,12 @@ sre_k_captures(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
            dbg_ts - dbg_t0, dbg_tw0 - dbg_ts, dbg_tw1 - dbg_tw0, wall_clock64() - dbg_tw1, tr.dbg_steps, tr.dbg_seg_calls,
            tr.dbg_seg_ticks, tr.dbg_entry_ticks, tr.dbg_blk_calls, tr.dbg_blk_ticks, tr.dbg_top, tr.dbg_sb, tr.dbg_rest);
 #endif
+    };
+    if (lane_mode) {
+        for (uint32_t s = blockIdx.x * 64u + wl; s < G.nstreams; s += gridDim.x * 64u) one_stream(s);
+    } else {
+        for (uint32_t s = blockIdx.x; s < G.nstreams; s += gridDim.x) one_stream(s);
+    }
 }
 
 
@@ -2989,7 +3001,9 @@ sre_launch_captures(const sre_scan_tables_t *d_tab, sre_scan_tables_t h_tab, sre
     if (verify && (geom.nstreams != 1 || geom.nsegs > SRE_VERIFY_ONE_SEGS || h_tab.mode == SRE_HIP_PIKE_COUNT || use_maps)) {
         return hipErrorInvalidValue;
     }
-    const uint32_t block = verify ? 1024 : 64, grid = geom.nstreams;
+    const uint32_t block = verify ? 1024 : 64;
+    const uint32_t want = (!verify && geom.nstreams >= SRE_CAPTURE_LANE_STREAMS) ? (geom.nstreams + 63u) / 64u : geom.nstreams;
+    const uint32_t grid = want < SRE_CAPTURE_MAX_GRID ? want : SRE_CAPTURE_MAX_GRID;
     const size_t   shmem = (size_t) h_tab.fast_bytes + 256
                          + ((size_t) h_tab.nstates * (h_tab.ncls + 1) + SRE_SCAN_NINIT) * sizeof(sre_dev_trans_t)
                          + (size_t) h_tab.lin_total * 9 + ((size_t) h_tab.nstates + 1 + h_tab.list_total) * 4 + 16;

@@ -222,6 +222,37 @@ def test_many_ragged_streams_one_call(gpu):
             b.free()
 
 
+def test_thousands_of_short_streams_one_call(gpu):
+    """A batch of log lines: 6000 short streams (0-300 bytes) in one call — at 4096 streams and more the capture
+    walker takes the streams by LANES (64 walks per wave side by side; one walking lane per workgroup made 8.8 ms
+    of a million lines with a match each, tools/many_small_probe.py).  First match + captures and find-all
+    counts of every line against the oracle."""
+    import random
+    ora = harness.OracleEngine()
+    rng = random.Random(5)
+    words = [b"GET ", b"/index.html ", b"user ", b"a@abc.cc ", b"x@y.zz ", b"nobody ", b"@@ ", b"q@w ", b"\n", b"[abc] "]
+    lines = [b"".join(rng.choice(words) for _ in range(rng.randrange(0, 24))) for _ in range(6000)]
+    blob = b"".join(lines)
+    offs, o = [], 0
+    for ln in lines:
+        offs.append(o)
+        o += len(ln)
+    with S.Pool() as pool:
+        re = S.parse(pool, [rb"([a-z]+)@([a-z]+)\.[a-z]+", rb"\[(\w+)\]"])
+        prog = S.compile(pool, re)
+        buf = S.DeviceBuffer.from_bytes(blob)
+        ptrs, lens = [buf.ptr + x for x in offs], [len(ln) for ln in lines]
+        first = S.Scanner(pool, prog, S.HIP_PIKE_FIRST).scan(ptrs, lens)
+        count = S.Scanner(pool, prog, S.HIP_PIKE_COUNT).scan(ptrs, lens)
+        buf.free()
+        cache = {}
+        for ln, f, c in zip(lines, first, count):
+            if ln not in cache:
+                cache[ln] = _expect(ora, prog, re.ncaps, ln)
+            wf, wc = cache[ln]
+            assert f == wf and c == wc, (ln, f, wf, c, wc)
+
+
 def test_gen_data_kernel_matches_host_generator(gpu):
     for n, tail in [(0, b""), (1, b""), (5, b""), (4098, b"aaabbccb"), (100003, b"@abc.cc "), (77, b"x" * 77)]:
         n = S.gen_data_length(n, len(tail)) if n >= len(tail) else len(tail)
