@@ -795,7 +795,8 @@ nfa_settle(sre_hip_scanner_t *sc, size_t n, hipStream_t stream, bool *psettled)
             return -1;
         }
         SRE_HIP_TRY(hipMemcpyAsync(sc->d_lo, sc->h_lo, n * sizeof(int64_t), hipMemcpyHostToDevice, stream));
-        if (sc->fixup_rounds > SRE_SPECULATIVE_FIXUPS && getenv("SRE_HIP_NO_NFA_EXACT") == NULL) {
+        if (sc->fixup_rounds > SRE_SPECULATIVE_FIXUPS && sc->geom.nsegs <= ((size_t) 1 << 23)       /* (512 bytes a segment) */
+            && getenv("SRE_HIP_NO_NFA_EXACT") == NULL) {
             /* speculation does not settle this batch (a program that never forgets): every remaining lane's
              * exact entry set from the segments' singleton exit sets — the pass below is then exact */
             if (sc->geom.nsegs > sc->nmat_cap) {
