@@ -34,6 +34,9 @@
 /*   bit  5       EVT (COUNT tables, which have no STABLE entries): a sub-step recorded a match that is still
  *                pending at its end — the list lives on in a FRESH state (sre_scan_host.cpp) */
 #define SRE_FAST_EVT        32u
+/*   bit  6       NEXT_FRESH (COUNT tables): the state the entry ends in is FRESH — the scan kernel reads it off the
+ *                last entry of a round instead of looking the state's flags up (a dependent LDS access per round) */
+#define SRE_FAST_NEXT_FRESH 64u
 #define SRE_STATE_FRESH     8u      /* sre_scan_tables_t.state_flags: every way into the state records a match that ends
                                        with the byte just consumed */
 #define SRE_FAST_ROW_BYTES  1024u

@@ -634,6 +634,7 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
      * of lookups carries no per-step flag test, the flag is there at its end. */
     constexpr uint32_t LDS_SLOW = 1u << 16;
     constexpr uint32_t LDS_CNT_SHIFT = 24;
+    constexpr uint32_t LDS_FRESH = 1u << 17;        /* COUNT: the entry ends in a FRESH state */
     const uint32_t fast_lds = (uint32_t) (uintptr_t) (__attribute__((address_space(3))) uint8_t *) lds;
     const uint32_t trap_lds = fast_lds + nst * SRE_FAST_ROW_BYTES;
     const uint32_t shadow_lds = trap_lds + SRE_FAST_ROW_BYTES;      /* first shadow row */
@@ -643,7 +644,8 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
          * both — completions in the low seven bits (<= 64 a round), entries with a growing match above */
         return (fast_lds + (g & ~(SRE_FAST_ROW_BYTES - 1)))
                | (((g >> SRE_FAST_CNT_SHIFT) & SRE_FAST_CNT_MASK) << LDS_CNT_SHIFT)
-               | ((MODE == SRE_HIP_PIKE_COUNT && (g & SRE_FAST_EVT)) ? (128u << LDS_CNT_SHIFT) : 0u);
+               | ((MODE == SRE_HIP_PIKE_COUNT && (g & SRE_FAST_EVT)) ? (128u << LDS_CNT_SHIFT) : 0u)
+               | ((MODE == SRE_HIP_PIKE_COUNT && (g & SRE_FAST_NEXT_FRESH)) ? LDS_FRESH : 0u);
     };
     for (uint32_t i = tid; i < nst * 64; i += SRE_SCAN_BLOCK) {
         uint4 e = reinterpret_cast<const uint4 *>(tabp->fast)[i];
@@ -862,8 +864,8 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
     };
     constexpr bool any_fresh = GROW;
     /* after a fast span of a COUNT scan: sum = what the lookups' count bytes added up to (completions in the
-     * low seven bits, entries with a growing match above), st1 = the state it ended in */
-    auto fast_span_done = [&](int64_t pos, uint32_t len, uint32_t s0, uint32_t sum, uint32_t st1, bool warm_round) {
+     * low seven bits, entries with a growing match above), fresh1 = it ended in a FRESH state (its last entry says so) */
+    auto fast_span_done = [&](int64_t pos, uint32_t len, uint32_t s0, uint32_t sum, bool fresh1, bool warm_round) {
         if (!any_fresh) {
             if (sum) note_span(pos, len, s0, sum, warm_round);      /* (a table without growing matches: completions only) */
             return;
@@ -874,7 +876,7 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
         }
         if (sum & 127u) note_span(pos, len, s0, sum & 127u, warm_round);
         else if (sum) w.fl &= ~F_HAS_EV;        /* a later match of the same search supersedes the recorded one */
-        if (sfl[st1] & SRE_STATE_FRESH) {
+        if (fresh1) {
             w.fl |= F_PEND_LAZY;
             w.set(F_LZ_GROUP, len == 16u);
             lz_pos = pos;
@@ -1020,7 +1022,7 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
                 /* matches completed in the round, each followed by a restart at
                  * the next byte, are only counted here (see note_span) */
                 const uint32_t ridx = ((t & 0xffffu) - fast_lds) / SRE_FAST_ROW_BYTES;
-                if (MODE == SRE_HIP_PIKE_COUNT) fast_span_done(base, TILE, w.st, cnt, ridx, warm_round);
+                if (MODE == SRE_HIP_PIKE_COUNT) fast_span_done(base, TILE, w.st, cnt, (t & LDS_FRESH) != 0, warm_round);
                 w.st = MODE == SRE_HIP_PIKE_COUNT ? ridx : ridx <= nst ? ridx : ridx == nst + 1 ? sh_st0 : sh_st1;
                 if (MODE != SRE_HIP_PIKE_COUNT && w.f(F_SHADOW) && ridx <= nst) {
                     /* left the shadow rows: the stable stretch ended in this round */
@@ -1078,7 +1080,7 @@ sre_k_scan(const sre_scan_tables_t *__restrict__ tabp, sre_scan_geom_t G,
                 slow_run<MODE>(w, gp, g_end, warm_round, seed);
             } else {
                 const uint32_t st1 = ((t & 0xffffu) - fast_lds) / SRE_FAST_ROW_BYTES;    /* ordinary rows only on this path */
-                if (MODE == SRE_HIP_PIKE_COUNT) fast_span_done(gp, 16, w.st, cnt, st1, warm_round);
+                if (MODE == SRE_HIP_PIKE_COUNT) fast_span_done(gp, 16, w.st, cnt, (t & LDS_FRESH) != 0, warm_round);
                 w.st = st1;
             }
         }

@@ -243,6 +243,8 @@ sre_scan_tables_build(const sre_program_t *prog, const sre_dfa_t *d, int mode, c
                 st = s;
                 cnt = 0;
                 flags = SRE_FAST_SLOW;
+            } else if (fmode == SRE_HIP_PIKE_COUNT && st < d->nstates && fresh[st]) {
+                flags |= SRE_FAST_NEXT_FRESH;
             }
             fast[(size_t) s * 256 + idx] = st * SRE_FAST_ROW_BYTES | flags
                                            | (cnt << SRE_FAST_CNT_SHIFT);
