@@ -22,24 +22,7 @@
  *                reached after the last restart)
  * (global-memory format; sre_k_scan re-packs an entry for LDS as
  *  [count : 8][flags : 8][LDS address of the next row : 16]) */
-#define SRE_FAST_SLOW       1u
-#define SRE_FAST_CNT_SHIFT  1u
-#define SRE_FAST_CNT_MASK   0xfu
-/*   bit  5       STABLE (tables without COUNT's folded restarts only): the step returns to
- *                the SAME state without an event, and every thread of the state's neutral
- *                set (sre_scan_tables_t.neutral) descends from ITSELF without saving a
- *                capture slot — a thread list "looping in place" (x+ over a run of x).
- *                The capture walker jumps over stretches made of such steps only. */
-#define SRE_FAST_STABLE     32u
-/*   bit  5       EVT (COUNT tables, which have no STABLE entries): a sub-step recorded a match that is still
- *                pending at its end — the list lives on in a FRESH state (sre_scan_host.cpp) */
-#define SRE_FAST_EVT        32u
-/*   bit  6       NEXT_FRESH (COUNT tables): the state the entry ends in is FRESH — the scan kernel reads it off the
- *                last entry of a round instead of looking the state's flags up (a dependent LDS access per round) */
-#define SRE_FAST_NEXT_FRESH 64u
-#define SRE_STATE_FRESH     8u      /* sre_scan_tables_t.state_flags: every way into the state records a match that ends
-                                       with the byte just consumed */
-#define SRE_FAST_ROW_BYTES  1024u
+#include "sre_scan_fast.h"     /* SRE_FAST_*, SRE_STATE_FRESH */
 
 /* In LDS the fast table has extra rows behind the automaton's own: one TRAP row (every
  * entry points back into it, flagged SLOW; SLOW entries of the other rows point there,

@@ -1,0 +1,119 @@
+"""The scanner's COUNT fast table (sregex_amd/csrc/sre_scan_fast.cpp: the find-all iteration's restarts folded into
+the table — matches that end with a consumed byte, that a look-ahead assertion completes, empty ones, matches that
+GROW while the list lives on, the list dying in a FRESH state) and the lane's bookkeeping around it (the last
+fast spans, their replay: sre_hip_scan.hip settle()), checked on the CPU through a test-only model of one lane
+(tests/scan_sim.cpp) against the oracle: the count of a whole find-all iteration, the end of its last match and
+the start of that match's search, with spans of 64 bytes (the kernel's round path), 16 (its group path) and with
+every byte on the exact path.  The GPU suite checks the kernel itself (tests/test_gpu_parity.py)."""
+import ctypes
+import os
+import random
+import subprocess
+
+import pytest
+
+import sregex_amd as S
+import harness
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+_vp, _i64 = ctypes.c_void_p, ctypes.c_int64
+
+
+@pytest.fixture(scope="module")
+def sim(lib):
+    out = os.path.join(HERE, "_build")
+    os.makedirs(out, exist_ok=True)
+    so = os.path.join(out, "libscansim.so")
+    csrc = os.path.join(ROOT, "sregex_amd", "csrc")
+    srcs = [os.path.join(HERE, "scan_sim.cpp"), os.path.join(csrc, "sre_scan_fast.cpp"), os.path.join(csrc, "sre_dfa.cpp")]
+    deps = srcs + [os.path.join(csrc, "sre_scan_fast.h")]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in deps):
+        subprocess.check_call(["g++", "-O2", "-g", "-std=c++17", "-shared", "-fPIC", "-o", so] + srcs +
+                              ["-I" + os.path.join(ROOT, "include"), "-I" + csrc])
+    L = ctypes.CDLL(so)
+    L.sre_dfa_build.restype = _vp
+    L.sre_dfa_build.argtypes = [_vp, ctypes.c_uint32, ctypes.POINTER(ctypes.c_char_p)]
+    L.sre_dfa_free.argtypes = [_vp]
+    L.scan_sim_count.argtypes = [_vp, ctypes.c_char_p, _i64, ctypes.c_int, ctypes.POINTER(_i64)]
+    return L
+
+
+def _want(ora, prog, ncaps, data):
+    """count, end of the last match, start of its search (the previous match's end, a byte further behind an
+    empty one), whether the iteration ended with SRE_ERROR"""
+    allm = harness.findall(ora, prog, ncaps, data)
+    final, matches = allm[-1][0], allm[:-1]
+    if not matches:
+        return 0, -1, -1, final == S.SRE_ERROR
+    sp = 0
+    if len(matches) > 1:
+        p0, p1 = matches[-2][1], matches[-2][2]
+        sp = p1 + 1 if p0 == p1 else p1
+    return len(matches), matches[-1][2], sp, final == S.SRE_ERROR
+
+
+def _runs(rng, alphabet, total):
+    out = bytearray()
+    while len(out) < total:
+        out += bytes([rng.choice(alphabet)]) * rng.choice([1, 1, 1, 2, 3, 9, 30])
+    return bytes(out[:total])
+
+
+ZOO = [[rb"[a-z]+"], [rb"a+"], [rb"\bfoo\b"], [rb"foo$"], [rb"^foo"], [rb"\b"], [rb"$"], [rb"x*"], [rb"a*"], [rb"a(?:bc)?"],
+       [rb"(a)(b)?"], [rb"a|ab|abc"], [rb"\w+\s"], [rb"[a-z]+@[a-z]+\.[a-z]+"], [rb"\b[a-z]+@[a-z]+\.[a-z]+\b"],
+       [rb'"[^"]*"'], [rb"x(?:[^y]{3})*y"], [rb"\d+(?:\.\d+)?"], [rb"foo|foobar"], [rb"a", rb"ab", rb"c", rb"b"],
+       [rb"\s+", rb"[a-c]+x"], [rb"(?:ab)+"], [rb"a.*b"], [rb"\n+"], [rb"^", rb"a"]]
+BODIES = [b"foo bar ", b"aaab", b"foo foo\nfoo\n", b"ab cd ", b"ab ", b'"ab" cde ', b"xabcabcy z", b"12.5 7 3.x ", b"foobar foo fooba ",
+          b"abccc", b"a", b"ababab \n"]
+
+
+def test_count_lane_model_vs_oracle(sim):
+    ora = harness.OracleEngine()
+    rng = random.Random(int(os.environ.get("SRE_FUZZ_SEED", "20261004")) + 31)
+    alphabet = b"abcx \n_."
+    cases = []
+    for pats in ZOO:
+        for body in BODIES:
+            cases.append((pats, body * rng.choice([1, 7, 40])))
+        cases.append((pats, _runs(rng, alphabet, 300)))
+    for _ in range(1500):
+        nre = 1 if rng.random() < 0.8 else rng.randrange(2, 4)
+        pats = [harness.random_regex(rng) for _ in range(nre)]
+        d = (bytes(rng.choice(alphabet) for _ in range(rng.choice([0, 1, 7, 40, 130, 400]))) if rng.random() < 0.5
+             else _runs(rng, alphabet, rng.choice([40, 130, 400])))
+        cases.append((pats, d))
+    n = grow = fast = total = 0
+    bad = []
+    for pats, data in cases:
+        with S.Pool() as pool:
+            try:
+                re = S.parse(pool, pats)
+            except Exception:
+                continue
+            prog = S.compile(pool, re)
+            if len(pats) > 1 and any(tok in p for p in pats for tok in (b"^", b"\\A", b"$", b"\\z", b"\\b", b"\\B")):
+                continue        # the scanner declines COUNT with ^ or look-ahead over several regexes (sre_scan_host.cpp)
+            why = ctypes.c_char_p()
+            d = sim.sre_dfa_build(prog.h, 63, ctypes.byref(why))
+            if not d:
+                continue
+            want = _want(ora, prog, re.ncaps, data)
+            for span in (64, 16, 0):
+                out = (_i64 * 6)()
+                sim.scan_sim_count(d, bytes(data), len(data), span, out)
+                got = (out[0], out[1], out[2], bool(out[3] & 8))
+                n += 1
+                if span == 64:
+                    grow += out[5]
+                    fast += out[4]
+                    total += len(data)
+                # (the start of the last match's search is compared when the model knows it)
+                ok = got[0] == want[0] and got[1] == want[1] and got[3] == want[3] and (got[2] < 0 or got[2] == want[2])
+                if out[3] & 16 or not ok:
+                    bad.append((pats, data[:60], span, got, want, out[3]))
+            sim.sre_dfa_free(d)
+    assert not bad, (len(bad), bad[:4])
+    assert n > 3000 and grow > 200, (n, grow)
+    # most bytes take fast entries (the folds keep the iteration on the table)
+    assert fast > 0.5 * total, (fast, total)
