@@ -139,4 +139,38 @@ void nfa_sim_run_sa(void *h, const uint8_t *data, int64_t n, int variant, int64_
     out[2] = bad;
 }
 
+
+/* The thread set after stepping S over data[0, n) with no regard to events (what a segment does to an entry set:
+ * sre_hip_nfa.hip sre_k_nfa_seg_matrix), by the plain form (sa == 0) or the shift-and form; prev0 = the kind of
+ * the byte in front (SRE_NFA_KIND_*).  The exact-entry fallback of the NFA tier rests on this being a
+ * union-homomorphism of S. */
+uint64_t nfa_sim_walk_set(void *h, int sa, uint64_t S, const uint8_t *data, int64_t n, uint32_t prev0)
+{
+    const sre_nfa_t    *g = static_cast<sre_nfa_t *>(h);
+    const sre_nfa_sa_t *a = g->sa;
+    uint32_t            prev = prev0;
+    for (int64_t p = 0; p < n; p++) {
+        const uint32_t cur = g->kind[data[p]] & 3u;
+        if (sa) {
+            if (a->nassert) S |= a->expand[(size_t) (prev * 4 + cur) * 256 + ((S >> (8 * a->assert_byte)) & 0xff)];
+            uint64_t t;
+            S = sa_step(a, S, data[p], &t);
+        } else {
+            if (g->nassert) S |= g->expand[(size_t) (prev * 4 + cur) * 256 + ((S >> (8 * g->assert_slice)) & 0xff)];
+            const uint64_t t = S & (g->accept[data[p]] | g->match_bits);
+            uint64_t       r = t & g->match_bits;
+            for (uint32_t k = 0; k < g->nslices; k++) r |= g->follow[(size_t) k * 256 + ((t >> (8 * k)) & 0xff)];
+            S = r;
+        }
+        prev = cur;
+    }
+    return S;
+}
+uint64_t nfa_sim_valid_bits(void *h, int sa)
+{
+    const sre_nfa_t *g = static_cast<sre_nfa_t *>(h);
+    if (sa) return g->sa ? g->sa->valid : 0;
+    return g->nbits >= 64 ? ~0ull : ((1ull << g->nbits) - 1);
+}
+
 }

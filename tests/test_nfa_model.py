@@ -38,6 +38,10 @@ def sim(lib):
     L.nfa_sim_build2.argtypes = [_vp, ctypes.c_uint, ctypes.POINTER(ctypes.c_char_p)]
     L.nfa_sim_sa_info.argtypes = [_vp, ctypes.POINTER(ctypes.c_int32)]
     L.nfa_sim_run_sa.argtypes = [_vp, ctypes.c_char_p, _i64, ctypes.c_int, ctypes.POINTER(_i64)]
+    L.nfa_sim_walk_set.restype = ctypes.c_uint64
+    L.nfa_sim_walk_set.argtypes = [_vp, ctypes.c_int, ctypes.c_uint64, ctypes.c_char_p, _i64, ctypes.c_uint32]
+    L.nfa_sim_valid_bits.restype = ctypes.c_uint64
+    L.nfa_sim_valid_bits.argtypes = [_vp, ctypes.c_int]
     return L
 
 
@@ -236,3 +240,52 @@ def test_shift_and_form_of_the_bench_programs(sim):
             assert info["has"], name
             for k, v in want.items():
                 assert info[k] <= v, (name, k, info)
+
+
+def test_a_segment_is_a_union_homomorphism_of_its_entry_set(sim):
+    """What the exact-entry fallback of the NFA tier rests on (sre_hip_nfa.hip sre_k_nfa_seg_matrix /
+    sre_k_nfa_exact_entries): stepping a thread set over a segment distributes over unions, so a segment's effect on
+    ANY entry set follows from its effect on the singletons — F(B u M) = F(B) u U_{i in M} F({i}).  Checked for the
+    plain slices and the shift-and form under every build option (32 / 64 bits, carry, masked, event accumulation,
+    explicit `.*?` thread), with and without look-ahead assertions, over random sets and segments."""
+    rng = random.Random(int(os.environ.get("SRE_FUZZ_SEED", "20261004")) + 41)
+    alphabet = b"abcx \n_.y@"
+    zoo = [[rb"(?:a|b)*a(?:a|b){7}@"], [rb"x[^y]*y(?:a|b)*a(?:a|b){7}@"], [rb"x.*y(?:a|b)*a(?:a|b){7}@$"],
+           [rb"(?:a|b)*a[ab]{20}c[^x]{30}@"], [rb"\b(?:a|b)*a(?:a|b){5}\b"], [rb"^x[^y]*y[ab]{9}"],
+           [rb"a", rb"ab", rb"c", rb"a(bc)", rb"e(f)", rb"gh", rb"A", rb"b", rb"BLAH", rb"\s+", rb"abcd", rb"bc"]]
+    progs = zoo + [[harness.random_regex(rng) for _ in range(1 if rng.random() < 0.8 else 2)] for _ in range(300)]
+    n = forms = 0
+    bad = []
+    for pats in progs:
+        with S.Pool() as pool:
+            try:
+                re = S.parse(pool, pats)
+            except Exception:
+                continue
+            prog = S.compile(pool, re)
+            for opts in (0, 128, 1, 2 + 16, 4, 4 + 8, 32 + 64):
+                why = ctypes.c_char_p()
+                h = sim.nfa_sim_build2(prog.h, opts, ctypes.byref(why))
+                if not h:
+                    continue
+                info = (ctypes.c_int32 * 10)()
+                sim.nfa_sim_sa_info(h, info)
+                for sa in ((0, 1) if info[0] else (0,)):
+                    valid = sim.nfa_sim_valid_bits(h, sa)
+                    forms += 1
+                    for _ in range(6):
+                        seg = bytes(rng.choice(alphabet) for _ in range(rng.choice([1, 5, 64, 200])))
+                        prev = rng.randrange(4)
+                        B = rng.getrandbits(64) & valid & rng.getrandbits(64)
+                        M = rng.getrandbits(64) & valid & rng.getrandbits(64) & rng.getrandbits(64)
+                        whole = sim.nfa_sim_walk_set(h, sa, B | M, seg, len(seg), prev)
+                        parts = sim.nfa_sim_walk_set(h, sa, B, seg, len(seg), prev)
+                        for i in range(64):
+                            if (M >> i) & 1:
+                                parts |= sim.nfa_sim_walk_set(h, sa, 1 << i, seg, len(seg), prev)
+                        n += 1
+                        if whole != parts:
+                            bad.append((pats, opts, sa, seg[:30], hex(B), hex(M), hex(whole), hex(parts)))
+                sim.nfa_sim_free(h)
+    assert not bad, (len(bad), bad[:3])
+    assert n > 3000 and forms > 400, (n, forms)
