@@ -9,6 +9,7 @@
  * tests/_build/; not part of, nor linked into, the product library.
  */
 #include "sre_nfa.h"
+#include <string.h>
 #include <stdint.h>
 
 extern "C" {
@@ -172,5 +173,98 @@ uint64_t nfa_sim_valid_bits(void *h, int sa)
     if (sa) return g->sa ? g->sa->valid : 0;
     return g->nbits >= 64 ? ~0ull : ((1ull << g->nbits) - 1);
 }
+
+
+/* One exec() of the Thompson WAVE kernel (sre_hip_vm.hip thompson_wave_run: lanes = threads, the live set a 64-bit
+ * mask, S' = ballot(pred[lane] & S & accept[byte]), 64 bytes a block) on the mask *S_io, with its STABLE RUNS: a
+ * byte that maps S to itself joins a 256-bit set kept for that S, and from the second such step in a row the bytes
+ * of the set that follow are skipped — inside the block by one ballot, across blocks 512 bytes at a time.
+ * ff == 0: without the skipping.  Returns 0 (match), -5 (declined), -2 (again); *skipped += bytes not stepped. */
+int64_t nfa_sim_thompson_wave(void *h, uint64_t *S_io, const uint8_t *input, int64_t size, int eof, int ff, int64_t *skipped)
+{
+    const sre_nfa_t *g = static_cast<sre_nfa_t *>(h);
+    uint64_t pred[64];
+    memset(pred, 0, sizeof(pred));
+    for (uint32_t i = 0; i < g->nbits; i++) {
+        const uint64_t f = g->follow[(size_t) (i / 8) * 256 + (1u << (i % 8))];
+        for (uint32_t q = 0; q < g->nbits; q++) {
+            if ((f >> q) & 1) pred[q] |= 1ull << i;
+        }
+    }
+    const uint64_t match = g->match_bits;
+    uint64_t       S = *S_io, stabS = 0;
+    uint32_t       stab[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool           stab_valid = false, streak = false;
+    auto member = [&](uint32_t c) { return ((stab[c >> 5] >> (c & 31)) & 1u) != 0; };
+    int64_t base = 0, rc = -100;
+    while (base < size && rc == -100) {
+        if (ff && streak && stab_valid && stabS == S) {
+            bool found = false;
+            while (!found && base < size) {
+                for (int k = 0; k < 8 && !found; k++) {
+                    for (int lane = 0; lane < 64 && !found; lane++) {
+                        const int64_t p = base + k * 64 + lane;
+                        if (p >= size || !member(input[p])) {
+                            *skipped += k * 64 + lane;
+                            base += k * 64 + lane;
+                            found = true;
+                        }
+                    }
+                }
+                if (!found) {
+                    *skipped += 512;
+                    base += 512;
+                }
+            }
+            if (base >= size) break;
+        }
+        const uint32_t nb = size - base < 64 ? (uint32_t) (size - base) : 64u;
+        uint32_t       i = 0;
+        while (i < nb) {
+            if (S == 0) {
+                rc = eof ? -5 : -2;
+                break;
+            }
+            if (S & match) {
+                rc = 0;
+                break;
+            }
+            const uint64_t T = S & g->accept[input[base + i]];
+            uint64_t       S1 = 0;
+            for (uint32_t q = 0; q < 64; q++) {
+                if (pred[q] & T) S1 |= 1ull << q;
+            }
+            i++;
+            if (S1 != S) {
+                S = S1;
+                streak = false;
+                continue;
+            }
+            if (streak && ff) {
+                const uint32_t b = input[base + i - 1];
+                if (!stab_valid || stabS != S) {
+                    memset(stab, 0, sizeof(stab));
+                    stabS = S;
+                    stab_valid = true;
+                }
+                stab[b >> 5] |= 1u << (b & 31);
+                if (i < nb) {
+                    uint32_t run = 0;
+                    while (i + run < nb && member(input[base + i + run])) run++;
+                    *skipped += run;
+                    i += run;
+                }
+            }
+            streak = true;
+        }
+        base += nb;
+    }
+    *S_io = S;
+    if (rc != -100) return rc;
+    if (eof && (S & match)) return 0;
+    return eof ? -5 : -2;
+}
+uint64_t nfa_sim_init0(void *h) { return static_cast<sre_nfa_t *>(h)->init[0]; }
+int nfa_sim_nassert(void *h) { return (int) static_cast<sre_nfa_t *>(h)->nassert; }
 
 }

@@ -42,6 +42,12 @@ def sim(lib):
     L.nfa_sim_walk_set.argtypes = [_vp, ctypes.c_int, ctypes.c_uint64, ctypes.c_char_p, _i64, ctypes.c_uint32]
     L.nfa_sim_valid_bits.restype = ctypes.c_uint64
     L.nfa_sim_valid_bits.argtypes = [_vp, ctypes.c_int]
+    L.nfa_sim_thompson_wave.restype = _i64
+    L.nfa_sim_thompson_wave.argtypes = [_vp, ctypes.POINTER(ctypes.c_uint64), ctypes.c_char_p, _i64, ctypes.c_int, ctypes.c_int,
+                                        ctypes.POINTER(_i64)]
+    L.nfa_sim_init0.restype = ctypes.c_uint64
+    L.nfa_sim_init0.argtypes = [_vp]
+    L.nfa_sim_nassert.argtypes = [_vp]
     return L
 
 
@@ -289,3 +295,77 @@ def test_a_segment_is_a_union_homomorphism_of_its_entry_set(sim):
                 sim.nfa_sim_free(h)
     assert not bad, (len(bad), bad[:3])
     assert n > 3000 and forms > 400, (n, forms)
+
+
+def test_thompson_wave_with_stable_runs_vs_oracle(sim):
+    """The Thompson wave kernel (sre_hip_vm.hip thompson_wave_run: lanes = threads, the live set a 64-bit mask, one
+    ballot per byte) with its stable runs — a byte that maps the set to itself joins a byte set kept for that set,
+    the bytes of the set that follow are skipped inside the block and 512 at a time across blocks — modelled on the
+    CPU (tests/nfa_sim.cpp nfa_sim_thompson_wave) with the skipping on and off, against the oracle's Thompson VM:
+    whole buffers, and buffers fed in chunks with the mask as the context (programs without ^: this VM's ^ is
+    local to the buffer of a call)."""
+    ora = harness.OracleEngine()
+    rng = random.Random(int(os.environ.get("SRE_FUZZ_SEED", "20261004")) + 43)
+    alphabet = b"abcx \n_."
+
+    def runs(total):
+        out = bytearray()
+        while len(out) < total:
+            out += bytes([rng.choice(alphabet)]) * rng.choice([1, 1, 2, 3, 9, 30, 70, 150, 700])
+        return bytes(out[:total])
+
+    zoo = [[rb"[a-z]+@[a-z]+\.[a-z]+"], [rb"a+b"], [rb"x(.*)y(.*)z"], [rb"(?:a|b)*c"], [rb"a.*b"], [rb"(a*)*x"], [rb"\n+a"],
+           [rb"[^x]+x", rb"a+_"], [rb"(?:aa)+b"], [rb"a{3,}b"], [rb"(?:.|\n)*x"], [rb"\s+\S"], [rb"(?:a|b)*a(?:a|b){7}_"]]
+    progs = zoo + [[harness.random_regex(rng) for _ in range(1 if rng.random() < 0.8 else 2)] for _ in range(500)]
+    n = chunked = 0
+    skipped = _i64(0)
+    bad = []
+    for pats in progs:
+        with S.Pool() as pool:
+            try:
+                re = S.parse(pool, pats)
+            except Exception:
+                continue
+            prog = S.compile(pool, re)
+            why = ctypes.c_char_p()
+            h = sim.nfa_sim_build(prog.h, ctypes.byref(why))
+            if not h:
+                continue
+            if sim.nfa_sim_nassert(h):
+                sim.nfa_sim_free(h)
+                continue                # (look-ahead programs keep the scalar VM)
+            for _ in range(4):
+                d = runs(rng.choice([1, 40, 300, 2000, 5000])) if rng.random() < 0.8 else b""
+                t = ora.thompson(prog)
+                want = t.exec(d, True)
+                t.close()
+                if want == S.SRE_ERROR:
+                    continue            # the reference's thread list overflows here (oracle guard)
+                for ff in (1, 0):
+                    m = ctypes.c_uint64(sim.nfa_sim_init0(h))
+                    got = sim.nfa_sim_thompson_wave(h, ctypes.byref(m), d, len(d), 1, ff, ctypes.byref(skipped))
+                    n += 1
+                    if got != want:
+                        bad.append((pats, d[:60], ff, got, want))
+                if not any(b"^" in p or b"\\A" in p for p in pats):
+                    sizes = [rng.choice([0, 1, 5, 64, 65, 200, 700]) for _ in range(rng.randrange(1, 8))]
+                    t = ora.thompson(prog)
+                    m = ctypes.c_uint64(sim.nfa_sim_init0(h))
+                    off, rcs = 0, []
+                    for sz in sizes + [len(d)]:
+                        chunk = d[off:off + sz]
+                        off += len(chunk)
+                        eof = 1 if off >= len(d) else 0
+                        a = t.exec(chunk, bool(eof))
+                        b = sim.nfa_sim_thompson_wave(h, ctypes.byref(m), chunk, len(chunk), eof, 1, ctypes.byref(skipped))
+                        rcs.append((a, b))
+                        if a != S.SRE_AGAIN or eof:
+                            break
+                    t.close()
+                    chunked += 1
+                    if any(a != b for a, b in rcs if a != S.SRE_ERROR):
+                        bad.append((pats, d[:60], "chunks", sizes, rcs))
+            sim.nfa_sim_free(h)
+    assert not bad, (len(bad), bad[:3])
+    assert n > 1500 and chunked > 500, (n, chunked)
+    assert skipped.value > 100000, skipped.value
