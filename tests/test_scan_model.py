@@ -63,9 +63,11 @@ def _runs(rng, alphabet, total):
 ZOO = [[rb"[a-z]+"], [rb"a+"], [rb"\bfoo\b"], [rb"foo$"], [rb"^foo"], [rb"\b"], [rb"$"], [rb"x*"], [rb"a*"], [rb"a(?:bc)?"],
        [rb"(a)(b)?"], [rb"a|ab|abc"], [rb"\w+\s"], [rb"[a-z]+@[a-z]+\.[a-z]+"], [rb"\b[a-z]+@[a-z]+\.[a-z]+\b"],
        [rb'"[^"]*"'], [rb"x(?:[^y]{3})*y"], [rb"\d+(?:\.\d+)?"], [rb"foo|foobar"], [rb"a", rb"ab", rb"c", rb"b"],
-       [rb"\s+", rb"[a-c]+x"], [rb"(?:ab)+"], [rb"a.*b"], [rb"\n+"], [rb"^", rb"a"]]
+       [rb"\s+", rb"[a-c]+x"], [rb"(?:ab)+"], [rb"a.*b"], [rb"\n+"], [rb"^", rb"a"],
+       # more than 16 byte classes: one input byte per table entry (an 8-bit index)
+       [rb"abcdefghijklmnopq+"], [rb"[a-c]+1|[d-f]+2|[g-i]+3|[j-l]+4|[m-o]+5|[p-r]+6|[s-u]+7|[v-x]+8|yz"], [rb"\b[0-9a-f]+\b"]]
 BODIES = [b"foo bar ", b"aaab", b"foo foo\nfoo\n", b"ab cd ", b"ab ", b'"ab" cde ', b"xabcabcy z", b"12.5 7 3.x ", b"foobar foo fooba ",
-          b"abccc", b"a", b"ababab \n"]
+          b"abccc", b"a", b"ababab \n", b"abcdefghijklmnopqqq abcdefghijklmnop ", b"abc1 def2ghi3 yz mno5x", b"dead beef 0x1f g00 "]
 
 
 def test_count_lane_model_vs_oracle(sim):
