@@ -41,6 +41,9 @@ struct Lane {
     uint32_t st = 0, fl = 0;
     uint32_t ev_kind = 0, ev_state = 0, ev_sym = 0, lm_state = 0, lm_sym = 0;
     int64_t  ev_pos = -1, ev_sp = -1, cur_sp = -1, lm_pos = -1, lm_sp = -1, count = 0, term_pos = -1;
+    /* the capture walker's anchor: a state of the match's search shortly in front of its event (-1 none) */
+    int64_t  anchor_pos = -1, ev_apos = -1, lm_apos = -1;
+    uint32_t anchor_state = 0, ev_astate = 0, lm_astate = 0;
     /* spans */
     int64_t  fcA_pos = -1, fcB_pos = -1, fc_sp0 = -1, lz_pos = -1;
     uint32_t fcA_len = 0, fcA_s0 = 0, fcB_len = 0, fcB_s0 = 0, lz_s0 = 0;
@@ -62,6 +65,8 @@ struct Lane {
         lm_sym = ev_sym;
         lm_pos = ev_pos;
         lm_sp = ev_sp;
+        lm_apos = ev_apos;
+        lm_astate = ev_astate;
         fl &= ~F_HAS_EV;
     }
     /* sre_hip_scan.hip slow_run<COUNT>, not warm */
@@ -90,6 +95,14 @@ struct Lane {
                 ev_sym = sym;
                 ev_pos = p;
                 ev_sp = cur_sp;
+                /* (strictly behind the search start: sre_hip_scan.hip slow_run) */
+                if (anchor_pos >= 0 && anchor_pos <= p && p - anchor_pos <= 256 && (cur_sp < 0 || anchor_pos > cur_sp)) {
+                    ev_apos = anchor_pos;
+                    ev_astate = anchor_state;
+                } else {
+                    ev_apos = -1;
+                    ev_astate = 0;
+                }
             }
             st = t2 & 0xffu;
             if (st != 0) {
@@ -119,6 +132,7 @@ struct Lane {
             st = d->init[variant_of(data[cur_sp - 1])];
             p = cur_sp;
             if (p > p_to && p_to <= n) fl |= F_SKIP_NEXT;
+            anchor_pos = -1;        /* the span's entry state belonged to the previous search */
         }
     }
     SpanResult resolve(int64_t gpos, uint32_t len, uint32_t s0, int64_t sp0, int64_t p0_pos, uint32_t p0_state, uint32_t p0_sym) const
@@ -235,6 +249,9 @@ struct Lane {
                 lm_state = r.last_state;
                 lm_sym = r.last_sym;
                 lm_sp = r.last_sp;
+                const bool anchored = r.last_sp < fcB_pos && r.last_pos - fcB_pos <= 256;
+                lm_apos = anchored ? fcB_pos : -1;
+                lm_astate = anchored ? fcB_s0 : 0u;
             }
             cur_sp = r.sp;
             fl &= ~F_SP_DIRTY;
@@ -249,6 +266,9 @@ struct Lane {
                 ev_sym = r.pend_sym;
                 ev_kind = tr2[r.pend_state * nsym + r.pend_sym] >> 8;
                 ev_sp = cur_sp;
+                const bool anchored = cur_sp < lz_pos;
+                ev_apos = anchored ? lz_pos : -1;
+                ev_astate = anchored ? lz_s0 : 0u;
             }
         }
     }
@@ -280,6 +300,8 @@ struct Lane {
                     cur = e / SRE_FAST_ROW_BYTES;
                 }
             }
+            anchor_pos = base;
+            anchor_state = st;
             if (exact) {
                 settle();
                 slow_run(base, end);
@@ -291,6 +313,7 @@ struct Lane {
         }
         if (!f(F_FINISHED)) {
             settle();
+            anchor_pos = -1;
             slow_run(n, n + 1);
         }
         settle();
@@ -305,7 +328,8 @@ extern "C" {
  * One COUNT lane over the whole stream.  span: 64 (round path), 16 (group path), 0 (every byte on the exact
  * path).  out[0] = count, out[1] = end of the last completed match (-1 none), out[2] = start of its search
  * (-1 unknown), out[3] = flags (8: the iteration ended with SRE_ERROR, 16: unresolved), out[4] = bytes taken
- * by fast entries, out[5] = 1 when the table has FRESH states.
+ * by fast entries, out[5] = 1 when the table has FRESH states, out[6] / out[7] = the anchor handed to the capture
+ * walker with the last match (position, state; -1: none), out[8] = the position of the last match's event.
  */
 void scan_sim_count(void *dv, const uint8_t *data, int64_t n, int span, int64_t *out)
 {
@@ -336,6 +360,24 @@ void scan_sim_count(void *dv, const uint8_t *data, int64_t n, int span, int64_t 
     out[3] = L.fl & (F_ERROR | F_UNRESOLVED);
     out[4] = L.fast_bytes;
     out[5] = L.F.any_fresh;
+    out[6] = L.f(F_LM_VALID) ? L.lm_apos : -1;
+    out[7] = L.lm_astate;
+    out[8] = L.f(F_LM_VALID) ? L.lm_pos : -1;
+}
+
+/* the state of the ONE search that starts at sp, in front of position q (no restarts: the automaton alone) */
+uint32_t scan_sim_state_at(void *dv, const uint8_t *data, int64_t sp, int64_t q)
+{
+    const sre_dfa_t *d = static_cast<const sre_dfa_t *>(dv);
+    const uint32_t   word_restart = d->init[SRE_DFA_INIT_RESTART_WORD] != d->init[SRE_DFA_INIT_RESTART];
+    uint32_t         v = SRE_DFA_INIT_START;
+    if (sp > 0) {
+        const uint32_t c = data[sp - 1];
+        v = c == '\n' ? 1u : (word_restart && sre_isword(c)) ? 3u : 2u;
+    }
+    uint32_t st = d->init[v];
+    for (int64_t p = sp; p < q && st != 0; p++) st = d->t(st, d->cls_map[data[p]]).next;
+    return st;
 }
 
 }
